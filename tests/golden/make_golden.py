@@ -1,0 +1,139 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE on CPU.
+
+Only runs where ``/root/reference`` is mounted (the build container); the GPU box has no
+reference, which is why the outputs are committed as small ``.npz`` files.  Nothing here is
+imported by the product.  Usage:  ``python tests/golden/make_golden.py``
+
+Fixtures (all float32 unless noted):
+  upsample.npz      ddsp.core.upsample                                   core.py:66
+  phase.npz         the inlined phase accumulation of Sins/CombSub       vocoder.py:564-575
+  filter_*.npz      ddsp.core.frequency_filter, three window modes       core.py:273
+  sins_*.npz        Sins.forward with captured controls + injected noise vocoder.py:556-611
+  combsub_*.npz     CombSub.forward, same                                vocoder.py:811-862
+"""
+import os
+import sys
+from unittest import mock
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for m in ["transformers", "pyworld", "parselmouth", "torchcrepe", "resampy", "fairseq",
+              "torchaudio", "torchaudio.transforms", "gin", "local_attention", "librosa",
+              "librosa.sequence", "librosa.util", "librosa.filters", "librosa.core", "soundfile"]:
+        sys.modules.setdefault(m, MagicMock())
+    import ddsp.core as core
+    import ddsp.vocoder as vocoder
+    return core, vocoder
+
+
+def main():
+    from oracle import ddsp_oracle as O
+    core, V = import_reference()
+    torch.manual_seed(0)
+    sr, hop = 44100, 512
+
+    # ---- upsample -----------------------------------------------------------------
+    g = torch.Generator().manual_seed(11)
+    sig = torch.rand(2, 9, 3, generator=g) * 700 + 65
+    np.savez(os.path.join(HERE, "upsample.npz"), sig=sig.numpy(), hop=np.int64(hop),
+             out=core.upsample(sig, hop).numpy())
+    sig = torch.randn(1, 5, 1, generator=g)
+    np.savez(os.path.join(HERE, "upsample_hop64.npz"), sig=sig.numpy(), hop=np.int64(64),
+             out=core.upsample(sig, 64).numpy())
+
+    # ---- phase ----------------------------------------------------------------------
+    f0 = torch.from_numpy(O.synth_f0(3, 40, sr, hop, seed=5))
+    ip = torch.tensor([0.3, -2.0, 5.5]).reshape(3, 1, 1)
+    out = {"f0_frames": f0.numpy(), "initial_phase": ip.numpy().reshape(3)}
+    for infer in (True, False):
+        for use_ip in (False, True):
+            f0u = core.upsample(f0, hop)
+            if infer:
+                x = torch.cumsum(f0u.double() / sr, axis=1)
+            else:
+                x = torch.cumsum(f0u / torch.tensor(sr), axis=1)
+            if use_ip:
+                x += ip.to(x) / 2 / np.pi
+            x = x - torch.round(x)
+            x = x.to(f0u)
+            phase = 2 * np.pi * x
+            tag = f"infer{int(infer)}_ip{int(use_ip)}"
+            out["x_" + tag] = x.squeeze(-1).numpy()
+            out["phase_frames_" + tag] = phase[:, ::hop, 0].numpy()
+    np.savez(os.path.join(HERE, "phase.npz"), **out)
+
+    # ---- frequency_filter, three modes -------------------------------------------------
+    for n_mag, Fr, h in ((65, 10, 512), (129, 7, 256), (256, 12, 512)):
+        g = torch.Generator().manual_seed(100 + n_mag)
+        B = 2
+        T = Fr * h
+        audio = torch.rand(B, T, generator=g) * 2 - 1
+        c = torch.randn(B, Fr, n_mag, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, h, seed=n_mag))
+        f0f[1] = f0f[1] * 0 + 500.0          # constant high f0: exercises the w>1 clamp quirk
+        gd = np.pi * torch.tanh(c)
+        ap = torch.exp(1.j * torch.cumsum(gd, axis=-1))
+        mag = torch.exp(c)
+        hw = 1.5 * sr / (f0f + 1e-3)
+        np.savez(os.path.join(HERE, f"filter_n{n_mag}.npz"),
+                 audio=audio.numpy(), ctrl=c.numpy(), f0_frames=f0f.numpy(),
+                 half_width=hw.numpy()[..., 0],
+                 resp_re=ap.real.numpy(), resp_im=ap.imag.numpy(), mag=mag.numpy(),
+                 y_roll=core.frequency_filter(audio, ap, hann_window=False).numpy(),
+                 y_hann=core.frequency_filter(audio, torch.complex(mag, torch.zeros_like(mag)),
+                                              hann_window=True).numpy(),
+                 y_dyn=core.frequency_filter(audio, torch.complex(mag, torch.zeros_like(mag)),
+                                             hann_window=True, half_width_frames=hw).numpy(),
+                 ir_roll=core.frequency_impulse_response(ap, hann_window=False).numpy(),
+                 ir_hann=core.frequency_impulse_response(torch.complex(mag, torch.zeros_like(mag))).numpy(),
+                 ir_dyn=core.frequency_impulse_response(torch.complex(mag, torch.zeros_like(mag)),
+                                                        half_width_frames=hw).numpy())
+
+    # ---- module forwards with captured controls and injected noise ------------------------
+    def run_module(kind, sizes, B, Fr, seed, infer=True):
+        torch.manual_seed(seed)
+        if kind == "sins":
+            model = V.Sins(sr, hop, sizes[0], sizes[1], sizes[2], n_unit=64, n_spk=1).eval()
+        else:
+            model = V.CombSub(sr, hop, sizes[0], sizes[1], sizes[2], n_unit=64, n_spk=1).eval()
+        # random-init Unit2Control emits small controls; widen them so exp()/tanh() are exercised
+        with torch.no_grad():
+            model.unit2ctrl.dense_out.weight_g.mul_(4.0)
+        g = torch.Generator().manual_seed(seed + 1)
+        units = torch.randn(B, Fr, 64, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=seed + 2))
+        f0f[0] = torch.clamp(f0f[0] * 2.2, 65, 800)      # one utterance well above 259 Hz
+        vol = torch.rand(B, Fr, 1, generator=g) * 0.1
+        u01 = torch.rand(B, Fr * hop, generator=g)
+        cap = {}
+        hk = model.unit2ctrl.register_forward_hook(lambda mod, i, o: cap.update(ctrls=o[0]))
+        with torch.no_grad(), mock.patch("torch.rand_like", side_effect=lambda t: u01.to(t)):
+            signal, hidden, (harm, nz) = model(units, f0f, vol, infer=infer)
+        hk.remove()
+        ctrls = {k: v.detach().numpy() for k, v in cap["ctrls"].items()}
+        return dict(f0_frames=f0f.numpy(), noise=(u01 * 2 - 1).numpy(),
+                    signal=signal.numpy(), harmonic=harm.numpy(), noise_out=nz.numpy(),
+                    sizes=np.array(sizes), **{"ctrl_" + k: v for k, v in ctrls.items()})
+
+    np.savez(os.path.join(HERE, "sins_h256.npz"), **run_module("sins", (256, 256, 256), 2, 24, 7))
+    np.savez(os.path.join(HERE, "sins_h128.npz"), **run_module("sins", (128, 256, 256), 1, 16, 8))
+    np.savez(os.path.join(HERE, "sins_h40_train.npz"), **run_module("sins", (40, 65, 129), 2, 10, 9, infer=False))
+    np.savez(os.path.join(HERE, "combsub_256.npz"), **run_module("combsub", (256, 256, 256), 2, 24, 17))
+    np.savez(os.path.join(HERE, "combsub_128.npz"), **run_module("combsub", (256, 128, 256), 1, 16, 18))
+    np.savez(os.path.join(HERE, "combsub_small_train.npz"), **run_module("combsub", (65, 129, 33), 2, 10, 19, infer=False))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()
