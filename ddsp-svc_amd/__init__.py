@@ -1,0 +1,12 @@
+"""ddsp_svc_amd -- MI355X-native DDSP harmonic-plus-noise synthesiser (drop-in for the
+Sins/CombSub forward pass of yxlllc/DDSP-SVC).  Import name: ``ddsp_svc_amd`` (the directory is
+``ddsp-svc_amd/``; ``ddsp_svc_amd.py`` at the repo root aliases it).
+
+  core      -- ddsp/core.py functions (upsample, frequency_filter, ...) on HIP kernels
+  synth     -- phase state, exciters, fused Sins / CombSub DSP tails
+  vocoder   -- nn.Module drop-ins + patch_reference()
+  sharding  -- utterance sharding across the GPUs of a node (+ optional RCCL gather)
+"""
+from . import _ffi, build, core, synth  # noqa: F401
+
+__version__ = "0.1.0"

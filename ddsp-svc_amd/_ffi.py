@@ -1,0 +1,89 @@
+"""ctypes binding of libddsp_hip.so (C ABI declared in include/ddsp_hip.h).
+
+The library is the only compute path: there is no CPU fallback.  ``lib()`` raises if the shared
+object cannot be loaded (or built with hipcc), and ``check_device`` rejects host tensors.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import build as _build
+
+c_int, c_long, c_float, c_double, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
+                                              ctypes.c_double, ctypes.c_size_t)
+P = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ddsp_hip.h one to one
+SIGNATURES = {
+    "ddsp_hip_version": (c_int, []),
+    "ddsp_hip_error_string": (ctypes.c_char_p, [c_int]),
+    "ddsp_hip_upsample": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "ddsp_hip_remove_above_fmax": (c_int, [P, P, c_long, c_int, c_float, c_int, P, P]),
+    "ddsp_hip_phase": (c_int, [P, P, c_int, c_int, c_int, c_double, c_int, P, P, P, P, P]),
+    "ddsp_hip_ir_table_bytes": (c_size_t, [c_int]),
+    "ddsp_hip_ir_table": (c_int, [c_int, P, P]),
+    "ddsp_hip_allpass_response": (c_int, [P, c_long, c_long, c_int, P, P, P]),
+    "ddsp_hip_impulse_response": (c_int, [P, c_long, P, c_long, c_int, c_float, c_int, P, c_long, c_int, P, P, P]),
+    "ddsp_hip_fft_convolve": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "ddsp_hip_sins_synth": (c_int, [P, P, P, P, c_long, P, c_long, P, c_long, P, c_int,
+                                    c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_int,
+                                    P, P, P, P, P, P, c_size_t, c_int, P]),
+    "ddsp_hip_combsub_synth": (c_int, [P, P, P, P, c_long, P, c_long, P, c_long, P, c_int,
+                                       c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_int,
+                                       P, P, P, P, P, P, P, c_size_t, c_int, P]),
+    "ddsp_hip_synth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddsp_hip_combtooth": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_int, P, P]),
+    "ddsp_hip_sinusoid_bank": (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_double, c_int, P, P]),
+}
+
+MODE_ROLL, MODE_HANN, MODE_DYNAMIC = 0, 1, 2
+ACT_NONE, ACT_EXP = 0, 1
+FIR_AUTO, FIR_SIMPLE, FIR_MFMA = 0, 1, 2
+
+_LIB = None
+_LOCK = threading.Lock()
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every exported entry point; raises if a symbol is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)            # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def lib():
+    """The loaded libddsp_hip.so.  Built in-tree with hipcc on first use if absent."""
+    global _LIB
+    if _LIB is None:
+        with _LOCK:
+            if _LIB is None:
+                path = _build.LIB
+                if not os.path.exists(path):
+                    path = _build.build()
+                _LIB = bind(ctypes.CDLL(path))
+    return _LIB
+
+
+def check_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ddsp_svc_amd: tensors must live on the MI355X (got a %s tensor); "
+                               "this package has no CPU path" % t.device.type)
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def check(code):
+    if code != 0:
+        msg = lib().ddsp_hip_error_string(code)
+        raise RuntimeError("libddsp_hip: %s (code %d)" % (msg.decode() if msg else "?", code))

@@ -1,0 +1,127 @@
+"""Drop-in for the functions of the reference's ``ddsp/core.py`` that sit on the synthesis path
+(same names, positional order and defaults), computed by the HIP kernels of libddsp_hip.so.
+
+Reference lines are cited per function.  All tensors must be float32 (complex64 for responses)
+on the GPU; errors mirror the reference (``ValueError`` on batch mismatch / bad padding).
+"""
+import math
+
+import torch
+
+from . import _ffi
+from ._ffi import ptr
+
+_TABLES = {}
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ir_table(n_mag, device):
+    """Cosine/sine/Hann basis for ``n_mag`` bins, built once per (device, n_mag) on the GPU."""
+    key = (str(device), int(n_mag))
+    tab = _TABLES.get(key)
+    if tab is None:
+        L = _ffi.lib()
+        nbytes = L.ddsp_hip_ir_table_bytes(int(n_mag))
+        tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _ffi.check_device(tab)
+        _ffi.check(L.ddsp_hip_ir_table(int(n_mag), ptr(tab), _ffi.stream_of(tab)))
+        _TABLES[key] = tab
+    return tab
+
+
+def get_fft_size(frame_size, ir_size, power_of_2=True):
+    """core.py:47-63 (kept for API parity; the HIP path has no FFT size)."""
+    convolved = ir_size + frame_size - 1
+    return int(2 ** math.ceil(math.log2(convolved))) if power_of_2 else convolved
+
+
+def upsample(signal, factor):
+    """core.py:66-70: ``[B,F,C] -> [B,F*factor,C]`` linear interpolation, last frame held."""
+    _ffi.check_device(signal)
+    sig = _f32c(signal)
+    B, F, C = sig.shape
+    factor = int(factor)
+    out = torch.empty(B, F * factor, C, dtype=torch.float32, device=sig.device)
+    _ffi.check(_ffi.lib().ddsp_hip_upsample(ptr(sig), B, F, C, factor, ptr(out), _ffi.stream_of(sig)))
+    return out
+
+
+def remove_above_fmax(amplitudes, pitch, fmax, level_start=1):
+    """core.py:73-77: ``amplitudes * ((pitch*k < fmax) + 1e-7)``."""
+    _ffi.check_device(amplitudes, pitch)
+    a = _f32c(amplitudes)
+    H = a.shape[-1]
+    rows = a.numel() // H
+    p = _f32c(pitch.expand(*a.shape[:-1], 1))
+    out = torch.empty_like(a)
+    _ffi.check(_ffi.lib().ddsp_hip_remove_above_fmax(ptr(a), ptr(p), rows, H, float(fmax), int(level_start),
+                                                     ptr(out), _ffi.stream_of(a)))
+    return out
+
+
+def crop_and_compensate_delay(audio, audio_size, ir_size, padding="same", delay_compensation=-1):
+    """core.py:80-117 (pure slicing; ``fft_convolve`` here already returns the cropped signal)."""
+    if padding == "valid":
+        crop_size = ir_size + audio_size - 1
+    elif padding == "same":
+        crop_size = audio_size
+    else:
+        raise ValueError("Padding must be 'valid' or 'same', instead of {}.".format(padding))
+    total = int(audio.shape[-1])
+    crop = total - crop_size
+    start = ir_size // 2 if delay_compensation < 0 else delay_compensation
+    end = crop - start
+    return audio[:, start:-end]
+
+
+def frequency_impulse_response(magnitudes, hann_window=True, half_width_frames=None):
+    """core.py:254-270: one-sided response ``[B,F,n]`` (complex or real) -> taps ``[B,F,2(n-1)]``
+    in causal form, windowed as the flags select."""
+    _ffi.check_device(magnitudes, half_width_frames)
+    if magnitudes.is_complex():
+        re, im = _f32c(magnitudes.real), _f32c(magnitudes.imag)
+    else:
+        re, im = _f32c(magnitudes), None
+    B, F, n = re.shape
+    N = 2 * (n - 1)
+    if not hann_window:
+        mode, hw = _ffi.MODE_ROLL, None
+    elif half_width_frames is None:
+        mode, hw = _ffi.MODE_HANN, None
+    else:
+        mode, hw = _ffi.MODE_DYNAMIC, _f32c(half_width_frames.expand(B, F, 1))
+    taps = torch.empty(B, F, N, dtype=torch.float32, device=re.device)
+    tab = ir_table(n, re.device)
+    _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(re), n, ptr(im), n, _ffi.ACT_NONE, 1.0, mode, ptr(hw),
+                                                    B * F, n, ptr(tab), ptr(taps), _ffi.stream_of(re)))
+    return taps
+
+
+def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
+    """core.py:120-182: time-varying FIR of ``audio [B,T]`` with ``impulse_response [B,F,N]``
+    (or ``[B,N]`` for a single filter), ``T = F*hop``; returns ``[B,T]``."""
+    _ffi.check_device(audio, impulse_response)
+    if impulse_response.dim() == 2:
+        impulse_response = impulse_response.unsqueeze(1)
+    Bi, F, N = impulse_response.shape
+    B, T = audio.shape
+    if B != Bi:
+        raise ValueError("Batch size of audio ({}) and impulse response ({}) must be the same.".format(B, Bi))
+    hop = int(T / F)
+    if hop * F != T:
+        raise ValueError("audio length {} is not a multiple of the {} impulse-response frames".format(T, F))
+    x, ir = _f32c(audio), _f32c(impulse_response)
+    out = torch.empty(B, T, dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ptr(x), 0, ptr(ir), None, ptr(out), None, B, F, hop, N, int(impl),
+                                                _ffi.stream_of(x)))
+    return out
+
+
+def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None):
+    """core.py:273-280."""
+    return fft_convolve(audio, frequency_impulse_response(magnitudes, hann_window, half_width_frames))

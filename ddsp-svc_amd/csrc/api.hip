@@ -1,0 +1,241 @@
+// C ABI of libddsp_hip.so (declared in include/ddsp_hip.h): argument checks, workspace carving and
+// the launch sequences of the two synthesiser tails.  No allocation, no synchronisation.
+#include "../../include/ddsp_hip.h"
+#include "kernels.h"
+
+using namespace ddsp;
+
+namespace {
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int finish() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Carver {
+  char* base;
+  size_t size, used;
+  bool ok;
+  Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n), used(0), ok(p != nullptr || n == 0) {}
+  template <class T> T* take(size_t count) {
+    size_t off = align_up(used, 256);
+    size_t end = off + count * sizeof(T);
+    if (end > size) { ok = false; used = end; return nullptr; }
+    used = end;
+    return reinterpret_cast<T*>(base + off);
+  }
+};
+
+struct SynthWs {
+  float *buf0, *buf1, *taps, *re, *im, *hw, *harm;
+};
+
+size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
+  const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_max - 1);
+  w.buf0 = c.take<float>(BT);
+  w.buf1 = c.take<float>(BT);
+  w.harm = c.take<float>(BT);
+  w.taps = c.take<float>(R * N);
+  w.re = c.take<float>(R * n_max);
+  w.im = c.take<float>(R * n_max);
+  w.hw = c.take<float>(R);
+  return align_up(c.used, 256);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddsp_hip_version(void) { return DDSP_HIP_VERSION; }
+
+const char* ddsp_hip_error_string(int code) {
+  switch (code) {
+    case 0: return "success";
+    case DDSP_HIP_EINVAL: return "ddsp_hip: invalid argument (null pointer or non-positive size)";
+    case DDSP_HIP_EHOP: return "ddsp_hip: hop > 2048 is not supported by the phase scan";
+    case DDSP_HIP_ESHAPE: return "ddsp_hip: shape not supported by the requested kernel";
+    case DDSP_HIP_EWS: return "ddsp_hip: workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ddsp_hip: unknown error";
+  }
+}
+
+int ddsp_hip_upsample(const float* sig, int B, int F, int C, int hop, float* out, void* stream) {
+  if (B < 0 || F <= 0 || C <= 0 || hop <= 0) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!sig || !out) return DDSP_HIP_EINVAL;
+  launch_upsample(sig, B, F, C, hop, out, S(stream));
+  return finish();
+}
+
+int ddsp_hip_remove_above_fmax(const float* amps, const float* pitch, long rows, int H, float fmax, int level_start,
+                               float* out, void* stream) {
+  if (rows < 0 || H <= 0) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!amps || !pitch || !out) return DDSP_HIP_EINVAL;
+  launch_remove_above_fmax(amps, pitch, rows, H, fmax, level_start, out, S(stream));
+  return finish();
+}
+
+int ddsp_hip_phase(const float* f0_frames, const float* initial_phase, int B, int F, int hop, double sr, int infer,
+                   double* frame_sums, double* phase0, float* phase_frames, float* x_or_null, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !frame_sums || !phase0) return DDSP_HIP_EINVAL;
+  if (launch_phase(f0_frames, initial_phase, B, F, hop, sr, infer, frame_sums, phase0, phase_frames, x_or_null,
+                   S(stream)) != 0)
+    return DDSP_HIP_EHOP;
+  return finish();
+}
+
+size_t ddsp_hip_ir_table_bytes(int n_mag) { return n_mag >= 2 ? ir_table_floats(n_mag) * sizeof(float) : 0; }
+
+int ddsp_hip_ir_table(int n_mag, float* table, void* stream) {
+  if (n_mag < 2 || !table) return DDSP_HIP_EINVAL;
+  launch_ir_table(n_mag, table, S(stream));
+  return finish();
+}
+
+int ddsp_hip_allpass_response(const float* c, long ld, long rows, int n_mag, float* re, float* im, void* stream) {
+  if (rows < 0 || n_mag < 2 || ld < n_mag) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!c || !re || !im) return DDSP_HIP_EINVAL;
+  launch_allpass_response(c, ld, rows, n_mag, re, im, S(stream));
+  return finish();
+}
+
+int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* resp_im, long ld_im, int act, float scale,
+                              int mode, const float* half_width, long rows, int n_mag, const float* table, float* taps,
+                              void* stream) {
+  if (rows < 0 || n_mag < 2 || ld_re < n_mag || (resp_im && ld_im < n_mag)) return DDSP_HIP_EINVAL;
+  if (mode < 0 || mode > 2 || act < 0 || act > 1) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!resp_re || !table || !taps) return DDSP_HIP_EINVAL;
+  if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
+  launch_ir_gemm(resp_re, ld_re, resp_im, ld_im, act, scale, table, mode, half_width, rows, n_mag, taps, S(stream));
+  return finish();
+}
+
+int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, const float* addend, float* out,
+                          float* out_plain, int B, int F, int hop, int N, int impl, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!audio || !taps || !out) return DDSP_HIP_EINVAL;
+  int used = launch_fir(audio, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, impl, S(stream));
+  if (used < 0) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_combtooth(const float* f0_frames, const float* initial_phase, const double* phase0, int B, int F, int hop,
+                       double sr, int infer, float* out, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !out) return DDSP_HIP_EINVAL;
+  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, out, S(stream)) != 0) return DDSP_HIP_EHOP;
+  return finish();
+}
+
+int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,
+                           long ld_amp, int B, int F, int hop, int H, double sr, int infer, float* out, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || H <= 0 || ld_amp < H || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !c_amp || !out) return DDSP_HIP_EINVAL;
+  int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, out, S(stream));
+  if (r == -1) return DDSP_HIP_EHOP;
+  if (r == -2) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max) {
+  if (B <= 0 || F <= 0 || hop <= 0 || n_max < 2) return 0;
+  Carver c(nullptr, (size_t)-1);
+  c.base = nullptr;
+  SynthWs w;
+  return carve_synth(c, B, F, hop, n_max, w);
+}
+
+int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,
+                        long ld_amp, const float* c_gd, long ld_gd, const float* c_nz, long ld_nz, const float* noise,
+                        int noise_is_u01, int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,
+                        const float* table_ap, const float* table_nz, float* signal, float* harmonic_or_null,
+                        float* noise_out_or_null, void* ws, size_t ws_bytes, int fir_impl, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || H <= 0 || n_ap < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (ld_amp < H || ld_gd < n_ap || ld_nz < n_nz) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !c_amp || !c_gd || !c_nz || !noise || !table_ap || !table_nz || !signal)
+    return DDSP_HIP_EINVAL;
+  const int n_max = n_ap > n_nz ? n_ap : n_nz;
+  Carver c(ws, ws_bytes);
+  SynthWs w;
+  carve_synth(c, B, F, hop, n_max, w);
+  if (!c.ok) return DDSP_HIP_EWS;
+  hipStream_t st = S(stream);
+  const long R = (long)B * F;
+  float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
+  // exciter: sinusoid bank (vocoder.py:585-594)
+  int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
+  if (r == -1) return DDSP_HIP_EHOP;
+  if (r == -2) return DDSP_HIP_ESHAPE;
+  // harmonic = all-pass(group delay) applied to the sinusoids (vocoder.py:597-600)
+  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
+  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                 w.taps, st);
+  if (launch_fir(w.buf0, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
+    return DDSP_HIP_ESHAPE;
+  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise, added to harmonic (vocoder.py:603-609)
+  launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                 n_nz, w.taps, st);
+  if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                 st) < 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_gd,
+                           long ld_gd, const float* c_harm, long ld_harm, const float* c_nz, long ld_nz,
+                           const float* noise, int noise_is_u01, int B, int F, int hop, double sr, int infer, int n_ap,
+                           int n_harm, int n_nz, const float* table_ap, const float* table_harm, const float* table_nz,
+                           float* signal, float* harmonic_or_null, float* noise_out_or_null, void* ws, size_t ws_bytes,
+                           int fir_impl, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || n_ap < 2 || n_harm < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (ld_gd < n_ap || ld_harm < n_harm || ld_nz < n_nz) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !c_gd || !c_harm || !c_nz || !noise || !table_ap || !table_harm || !table_nz || !signal)
+    return DDSP_HIP_EINVAL;
+  int n_max = n_ap > n_nz ? n_ap : n_nz;
+  if (n_harm > n_max) n_max = n_harm;
+  Carver c(ws, ws_bytes);
+  SynthWs w;
+  carve_synth(c, B, F, hop, n_max, w);
+  if (!c.ok) return DDSP_HIP_EWS;
+  hipStream_t st = S(stream);
+  const long R = (long)B * F;
+  float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
+  // exciter: combtooth (vocoder.py:839-840)
+  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st) != 0) return DDSP_HIP_EHOP;
+  // all-pass (vocoder.py:843-846)
+  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
+  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                 w.taps, st);
+  if (launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
+    return DDSP_HIP_ESHAPE;
+  // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851)
+  launch_half_width(f0_frames, R, (float)sr, w.hw, st);
+  launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, w.hw, R, n_harm,
+                 w.taps, st);
+  if (launch_fir(w.buf1, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+    return DDSP_HIP_ESHAPE;
+  // noise branch + mix (vocoder.py:854-860)
+  launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                 n_nz, w.taps, st);
+  if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                 st) < 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Shared device helpers for the DDSP hot-path kernels (gfx950 / CDNA4, wave64).
+// Compiled with -ffp-contract=off: every fused multiply-add below is written explicitly, because a
+// few expressions must round exactly like the reference's CPU ATen kernels do (see aten_upsample_at).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DDSP_WAVE 64
+
+namespace ddsp {
+
+constexpr float kPiF = 3.14159265358979323846f;       // fl32(pi)  = 0x40490FDB
+constexpr float kTwoPiF = 6.28318530717958647692f;    // fl32(2pi) = 0x40C90FDB
+constexpr double kPiD = 3.14159265358979323846;
+
+// What ddsp/core.py:66-70 evaluates for output position t of a control row of F frames:
+// F.interpolate(cat(sig, last), size=F*hop+1, mode='linear', align_corners=True)[..., :-1].
+// ATen: scale = float(F)/float(F*hop); src = scale*float(t); i0 = min(floor(src), F);
+// l1 = src-i0; l0 = 1-l1; i1 = i0 + (i0 < F); out = fma(l0, in[i0], fl32(l1*in[i1]))
+// (the last form probed bit-exact against torch 2.10 CPU).  Row index F is the held last frame.
+struct Upsampler {
+  float scale;
+  int F;
+  __device__ __forceinline__ void locate(long t, int& i0, int& i1, float& l0, float& l1) const {
+    float src = scale * (float)t;
+    int k = (int)src;
+    if (k > F) k = F;
+    l1 = src - (float)k;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    l0 = 1.0f - l1;
+    int k1 = k + (k < F ? 1 : 0);
+    i0 = k < F - 1 ? k : F - 1;
+    i1 = k1 < F - 1 ? k1 : F - 1;
+  }
+  __device__ __forceinline__ float at(const float* __restrict__ row, long stride, long t) const {
+    int i0, i1;
+    float l0, l1;
+    locate(t, i0, i1, l0, l1);
+    float a = row[(long)i0 * stride];
+    float b = row[(long)i1 * stride];
+    return fmaf(l0, a, l1 * b);
+  }
+};
+
+// Phase bookkeeping shared by the scan kernels and every consumer that re-derives x[t].
+// infer != 0: terms and running sum in float64 (vocoder.py:566); infer == 0: float32 terms, float64
+// running sum rounded to float32 per output as ATen's CPU cumsum does, then float32 wrap (vocoder.py:568).
+struct PhaseCfg {
+  double sr_d;
+  float sr_f;
+  int infer;
+  int has_ip;
+  __device__ __forceinline__ double term(float f0u) const {
+    return infer ? ((double)f0u / sr_d) : (double)(f0u / sr_f);
+  }
+  // running (unwrapped) sum P in cycles -> wrapped float32 x, vocoder.py:569-572
+  __device__ __forceinline__ float wrap(double P, float ip) const {
+    if (infer) {
+      double x = P;
+      if (has_ip) x = x + ((double)ip / 2.0) / kPiD;
+      x = x - rint(x);
+      return (float)x;
+    }
+    float x = (float)P;
+    if (has_ip) x = x + (ip / 2.0f) / kPiF;
+    return x - rintf(x);
+  }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// exclusive prefix over the 64 lanes of a wave
+__device__ __forceinline__ double wave_excl_scan(double v, int lane) {
+  double inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double u = __shfl_up(inc, d);
+    if (lane >= d) inc += u;
+  }
+  return inc - v;
+}
+
+// torch.sinc on a float32 tensor: sin(fl32(pi32*z)) / fl32(pi32*z), 1 at z == 0 (vocoder.py:839)
+__device__ __forceinline__ float sinc_f32(float z) {
+  if (z == 0.0f) return 1.0f;
+  float p = kPiF * z;
+  return sinf(p) / p;
+}
+
+}  // namespace ddsp

@@ -1,0 +1,27 @@
+// host-side launcher prototypes shared between the translation units of libddsp_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace ddsp {
+int spl_for_hop(int hop);
+void launch_upsample(const float* sig, int B, int F, int C, int hop, float* out, hipStream_t st);
+void launch_remove_above_fmax(const float* amps, const float* pitch, long rows, int H, float fmax, int level_start,
+                              float* out, hipStream_t st);
+int launch_phase(const float* f0_frames, const float* initial_phase, int B, int F, int hop, double sr, int infer,
+                 double* frame_sums, double* phase0, float* phase_frames, float* x_or_null, hipStream_t st);
+int launch_combtooth(const float* f0_frames, const float* initial_phase, int B, int F, int hop, double sr, int infer,
+                     const double* phase0, float* out, hipStream_t st);
+int launch_sins_bank(const float* f0_frames, const float* initial_phase, const float* c_amp, long ld_amp, int B, int F,
+                     int hop, int H, double sr, int infer, const double* phase0, float* out, hipStream_t st);
+size_t ir_table_floats(int n);
+void launch_ir_table(int n, float* table, hipStream_t st);
+void launch_allpass_response(const float* c, long ld, long rows, int n, float* re, float* im, hipStream_t st);
+void launch_half_width(const float* f0_frames, long rows, float sr, float* hw, hipStream_t st);
+void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale,
+                    const float* table, int mode, const float* half_width, long rows, int n, float* taps,
+                    hipStream_t st);
+size_t fir_mfma_lds_bytes(int F, int hop, int N);
+int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
+               int B, int F, int hop, int N, int impl, hipStream_t st);
+}  // namespace ddsp

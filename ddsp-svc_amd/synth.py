@@ -1,0 +1,157 @@
+"""Functional layer over the fused C-ABI entry points: phase state, exciters and the two DSP tails
+(reference: ddsp/vocoder.py:564-611 Sins, :819-862 CombSub).  Tensors in, tensors out, all on
+the GPU; controls may be non-contiguous ``torch.split`` views (row stride is passed through)."""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _ffi
+from ._ffi import ptr
+from .core import _f32c, ir_table
+
+
+@dataclass
+class PhaseState:
+    """Output of HOT-1.  ``phase_frames [B,F,1]`` goes to Unit2Control; ``phase0 [B,F]`` (float64,
+    unwrapped cycles accumulated before each frame) is what the exciters restart from."""
+    phase0: torch.Tensor
+    phase_frames: torch.Tensor
+    initial_phase: Optional[torch.Tensor]
+    infer: bool
+    x: Optional[torch.Tensor] = None
+
+
+def _rows(t, n):
+    """pointer-compatible view of a ``[B,F,n]`` control: last dim contiguous, uniform frame stride"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    B, F, nn = t.shape
+    assert nn == n
+    if t.stride(2) != 1 or (B > 1 and t.stride(0) != F * t.stride(1)) or t.stride(1) < n:
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
+def _initial_phase(initial_phase, B, device):
+    if initial_phase is None:
+        return None
+    ip = initial_phase.to(device=device, dtype=torch.float32).reshape(-1)
+    if ip.numel() == 1:
+        ip = ip.expand(B)
+    if ip.numel() != B:
+        raise ValueError("initial_phase must hold one value per utterance")
+    return ip.contiguous()
+
+
+def phase(f0_frames, sampling_rate, block_size, initial_phase=None, infer=True, want_x=False) -> PhaseState:
+    """vocoder.py:564-575: upsample f0, cumulative phase (float64 scan if ``infer``), wrap,
+    ``phase_frames = 2*pi*x[:, ::block_size]``."""
+    _ffi.check_device(f0_frames)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    dev = f0.device
+    ip = _initial_phase(initial_phase, B, dev)
+    sums = torch.empty(B, F, dtype=torch.float64, device=dev)
+    phase0 = torch.empty(B, F, dtype=torch.float64, device=dev)
+    pf = torch.empty(B, F, 1, dtype=torch.float32, device=dev)
+    x = torch.empty(B, F * hop, dtype=torch.float32, device=dev) if want_x else None
+    _ffi.check(_ffi.lib().ddsp_hip_phase(ptr(f0), ptr(ip), B, F, hop, float(sampling_rate), int(bool(infer)),
+                                         ptr(sums), ptr(phase0), ptr(pf), ptr(x), _ffi.stream_of(f0)))
+    return PhaseState(phase0, pf, ip, bool(infer), x)
+
+
+def combtooth(f0_frames, state: PhaseState, sampling_rate, block_size):
+    """vocoder.py:839-840: ``sinc(sr * x / (f0 + 1e-3))`` -> ``[B,T]``."""
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    out = torch.empty(B, F * hop, dtype=torch.float32, device=f0.device)
+    _ffi.check(_ffi.lib().ddsp_hip_combtooth(ptr(f0), ptr(state.initial_phase), ptr(state.phase0), B, F, hop,
+                                             float(sampling_rate), int(state.infer), ptr(out), _ffi.stream_of(f0)))
+    return out
+
+
+def sinusoid_bank(f0_frames, state: PhaseState, amplitudes_ctrl, sampling_rate, block_size):
+    """vocoder.py:580,585-594 from the raw ``amplitudes`` control -> ``[B,T]``."""
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    H = amplitudes_ctrl.shape[-1]
+    c, ld = _rows(amplitudes_ctrl, H)
+    out = torch.empty(B, F * hop, dtype=torch.float32, device=f0.device)
+    _ffi.check(_ffi.lib().ddsp_hip_sinusoid_bank(ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(c), ld,
+                                                 B, F, hop, H, float(sampling_rate), int(state.infer), ptr(out),
+                                                 _ffi.stream_of(f0)))
+    return out
+
+
+_WS = {}
+
+
+def _workspace(B, F, hop, n_max, device):
+    need = _ffi.lib().ddsp_hip_synth_workspace_bytes(B, F, hop, n_max)
+    key = str(device)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws, need
+
+
+def _outputs(B, T, device, want_components):
+    signal = torch.empty(B, T, dtype=torch.float32, device=device)
+    if want_components:
+        return signal, torch.empty_like(signal), torch.empty_like(signal)
+    return signal, None, None
+
+
+def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magnitude, noise, sampling_rate,
+               block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
+    """DSP tail of ``Sins.forward`` (vocoder.py:580-611) from raw controls.  ``noise [B,T]`` is the
+    uniform draw (``noise_is_u01``: raw ``rand_like`` output, else already ``2u-1``).
+    Returns ``(signal, harmonic|None, noise|None)``."""
+    _ffi.check_device(f0_frames, amplitudes, group_delay, noise_magnitude, noise, state.phase0)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    T = F * hop
+    H, n_ap, n_nz = amplitudes.shape[-1], group_delay.shape[-1], noise_magnitude.shape[-1]
+    ca, lda = _rows(amplitudes, H)
+    cg, ldg = _rows(group_delay, n_ap)
+    cn, ldn = _rows(noise_magnitude, n_nz)
+    nz = _f32c(noise.reshape(B, T))
+    dev = f0.device
+    ws, need = _workspace(B, F, hop, max(n_ap, n_nz), dev)
+    signal, harm, nzo = _outputs(B, T, dev, want_components)
+    _ffi.check(_ffi.lib().ddsp_hip_sins_synth(
+        ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(ca), lda, ptr(cg), ldg, ptr(cn), ldn,
+        ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), H, n_ap, n_nz,
+        ptr(ir_table(n_ap, dev)), ptr(ir_table(n_nz, dev)), ptr(signal), ptr(harm), ptr(nzo),
+        ptr(ws), need, int(fir_impl), _ffi.stream_of(f0)))
+    return signal, harm, nzo
+
+
+def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude, noise_magnitude, noise,
+                  sampling_rate, block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
+    """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls."""
+    _ffi.check_device(f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, state.phase0)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    T = F * hop
+    n_ap, n_h, n_nz = group_delay.shape[-1], harmonic_magnitude.shape[-1], noise_magnitude.shape[-1]
+    cg, ldg = _rows(group_delay, n_ap)
+    ch, ldh = _rows(harmonic_magnitude, n_h)
+    cn, ldn = _rows(noise_magnitude, n_nz)
+    nz = _f32c(noise.reshape(B, T))
+    dev = f0.device
+    ws, need = _workspace(B, F, hop, max(n_ap, n_h, n_nz), dev)
+    signal, harm, nzo = _outputs(B, T, dev, want_components)
+    _ffi.check(_ffi.lib().ddsp_hip_combsub_synth(
+        ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(cg), ldg, ptr(ch), ldh, ptr(cn), ldn,
+        ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), n_ap, n_h, n_nz,
+        ptr(ir_table(n_ap, dev)), ptr(ir_table(n_h, dev)), ptr(ir_table(n_nz, dev)),
+        ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0)))
+    return signal, harm, nzo

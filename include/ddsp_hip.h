@@ -1,0 +1,123 @@
+/* ddsp_hip.h -- C ABI of libddsp_hip.so, the MI355X (gfx950) implementation of the DDSP-SVC
+ * harmonic-plus-noise synthesis hot path.
+ *
+ * The reference (yxlllc/DDSP-SVC) is pure Python: the seam for this path is its Python API
+ * (ddsp/core.py functions, ddsp/vocoder.py Sins/CombSub forward).  These entry points are what a
+ * ctypes binding on the reference side calls; each one names the reference
+ * code it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (torch tensors' data_ptr()), including workspaces -- the library never allocates or frees;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), nothing synchronises;
+ *   - return 0 on success, a negative DDSP_HIP_E* code for argument errors, or a positive
+ *     hipError_t if a launch failed; ddsp_hip_error_string() decodes both;
+ *   - tensors are float32 row-major; B = utterances, F = frames, hop = samples per frame,
+ *     T = F*hop; control tensors take a row stride `ld` (floats between consecutive frames) so
+ *     the torch.split views of Unit2Control's output can be passed without a copy.
+ */
+#ifndef DDSP_HIP_H
+#define DDSP_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDSP_HIP_VERSION 100          /* 0.1.0 */
+
+#define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
+#define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
+#define DDSP_HIP_ESHAPE   (-3)        /* shape outside what the selected kernel supports */
+#define DDSP_HIP_EWS      (-4)        /* workspace too small */
+
+/* window handling of frequency_impulse_response (ddsp/core.py:254-270) */
+#define DDSP_HIP_MODE_ROLL    0       /* hann_window=False                     core.py:269 */
+#define DDSP_HIP_MODE_HANN    1       /* hann_window=True, half_width=None     core.py:263-264 */
+#define DDSP_HIP_MODE_DYNAMIC 2       /* hann_window=True, half_width given    core.py:265-266 */
+
+/* what the response pointers hold */
+#define DDSP_HIP_ACT_NONE 0           /* the (real, imaginary) response itself, as ddsp.core takes it */
+#define DDSP_HIP_ACT_EXP  1           /* raw control c: response = scale * exp(c)   vocoder.py:580,582,835,836 */
+
+/* FIR implementation selector (0 lets the library choose) */
+#define DDSP_HIP_FIR_AUTO   0
+#define DDSP_HIP_FIR_SIMPLE 1
+#define DDSP_HIP_FIR_MFMA   2
+
+int ddsp_hip_version(void);
+const char* ddsp_hip_error_string(int code);
+
+/* ddsp/core.py:66-70  upsample(signal[B,F,C], factor=hop) -> out[B,F*hop,C] */
+int ddsp_hip_upsample(const float* sig, int B, int F, int C, int hop, float* out, void* stream);
+
+/* ddsp/core.py:73-77  remove_above_fmax(amplitudes[rows,H], pitch[rows], fmax, level_start) */
+int ddsp_hip_remove_above_fmax(const float* amps, const float* pitch, long rows, int H, float fmax,
+                               int level_start, float* out, void* stream);
+
+/* ddsp/vocoder.py:564-575 (Sins) == :819-829 (CombSub): upsample f0, cumulative sum of f0/sr
+ * (float64 if infer, float32 outputs of a float64 running sum otherwise), optional initial phase,
+ * wrap to [-0.5,0.5].
+ *   f0_frames[B,F]; initial_phase[B] radians or NULL;
+ *   frame_sums[B,F] (double, scratch); phase0[B,F] (double): unwrapped running sum before each
+ *   frame -- the state the synth entry points consume; phase_frames[B,F] = 2*pi*x[:, ::hop]
+ *   (what Unit2Control receives); x_or_null[B,T]: the full wrapped phase if the caller wants it. */
+int ddsp_hip_phase(const float* f0_frames, const float* initial_phase, int B, int F, int hop, double sr,
+                   int infer, double* frame_sums, double* phase0, float* phase_frames, float* x_or_null,
+                   void* stream);
+
+/* basis table for n_mag bins (cosine | sine | periodic Hann); build once per n_mag and keep it */
+size_t ddsp_hip_ir_table_bytes(int n_mag);
+int ddsp_hip_ir_table(int n_mag, float* table, void* stream);
+
+/* ddsp/vocoder.py:581,599 / :834,845  exp(1j*cumsum(pi*tanh(c), -1)) -> re, im [rows,n_mag] */
+int ddsp_hip_allpass_response(const float* c, long ld, long rows, int n_mag, float* re, float* im,
+                              void* stream);
+
+/* ddsp/core.py:254-270  frequency_impulse_response: one-sided response [rows,n_mag] (+ imaginary
+ * part or NULL) -> causal-form taps [rows, N=2*(n_mag-1)]; `act`/`scale` fuse the control
+ * activation, `half_width[rows]` is required for MODE_DYNAMIC. */
+int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* resp_im, long ld_im, int act,
+                              float scale, int mode, const float* half_width, long rows, int n_mag,
+                              const float* table, float* taps, void* stream);
+
+/* ddsp/core.py:120-182  fft_convolve(audio[B,T], taps[B,F,N]) -> out[B,T]  (T = F*hop).
+ * x_is_u01: the input is a raw U[0,1) draw and 2*u-1 is applied on load (vocoder.py:603,854);
+ * addend[B,T] or NULL is added to the result (vocoder.py:609,860); out_plain[B,T] or NULL also
+ * receives the un-added result. */
+int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, const float* addend,
+                          float* out, float* out_plain, int B, int F, int hop, int N, int impl, void* stream);
+
+/* DSP tail of Sins.forward (ddsp/vocoder.py:580-611) from raw controls and the phase state.
+ * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1); tables for n_ap / n_nz bins.
+ * signal[B,T]; harmonic_or_null / noise_out_or_null [B,T] only if the caller wants the tuple. */
+int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
+                        const float* c_amp, long ld_amp, const float* c_gd, long ld_gd,
+                        const float* c_nz, long ld_nz, const float* noise, int noise_is_u01,
+                        int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,
+                        const float* table_ap, const float* table_nz,
+                        float* signal, float* harmonic_or_null, float* noise_out_or_null,
+                        void* ws, size_t ws_bytes, int fir_impl, void* stream);
+
+/* DSP tail of CombSub.forward (ddsp/vocoder.py:834-862). */
+int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
+                           const float* c_gd, long ld_gd, const float* c_harm, long ld_harm,
+                           const float* c_nz, long ld_nz, const float* noise, int noise_is_u01,
+                           int B, int F, int hop, double sr, int infer, int n_ap, int n_harm, int n_nz,
+                           const float* table_ap, const float* table_harm, const float* table_nz,
+                           float* signal, float* harmonic_or_null, float* noise_out_or_null,
+                           void* ws, size_t ws_bytes, int fir_impl, void* stream);
+
+/* workspace the two synth entry points need (bytes); n_max = largest n_mag among the filters */
+size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
+
+/* exciters on their own (used by tests and by callers that want the intermediate):
+ * combtooth (vocoder.py:839-840) and the sinusoid bank (vocoder.py:585-594), out[B,T] */
+int ddsp_hip_combtooth(const float* f0_frames, const float* initial_phase, const double* phase0, int B, int F,
+                       int hop, double sr, int infer, float* out, void* stream);
+int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, const double* phase0,
+                           const float* c_amp, long ld_amp, int B, int F, int hop, int H, double sr, int infer,
+                           float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDSP_HIP_H */

@@ -1,0 +1,48 @@
+"""Compile the product's HIP sources as host C++ against the hipemu header (CPU emulation of the
+device model, TEST INFRASTRUCTURE ONLY).  Output: tests/hipemu/_build/libddsp_hip_emu.so"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "ddsp-svc_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libddsp_hip_emu.so")
+SOURCES = ["phase.hip", "exciter.hip", "ir.hip", "fir.hip", "api.hip"]
+
+
+def _clang():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/llvm/bin/clang++"):
+        if os.path.exists(c):
+            return c
+    raise RuntimeError("ROCm clang++ not found (needed for ext_vector_type in host code)")
+
+
+def build(force=False, sanitize=False):
+    os.makedirs(OUT, exist_ok=True)
+    lib = LIB.replace(".so", "_asan.so") if sanitize else LIB
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+            os.path.join(ROOT, "include", "ddsp_hip.h")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    flags = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC,
+             "-Wno-unknown-attributes", "-Wno-unused-function"]
+    if sanitize:
+        flags += ["-fsanitize=address", "-fno-omit-frame-pointer"]
+    objs = []
+    for s in SOURCES + ["../../tests/hipemu/hipemu.cpp"]:
+        src = os.path.normpath(os.path.join(CSRC, s))
+        o = os.path.join(OUT, os.path.basename(s).replace(".hip", "").replace(".cpp", "") + ("_asan.o" if sanitize else ".o"))
+        subprocess.run([_clang(), *flags, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    link = [_clang(), "-shared", "-fPIC", *objs, "-o", lib]
+    if sanitize:
+        link.insert(1, "-fsanitize=address")
+    subprocess.run(link, check=True)
+    return lib
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force=True, sanitize="--asan" in sys.argv))

@@ -1,0 +1,231 @@
+// hipemu -- a minimal single-process CPU emulator of the HIP device model, TEST INFRASTRUCTURE ONLY.
+//
+// The product kernels under ddsp-svc_amd/csrc/*.hip are pure HIP for gfx950.  There is no GPU in
+// the build container, so tests/hipemu compiles those *same source files* as host C++ (clang++
+// -x c++ -I tests/hipemu) against this header: every workgroup runs as a set of cooperatively
+// scheduled fibers (one per work-item), __syncthreads() and the wave64 cross-lane operations
+// (__shfl*, f32 MFMA) are rendez-vous points between fibers.  That lets the CPU test-suite check
+// kernel *logic* (indexing, LDS staging, wave scans, MFMA fragment layouts, tails) under
+// AddressSanitizer before a GPU minute is spent.  It is never loaded by the product package and
+// is not a fallback: ddsp-svc_amd/_ffi.py only ever loads the hipcc-built libddsp_hip.so.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+
+// ---- qualifiers -------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __shared__ static
+#define __constant__ static
+#define __launch_bounds__(...)
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_shared());
+
+// ---- vector types -----------------------------------------------------------------------------
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return {x, y}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+
+// ---- runtime API subset -----------------------------------------------------------------------
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+
+namespace hipemu {
+struct Barrier { int count = 0; unsigned gen = 0; };
+struct Fiber {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  uint3 tid{0, 0, 0};
+  int lin = 0, wave = 0, lane = 0;
+  bool done = false;
+  Barrier* wait = nullptr;
+  unsigned wait_gen = 0;
+};
+struct Wave {
+  Barrier bar;
+  int alive = 0;
+  unsigned parity = 0;
+  alignas(16) unsigned char slot[2][64][64];   // per-lane deposit area, double buffered
+};
+struct State {
+  Fiber* cur = nullptr;
+  uint3 bid{0, 0, 0};
+  dim3 bdim, gdim;
+  Barrier blockbar;
+  int alive = 0;
+  Wave* waves = nullptr;
+  void* dynsh = nullptr;
+};
+extern State g;
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void block_sync();
+void wave_sync();            // all live lanes of the calling fiber's wave
+inline void* dyn_shared() { return g.dynsh; }
+inline Wave& wave() { return g.waves[g.cur->wave]; }
+// deposit a value, rendez-vous, return the wave's slot array for this collective
+template <class T> inline const unsigned char (*exchange(const T& v))[64] {
+  static_assert(sizeof(T) <= 64, "slot too small");
+  Wave& w = wave();
+  unsigned p = w.parity & 1u;      // same for all lanes of the wave at this collective
+  memcpy(w.slot[p][g.cur->lane], &v, sizeof(T));
+  wave_sync();                     // the releasing lane flips w.parity
+  return w.slot[p];
+}
+template <class T> inline T peek(const unsigned char (*s)[64], int lane) { T r; memcpy(&r, s[lane], sizeof(T)); return r; }
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g.cur->tid)
+#define blockIdx (hipemu::g.bid)
+#define blockDim (hipemu::g.bdim)
+#define gridDim (hipemu::g.gdim)
+static constexpr int warpSize = 64;
+
+template <class K, class... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
+}
+
+// ---- synchronisation and cross-lane -----------------------------------------------------------
+static inline void __syncthreads() { hipemu::block_sync(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+  auto s = hipemu::exchange(v);
+  int lane = hipemu::g.cur->lane;
+  int base = lane - (lane % width);
+  return hipemu::peek<T>(s, base + (((src % width) + width) % width));
+}
+template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  auto s = hipemu::exchange(v);
+  int lane = hipemu::g.cur->lane;
+  int in = lane % width;
+  return in >= (int)delta ? hipemu::peek<T>(s, lane - (int)delta) : v;
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  auto s = hipemu::exchange(v);
+  int lane = hipemu::g.cur->lane;
+  int in = lane % width;
+  return in + (int)delta < width ? hipemu::peek<T>(s, lane + (int)delta) : v;
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+  auto s = hipemu::exchange(v);
+  int lane = hipemu::g.cur->lane;
+  int tgt = lane ^ mask;
+  return (tgt / width == lane / width) ? hipemu::peek<T>(s, tgt) : v;
+}
+static inline unsigned long long __ballot(int pred) {
+  auto s = hipemu::exchange(pred);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (l < hipemu::wave().alive && hipemu::peek<int>(s, l)) m |= 1ull << l;
+  return m;
+}
+template <class T> static inline T __builtin_amdgcn_readfirstlane_emu(T v) {
+  auto s = hipemu::exchange(v);
+  return hipemu::peek<T>(s, 0);
+}
+#define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_sched_barrier(a) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+
+// ---- f32 MFMA (exact k-ordered fmaf chain, as on gfx950) ----------------------------------------
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+reg
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  float2 ab{a, b};
+  auto s = hipemu::exchange(ab);
+  int l = hipemu::g.cur->lane;
+  int col = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av = hipemu::peek<float2>(s, k * 16 + row).x;
+      float bv = hipemu::peek<float2>(s, k * 16 + col).y;
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+// A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5)
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+  float2 ab{a, b};
+  auto s = hipemu::exchange(ab);
+  int l = hipemu::g.cur->lane;
+  int col = l & 31;
+  hipemu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av = hipemu::peek<float2>(s, k * 32 + row).x;
+      float bv = hipemu::peek<float2>(s, k * 32 + col).y;
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
+
+// ---- device math / intrinsics subset ------------------------------------------------------------
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+static inline double __fma_rn(double a, double b, double c) { return fma(a, b, c); }
+#define __sinf(x) sinf(x)
+#define __cosf(x) cosf(x)
+#define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline void sincospif(float x, float* s, float* c) { *s = (float)sin(M_PI * (double)x); *c = (float)cos(M_PI * (double)x); }
+static inline float sinpif(float x) { return (float)sin(M_PI * (double)x); }
+static inline float cospif(float x) { return (float)cos(M_PI * (double)x); }
+static inline double sinpi(double x) { return sin(M_PI * x); }
+static inline double cospi(double x) { return cos(M_PI * x); }
+static inline int __float2int_rn(float x) { return (int)rintf(x); }
+static inline int __float2int_rd(float x) { return (int)floorf(x); }
+static inline float __int2float_rn(int x) { return (float)x; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
