@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples/s of the CombSub DSP path (BASELINE.json cfg 2) on N MI355X.
+
+A step = one pass of the hot path over one resident batch: HOT-1 (phase scan, phase_frames) +
+HOT-2 (combtooth, 3x tap synthesis, 3x time-varying FIR, mix) for B utterances of 10 s at
+44.1 kHz / hop 512 with 256/256/256 magnitude bins.  Inputs (f0, raw controls ~N(0,1), uniform
+noise) are already in HBM; only ``signal`` is written (the (harmonic, noise) tuple every reference
+caller discards is not materialised).  Multi-GPU: one process per GPU, utterances sharded, no
+data-path collective ("weak" scaling: B per GPU fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      the dominant kernel (k_fir_mfma) timed alone with events on the launch stream
+  cpu_baseline  the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
+                on this host's cores over a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+SR, HOP = 44100, 512
+
+
+def make_inputs(kind, B, F, sizes, device, seed):
+    from oracle import ddsp_oracle as O            # only the synthetic-input generators
+    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=seed)).to(device)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    ctrl = torch.randn(B, F, sum(sizes), generator=g).to(device)      # one tensor, split into strided views
+    ctrls = torch.split(ctrl, list(sizes), dim=-1)
+    noise = (torch.rand(B, F * HOP, generator=g) * 2 - 1).to(device)
+    return f0, ctrls, noise
+
+
+def _cpu_worker(args):
+    seed, F, kind, sizes = args
+    import numpy as _np
+    from oracle import ddsp_oracle as O
+    f0 = O.synth_f0(1, F, SR, HOP, seed=seed)
+    cs = O.synth_controls(1, F, sizes, seed=seed + 1)
+    nz = O.synth_noise(1, F * HOP, seed=seed + 2)
+    if kind == "combsub":
+        r = O.combsub_dsp(f0, cs[0], cs[1], cs[2], nz, SR, HOP)
+    else:
+        r = O.sins_dsp(f0, cs[0], cs[1], cs[2], nz, SR, HOP)
+    return float(_np.abs(r["signal"]).max())
+
+
+def cpu_baseline(kind, F, sizes, budget_s=20.0):
+    """Oracle timed on the host: one 10 s utterance per worker process, rounds until ~budget."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    ctx = mp.get_context("fork")
+    done, t0 = 0, time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(1000 + i, 8, kind, sizes) for i in range(cores)])     # warm the workers
+        t0 = time.perf_counter()
+        rounds = 0
+        while True:
+            pool.map(_cpu_worker, [(rounds * cores + i, F, kind, sizes) for i in range(cores)])
+            rounds += 1
+            done += cores
+            if time.perf_counter() - t0 > budget_s * 0.6 or rounds >= 4:
+                break
+        wall = time.perf_counter() - t0
+    return {"value": done * F * HOP / wall, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d utterances of %d frames (%.1f s audio each), numpy oracle, %d worker processes, %.1f s wall"
+                      % (done, F, F * HOP / SR, cores, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins"])
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--fir-impl", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the optional gather of the waveforms to rank 0")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from ddsp_svc_amd import _ffi, core, synth, sharding
+
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1              # the reference's frame-count rule (vocoder.py:222)
+    T = F * HOP
+    n = a.bins
+    sizes = (n, n, n)
+    f0, ctrls, noise = make_inputs(a.model, B, F, sizes, device, seed=1234 + rank)
+
+    def step():
+        st = synth.phase(f0, SR, HOP)
+        if a.model == "combsub":
+            return synth.combsub_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
+                                       want_components=False, fir_impl=a.fir_impl)[0]
+        return synth.sins_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
+                                want_components=False, fir_impl=a.fir_impl)[0]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    gather_ms = None
+    if a.gather and world > 1:
+        fence()
+        t1 = time.perf_counter()
+        full = sharding.gather_utterances(out, B * world, dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        del full
+
+    # ---- dominant kernel alone: the MFMA time-varying FIR, N = 2(n-1) taps, events on the launch stream ----
+    N = 2 * (n - 1)
+    taps = torch.randn(B, F, N, device=device) / N ** 0.5
+    y = torch.empty(B, T, device=device)
+    L = _ffi.lib()
+    st_ptr = torch.cuda.current_stream().cuda_stream
+
+    def fir_once():
+        _ffi.check(L.ddsp_hip_fft_convolve(noise.data_ptr(), 0, taps.data_ptr(), None, y.data_ptr(), None,
+                                           B, F, HOP, N, a.fir_impl, st_ptr))
+    for _ in range(3):
+        fir_once()
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fir_once()
+    e1.record()
+    torch.cuda.synchronize()
+    fir_ms = e0.elapsed_time(e1) / reps
+    fir_flops = 4.0 * N * B * T                      # 2N multiply-adds per output sample (two tap frames per input sample)
+    achieved = fir_flops / (fir_ms * 1e-3) / 1e12
+    fir_launches = 3 if a.model == "combsub" else 2
+
+    if rank == 0:
+        total = B * world * T * a.steps
+        value = total / elapsed
+        ms = elapsed / a.steps * 1e3
+        sigma_c = sum(sizes)
+        alg_bytes = (8.0 + 4.0 * (sigma_c + 1) / HOP) * B * T          # out + noise + controls + f0
+        res = {
+            "metric": "audio samples/sec, CombSub 44.1kHz 256-harm hop512" if a.model == "combsub"
+                      else "audio samples/sec, Sins 44.1kHz 256-harm hop512",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s B=%d/GPU x %.0f s utterances (F=%d, T=%d), n_mag %d/%d/%d, sr 44100, hop 512, "
+                                   "DSP path (HOT-1 + HOT-2) from resident f0 / raw controls ~N(0,1) / uniform noise, "
+                                   "signal only" % (a.model, B, a.seconds, F, T, n, n, n),
+                       "batch_per_gpu": B, "frames": F, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
+            "roofline": {"kernel": "k_fir_mfma", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": achieved / 157.3, "traffic": None, "avg_ms": fir_ms, "launches_per_step": fir_launches,
+                         "algorithmic_flops_per_launch": fir_flops},
+            "roofline_step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes,
+                                  "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},
+        }
+        if gather_ms is not None:
+            res["gather_ms"] = gather_ms
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.model, F, sizes)
+            res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""CPU checks: the gfx950 library builds, loads, and exports every symbol include/ddsp_hip.h declares;
+argument validation of the C ABI (no compute calls here -- no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from ddsp_svc_amd import _ffi, build
+    path = build.build()
+    assert os.path.exists(path)
+    lib = _ffi.bind(ctypes.CDLL(path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ddsp_hip.h")).read()
+    declared = set(re.findall(r"\b(ddsp_hip_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ddsp_hip_version() == 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from ddsp_svc_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.ddsp_hip_upsample(None, 1, 0, 1, 512, None, None) == -1          # F <= 0
+    assert lib.ddsp_hip_upsample(None, 0, 4, 1, 512, None, None) == 0           # empty batch is a no-op
+    assert lib.ddsp_hip_fft_convolve(None, 0, None, None, None, None, 1, 4, 512, 511, 0, None) == -1  # odd N
+    assert lib.ddsp_hip_ir_table_bytes(256) == (2 * 256 * 256 + 510) * 4
+    assert lib.ddsp_hip_synth_workspace_bytes(1, 4, 512, 256) > 3 * 4 * 512 * 4
+    assert b"workspace" in lib.ddsp_hip_error_string(-4)
+
+
+def test_host_tensors_are_rejected():
+    import torch
+    from ddsp_svc_amd import core
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        core.upsample(torch.zeros(1, 4, 1), 512)
