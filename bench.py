@@ -38,6 +38,14 @@ def make_inputs(kind, B, F, sizes, device, seed):
     return f0, ctrls, noise
 
 
+def _cpu_worker_init():
+    try:                                            # one thread per worker: the pool already uses every core
+        import threadpoolctl
+        _cpu_worker_init.limiter = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+
+
 def _cpu_worker(args):
     seed, F, kind, sizes = args
     import numpy as _np
@@ -56,10 +64,9 @@ def cpu_baseline(kind, F, sizes, budget_s=20.0):
     """Oracle timed on the host: one 10 s utterance per worker process, rounds until ~budget."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 64))
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
     ctx = mp.get_context("fork")
     done, t0 = 0, time.perf_counter()
-    with ctx.Pool(cores) as pool:
+    with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_worker, [(1000 + i, 8, kind, sizes) for i in range(cores)])     # warm the workers
         t0 = time.perf_counter()
         rounds = 0
