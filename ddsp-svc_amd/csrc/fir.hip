@@ -53,160 +53,219 @@ __global__ void __launch_bounds__(256) k_fir_simple(const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA form.  Workgroup = 4 waves = 1024 consecutive outputs of one utterance (256 per wave).
-// LDS: the input window it touches, pre-weighted twice (XA = (1-lam)*x for the frame's own taps,
-// XB = lam*x for the next frame's taps), and the zero-padded tap rows of every frame in reach.
+// MFMA form.  Workgroup = WAVES waves = WAVES*256 consecutive outputs of one utterance.
+//
+// LDS holds, for every frame j in reach, the chunk  Wj[o] = (x * tri_j)[(j-1)*hop + o], o in [0, 2*hop)
+// (first half = lam*x of frame j-1, second half = (1-lam)*x of frame j), chunks separated by FIR_G
+// zeros, plus the zero-padded tap rows.  Lanes that fall outside a frame's support read guard
+// zeros, so the inner loop has no selects or masks: per MFMA one ds_read for each operand.
+// Chunk storage is skewed by 2 words per 16 (fir_pad) so the 16-sample-strided B reads of a wave
+// hit 32 distinct banks; the K loop is phased so that 4 consecutive K steps stay inside one
+// 16-word block and use immediate offsets.
 // ------------------------------------------------------------------------------------------------
-constexpr int FIR_TILE = 1024;
+constexpr int FIR_G = 288;     // guard zeros between chunks: >= 16*15 + 3 + 2*15 (lane spread + loop phase slack)
+constexpr int FIR_FP = 16;     // zeros in front of a tap row: the phased K loop may start at u0 = -15
 
-__device__ __forceinline__ int fir_pad(int q) { return q + 2 * (q >> 4); }   // 18-word stride per 16: conflict-free B reads
+__device__ __forceinline__ int fir_pad(int q) { return q + 2 * (q >> 4); }
 
 struct FirGeom {
   int F, hop, N, D;
-  int KU;        // inner extent rounded up to the MFMA K step: roundup4(N + 15)
-  int HLEN;      // padded tap row: 15 zeros | N taps | zeros, KU + 16 words
-  int SLEN;      // staged input samples: FIR_TILE + N + 8
-  int XOFF;      // words between the XA and XB arrays
-  int NJ;        // tap rows held per workgroup
+  int KU;        // inner extent: u in [0, N+15)
+  int HLEN;      // words per padded tap row
+  int CH, CS;    // chunk length (2*hop) and chunk stride (CH + FIR_G), before the bank skew
+  int NJ;        // chunks / tap rows a workgroup can need
+  int WWORDS;    // words reserved for the chunk area (skewed)
   long T;
+  long TPU, NTILES;   // tiles per utterance, tiles in the launch
 };
 
-__global__ void __launch_bounds__(256) k_fir_mfma(const float* __restrict__ x, int x_is_u01,
-                                                  const float* __restrict__ taps, const float* __restrict__ addend,
-                                                  float* __restrict__ out, float* __restrict__ out_plain, FirGeom g) {
-  HIP_DYNAMIC_SHARED(float, lds)                    // XA | XB | taps[NJ][HLEN]
-  float* XA = lds;
-  float* XB = lds + g.XOFF;
-  float* HS = lds + 2 * g.XOFF;
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_fir_mfma(const float* __restrict__ x, int x_is_u01,
+                                                         const float* __restrict__ taps,
+                                                         const float* __restrict__ addend, float* __restrict__ out,
+                                                         float* __restrict__ out_plain, FirGeom g) {
+  constexpr int TILE = WAVES * 256;
+  constexpr int NT = WAVES * 64;
+  HIP_DYNAMIC_SHARED(float, lds)
+  float* W = lds;
+  float* HS = lds + g.WWORDS;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, l = tid & 63;
-  const long b = blockIdx.y;
-  const long T0 = (long)blockIdx.x * FIR_TILE;
-  const long S_lo = T0 - g.D - 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  // XCD-aware tile order: workgroup w is dispatched to XCD w % 8; give every XCD a contiguous run of
+  // tiles so neighbouring tiles (which share tap rows and the input halo) meet in the same L2
+  const long per_xcd = gridDim.x >> 3;
+  const long tile = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= g.NTILES) return;                      // grid is padded to a multiple of 8
+  const long b = tile / g.TPU;
+  const long T0 = (tile - b * g.TPU) * TILE;
+
+  // input samples this tile can touch, and the frames (tap rows) they belong to
+  long s_min = T0 - g.D + 1;
+  if (s_min < 0) s_min = 0;
+  long s_max = T0 + TILE - 1 + g.D;
+  if (s_max > g.T - 1) s_max = g.T - 1;
+  const int j_lo = (int)(s_min / g.hop);
+  int j_hi = (int)(s_max / g.hop) + 1;               // row F duplicates row F-1 (core.py:167)
+  if (j_hi > g.F) j_hi = g.F;
+  int nj = j_hi - j_lo + 1;
+  if (nj > g.NJ) nj = g.NJ;                          // cannot happen (host bound); keeps LDS accesses in range
+
+  // ---- stage guards, weighted chunks, tap rows -------------------------------------------------------
+  for (int jr = 0; jr <= nj; ++jr)
+    for (int t = tid; t < FIR_G; t += NT) W[fir_pad(jr * g.CS + t)] = 0.f;
   const float* xb = x + b * g.T;
   const float inv_hop = 1.0f / (float)g.hop;
-
-  // ---- stage the weighted input window -----------------------------------------------------------
-  for (int q = tid; q < g.SLEN; q += 256) {
-    const long s = S_lo + q;
-    float v = 0.f, lam = 0.f;
-    if (s >= 0 && s < g.T) {
-      v = xb[s];
-      if (x_is_u01) v = fmaf(2.0f, v, -1.0f);          // noise = rand*2-1 (vocoder.py:603,854)
-      const long k = s / g.hop;
-      lam = (float)(s - k * g.hop) * inv_hop;
+  const long st_lo = s_min - 16, st_hi = s_max + 16;
+  for (int jr = 0; jr < nj; ++jr) {
+    const long cs0 = (long)(j_lo + jr - 1) * g.hop;
+    const int cb = FIR_G + jr * g.CS;
+    for (int off = tid; off < g.CH; off += NT) {
+      const long s = cs0 + off;
+      float v = 0.f;
+      if (s >= st_lo && s <= st_hi && s >= 0 && s < g.T) {
+        v = xb[s];
+        if (x_is_u01) v = fmaf(2.0f, v, -1.0f);        // noise = rand*2-1 (vocoder.py:603,854)
+      }
+      const bool first = off < g.hop;
+      const float lam = (float)(first ? off : off - g.hop) * inv_hop;
+      W[fir_pad(cb + off)] = first ? lam * v : (1.0f - lam) * v;
     }
-    const int p = fir_pad(q);
-    XA[p] = (1.0f - lam) * v;
-    XB[p] = lam * v;
   }
-  // ---- stage the tap rows of frames j_lo .. j_lo+NJ-1 (row F duplicates row F-1, core.py:167) ---------
-  const long s_first = S_lo < 0 ? 0 : S_lo;
-  const int j_lo = (int)(s_first / g.hop);
-  for (int e = tid; e < g.NJ * g.HLEN; e += 256) {
-    const int jr = e / g.HLEN, idx = e - jr * g.HLEN;
+  for (int jr = 0; jr < nj; ++jr) {
     const int j = j_lo + jr;
-    const int m = idx - 15;
-    float v = 0.f;
-    if (j <= g.F && m >= 0 && m < g.N) {
-      const int row = j < g.F ? j : g.F - 1;
-      v = taps[(b * g.F + row) * (long)g.N + m];
+    const int row = j < g.F ? j : g.F - 1;
+    const float* trow = taps + (b * g.F + row) * (long)g.N;
+    float* hrow = HS + jr * g.HLEN;
+    for (int idx = tid; idx < g.HLEN; idx += NT) {
+      const int m = idx - (FIR_FP + 15);
+      hrow[idx] = (m >= 0 && m < g.N) ? trow[m] : 0.f;
     }
-    HS[e] = v;
   }
   __syncthreads();
 
-  // ---- contraction ---------------------------------------------------------------------------------
-  const int i = l & 15;                 // A: row (fine output offset);  B: column c (coarse offset, x16)
+  // ---- contraction ---------------------------------------------------------------------------------------
+  const int c = l & 15;                 // A: row i (fine output offset);  B: column c (coarse offset, x16)
   const int kq = l >> 4;                // K sub-index 0..3
   const long t0w = T0 + 256 * wave;
   if (t0w >= g.T) return;               // wave-uniform; no barrier below
-  // s(u0) for this lane's B element: t0w + 16*c + D + 15 - (u0 + kq)
-  const long sb = t0w + 16 * i + g.D + 15 - kq;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int jr = 0; jr < g.NJ; ++jr) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int jr = 0; jr < nj; ++jr) {
     const long j = j_lo + jr;
-    if (j > g.F) break;
-    const long sup_lo = (j - 1) * g.hop;            // frames j-1 and j carry a non-zero triangle of frame j
-    const long sup_hi = (j + 1) * g.hop;            // exclusive
-    const long mid = j * g.hop;
-    // K steps for which at least one lane of the wave reads inside the support
-    long ulo = t0w + g.D + 13 - sup_hi;             // u0 must exceed  t0w + D + 12 - sup_hi
-    long uhi = t0w + g.D + 255 - sup_lo + 1;        // u0 at most      t0w + D + 255 - sup_lo
-    if (ulo < 0) ulo = 0;
-    ulo &= ~3L;
-    if (uhi > g.KU) uhi = g.KU;
-    const float* hrow = HS + jr * g.HLEN + kq + i;
-    for (long u0 = ulo; u0 < uhi; u0 += 4) {
-      const float av = hrow[u0];
-      const long s = sb - u0;
-      const int p = fir_pad((int)(s - S_lo));
-      float bv = (s < mid) ? XB[p] : XA[p];
-      if (s < sup_lo || s >= sup_hi) bv = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    const long lo = (j - 1) * g.hop;                // support of tri_j: [lo, hi)
+    const long hi = (j + 1) * g.hop;
+    // K steps u0 for which at least one lane reads inside the support
+    const long ulo_l = t0w + g.D + 13 - hi;
+    const long uhi_l = t0w + g.D + 256 - lo;
+    const int uhi = uhi_l > g.KU ? g.KU : (int)uhi_l;
+    if (ulo_l >= uhi || uhi <= 0) continue;         // no lane of this wave reaches frame j
+    const int ulo = ulo_l < 0 ? 0 : (int)ulo_l;
+    // chunk-local index of lane (c=0,kq=0) at u0 = 0; phase the loop so that index % 16 == 15 at group start
+    const int W0 = FIR_G + jr * g.CS + (int)(t0w - lo) + g.D + 15;
+    const int r = (((W0 - 15) % 16) + 16) % 16;
+    const int ug0 = ulo - ((((ulo - r) % 16) + 16) % 16);
+    const int x0 = W0 - kq + 16 * c - ug0;
+    const float* bp = W + fir_pad(x0) - 12;
+    const float* ap = HS + jr * g.HLEN + FIR_FP + ug0 + kq + c;
+    const int ng = (uhi - ug0 + 15) >> 4;
+    // software pipeline: operands of group gi+1 are in flight while the 4 MFMAs of group gi issue;
+    // two accumulators break the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32
+    float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+    float b0 = bp[12], b1 = bp[8], b2 = bp[4], b3 = bp[0];
+    for (int gi = 1; gi < ng; ++gi) {
+      ap += 16;
+      bp -= 18;
+      const float na0 = ap[0], na1 = ap[4], na2 = ap[8], na3 = ap[12];
+      const float nb0 = bp[12], nb1 = bp[8], nb2 = bp[4], nb3 = bp[0];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc2, 0, 0, 0);
+      a0 = na0; a1 = na1; a2 = na2; a3 = na3;
+      b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
     }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc2, 0, 0, 0);
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
 
   // ---- epilogue: D layout col = l&15 (c), row = 4*(l>>4) + reg (i)  ->  4 consecutive samples per lane ----
   const long t = t0w + 16 * (l & 15) + 4 * (l >> 4);
   const long base = b * g.T + t;
   if (t + 3 < g.T && (base & 3) == 0) {
-    float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    if (out_plain) *reinterpret_cast<float4*>(out_plain + base) = r;
+    float4 r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (out_plain) *reinterpret_cast<float4*>(out_plain + base) = r4;
     if (addend) {
       const float4 a = *reinterpret_cast<const float4*>(addend + base);
-      r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+      r4.x += a.x; r4.y += a.y; r4.z += a.z; r4.w += a.w;
     }
-    *reinterpret_cast<float4*>(out + base) = r;
+    *reinterpret_cast<float4*>(out + base) = r4;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (t + e < g.T) {
-        float r = acc[e];
-        if (out_plain) out_plain[base + e] = r;
-        out[base + e] = addend ? r + addend[base + e] : r;
+        float rv = acc[e];
+        if (out_plain) out_plain[base + e] = rv;
+        out[base + e] = addend ? rv + addend[base + e] : rv;
       }
     }
   }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-static FirGeom fir_geom(int F, int hop, int N) {
+static FirGeom fir_geom(int F, int hop, int N, int tile) {
   FirGeom g;
   g.F = F; g.hop = hop; g.N = N; g.D = N / 2;
   g.T = (long)F * hop;
-  g.KU = (N + 15 + 3) & ~3;
-  g.HLEN = g.KU + 16;
-  g.SLEN = FIR_TILE + N + 8;
-  int padded = g.SLEN + 2 * ((g.SLEN >> 4) + 1);
-  g.XOFF = (padded + 31) & ~31;
-  g.NJ = (g.SLEN + hop - 1) / hop + 2;
+  g.KU = N + 15;
+  g.HLEN = (FIR_FP + g.KU + 32 + 3) & ~3;
+  g.CH = 2 * hop;
+  g.CS = g.CH + FIR_G;
+  g.NJ = (tile + 2 * g.D - 2) / hop + 3;
+  int last = g.NJ * g.CS + FIR_G;
+  g.WWORDS = (last + 2 * (last >> 4) + 2 + 31) & ~31;
   return g;
 }
 
-size_t fir_mfma_lds_bytes(int F, int hop, int N) {
-  FirGeom g = fir_geom(F, hop, N);
-  return ((size_t)2 * g.XOFF + (size_t)g.NJ * g.HLEN) * sizeof(float);
+size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves) {
+  FirGeom g = fir_geom(F, hop, N, waves * 256);
+  return ((size_t)g.WWORDS + (size_t)g.NJ * g.HLEN) * sizeof(float);
 }
 
-// impl: 0 = auto, 1 = simple, 2 = mfma.  Returns the implementation used, or <0 on error.
+// impl: 0 = auto, 1 = simple, 2 = mfma with 4 waves (1024 outputs) per workgroup, 3 = mfma with 8 waves.
+// Returns the implementation used, or <0 when the requested kernel cannot take the shape.
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                int B, int F, int hop, int N, int impl, hipStream_t st) {
   const long T = (long)F * hop;
   if (B == 0 || T == 0) return 0;
-  size_t lds = fir_mfma_lds_bytes(F, hop, N);
-  const bool mfma_ok = lds <= 64 * 1024 && (N % 2 == 0) && B <= 65535;
-  if (impl == 2 && !mfma_ok) return -1;
-  if (impl == 0) impl = mfma_ok ? 2 : 1;
+  if (N & 1) return -1;
+  auto fits = [&](int waves) { return fir_mfma_lds_bytes(F, hop, N, waves) <= 64 * 1024; };
+  if (impl == 0) impl = fits(4) ? 2 : 1;
+  if ((impl == 2 && !fits(4)) || (impl == 3 && !fits(8))) return -1;
   if (impl == 2) {
-    FirGeom g = fir_geom(F, hop, N);
-    dim3 grid((unsigned)((T + FIR_TILE - 1) / FIR_TILE), (unsigned)B), block(256);
-    hipLaunchKernelGGL(k_fir_mfma, grid, block, lds, st, x, x_is_u01, taps, addend, out, out_plain, g);
-  } else {
+    FirGeom g = fir_geom(F, hop, N, 1024);
+    g.TPU = (T + 1023) / 1024;
+    g.NTILES = g.TPU * B;
+    dim3 grid((unsigned)(((g.NTILES + 7) / 8) * 8));
+    hipLaunchKernelGGL(k_fir_mfma<4>, grid, dim3(256), fir_mfma_lds_bytes(F, hop, N, 4), st, x, x_is_u01, taps, addend,
+                       out, out_plain, g);
+  } else if (impl == 3) {
+    FirGeom g = fir_geom(F, hop, N, 2048);
+    g.TPU = (T + 2047) / 2048;
+    g.NTILES = g.TPU * B;
+    dim3 grid((unsigned)(((g.NTILES + 7) / 8) * 8));
+    hipLaunchKernelGGL(k_fir_mfma<8>, grid, dim3(512), fir_mfma_lds_bytes(F, hop, N, 8), st, x, x_is_u01, taps, addend,
+                       out, out_plain, g);
+  } else if (impl == 1) {
     if (B > 65535) return -1;
     dim3 grid((unsigned)((T + 255) / 256), (unsigned)B), block(256);
     hipLaunchKernelGGL(k_fir_simple, grid, block, 0, st, x, x_is_u01, taps, addend, out, out_plain, F, hop, N, T);
+  } else {
+    return -1;
   }
   return impl;
 }

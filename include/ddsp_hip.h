@@ -41,7 +41,8 @@ extern "C" {
 /* FIR implementation selector (0 lets the library choose) */
 #define DDSP_HIP_FIR_AUTO   0
 #define DDSP_HIP_FIR_SIMPLE 1
-#define DDSP_HIP_FIR_MFMA   2
+#define DDSP_HIP_FIR_MFMA   2       /* 4 waves = 1024 outputs per workgroup */
+#define DDSP_HIP_FIR_MFMA8  3       /* 8 waves = 2048 outputs per workgroup */
 
 int ddsp_hip_version(void);
 const char* ddsp_hip_error_string(int code);

@@ -182,7 +182,7 @@ def test_allpass_response(dev):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, 3])
 @pytest.mark.parametrize("n_mag", [65, 129, 256])
 def test_fft_convolve_golden(dev, golden_dir, impl, n_mag):
     from ddsp_svc_amd import core
@@ -203,8 +203,12 @@ def test_fft_convolve_shapes(dev, B, F, hop, N):
     audio = (rng.random((B, F * hop)) * 2 - 1).astype(np.float32)
     ir = rng.standard_normal((B, F, N)).astype(np.float32) / np.sqrt(N)
     ref = O.ltv_fir_blockfft(audio, ir)
-    for impl in (1, 2):
-        y = N_(core.fft_convolve(T_(audio, dev), T_(ir, dev), impl=impl))
+    for impl in (0, 1, 2, 3):
+        try:
+            y = N_(core.fft_convolve(T_(audio, dev), T_(ir, dev), impl=impl))
+        except RuntimeError as e:           # an explicitly requested MFMA tiling may not fit LDS: loud, not silent
+            assert impl in (2, 3) and "shape not supported" in str(e)
+            continue
         assert rms(y - ref) <= 2e-6 * rms(ref), (impl, rms(y - ref), rms(ref))
 
 
