@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) k_fir_simple(const float* __restrict__ x,
 // hit 32 distinct banks; the K loop is phased so that 4 consecutive K steps stay inside one
 // 16-word block and use immediate offsets.
 // ------------------------------------------------------------------------------------------------
-constexpr int FIR_G = 288;     // guard zeros between chunks: >= 16*15 + 3 + 2*15 (lane spread + loop phase slack)
+constexpr int FIR_G = 320;     // guard zeros between chunks: >= 16*15 + 3 + 2*15 (lane spread + loop phase slack) + 32 (prefetch overrun)
+constexpr int FIR_TAIL = 64;   // slack words after the last tap row (prefetch overrun)
 constexpr int FIR_FP = 16;     // zeros in front of a tap row: the phased K loop may start at u0 = -15
 
 __device__ __forceinline__ int fir_pad(int q) { return q + 2 * (q >> 4); }
@@ -112,35 +113,56 @@ __global__ void __launch_bounds__(WAVES * 64) k_fir_mfma(const float* __restrict
   int nj = j_hi - j_lo + 1;
   if (nj > g.NJ) nj = g.NJ;                          // cannot happen (host bound); keeps LDS accesses in range
 
-  // ---- stage guards, weighted chunks, tap rows -------------------------------------------------------
-  for (int jr = 0; jr <= nj; ++jr)
-    for (int t = tid; t < FIR_G; t += NT) W[fir_pad(jr * g.CS + t)] = 0.f;
+  // ---- staging ------------------------------------------------------------------------------------------
+  // A: every global load of the window is issued up front (one batch, independent)
+  constexpr int XMAX = (TILE + 1022 + 32 + NT - 1) / NT;      // window words per thread for N <= 1022
   const float* xb = x + b * g.T;
-  const float inv_hop = 1.0f / (float)g.hop;
-  const long st_lo = s_min - 16, st_hi = s_max + 16;
-  for (int jr = 0; jr < nj; ++jr) {
-    const long cs0 = (long)(j_lo + jr - 1) * g.hop;
-    const int cb = FIR_G + jr * g.CS;
-    for (int off = tid; off < g.CH; off += NT) {
-      const long s = cs0 + off;
-      float v = 0.f;
-      if (s >= st_lo && s <= st_hi && s >= 0 && s < g.T) {
-        v = xb[s];
-        if (x_is_u01) v = fmaf(2.0f, v, -1.0f);        // noise = rand*2-1 (vocoder.py:603,854)
-      }
-      const bool first = off < g.hop;
-      const float lam = (float)(first ? off : off - g.hop) * inv_hop;
-      W[fir_pad(cb + off)] = first ? lam * v : (1.0f - lam) * v;
-    }
+  const long st_lo = T0 - g.D + 1 - 16;
+  const int swin = TILE + 2 * g.D + 30;
+  float xv[XMAX];
+#pragma unroll
+  for (int i = 0; i < XMAX; ++i) {
+    const int q = tid + i * NT;
+    const long s = st_lo + q;
+    float v = 0.f;
+    if (q < swin && s >= 0 && s < g.T) v = xb[s];
+    xv[i] = v;
+  }
+  // B: zero the chunk area (guards + everything outside the window) and the tap-row pads; copy the taps
+  {
+    float4* W4 = reinterpret_cast<float4*>(W);
+    const int n4 = (fir_pad(nj * g.CS + FIR_G) + 4) >> 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = tid; t < n4; t += NT) W4[t] = z;
   }
   for (int jr = 0; jr < nj; ++jr) {
     const int j = j_lo + jr;
     const int row = j < g.F ? j : g.F - 1;
     const float* trow = taps + (b * g.F + row) * (long)g.N;
     float* hrow = HS + jr * g.HLEN;
-    for (int idx = tid; idx < g.HLEN; idx += NT) {
-      const int m = idx - (FIR_FP + 15);
-      hrow[idx] = (m >= 0 && m < g.N) ? trow[m] : 0.f;
+    for (int idx = tid; idx < FIR_FP + 15; idx += NT) hrow[idx] = 0.f;
+    for (int idx = FIR_FP + 15 + g.N + tid; idx < g.HLEN; idx += NT) hrow[idx] = 0.f;
+#pragma unroll 4
+    for (int m = tid; m < g.N; m += NT) hrow[FIR_FP + 15 + m] = trow[m];
+  }
+  __syncthreads();
+  // C: scatter each window sample into the two chunks that weight it
+  {
+    const float inv_hop = 1.0f / (float)g.hop;
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i) {
+      const int q = tid + i * NT;
+      const long s = st_lo + q;
+      if (q < swin && s >= 0 && s < g.T) {
+        float v = xv[i];
+        if (x_is_u01) v = fmaf(2.0f, v, -1.0f);        // noise = rand*2-1 (vocoder.py:603,854)
+        const int k = (int)(s / g.hop);
+        const int rr = (int)(s - (long)k * g.hop);
+        const float lam = (float)rr * inv_hop;
+        const int jr = k - j_lo;                        // chunk of frame k holds it as (1-lam)*x, second half
+        if (jr >= 0 && jr < nj) W[fir_pad(FIR_G + jr * g.CS + g.hop + rr)] = (1.0f - lam) * v;
+        if (jr + 1 >= 0 && jr + 1 < nj) W[fir_pad(FIR_G + (jr + 1) * g.CS + rr)] = lam * v;
+      }
     }
   }
   __syncthreads();
@@ -169,26 +191,42 @@ __global__ void __launch_bounds__(WAVES * 64) k_fir_mfma(const float* __restrict
     const float* bp = W + fir_pad(x0) - 12;
     const float* ap = HS + jr * g.HLEN + FIR_FP + ug0 + kq + c;
     const int ng = (uhi - ug0 + 15) >> 4;
-    // software pipeline: operands of group gi+1 are in flight while the 4 MFMAs of group gi issue;
-    // two accumulators break the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32
+    // software pipeline, two register sets: while the 4 MFMAs of one group issue, the operands of the
+    // group after next are already in flight.  Prefetches may run up to two groups past the end of the
+    // pass (never used; FIR_G and the tail slack of the tap area keep them inside the LDS allocation).
+    // Two accumulators break the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32.
     float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
     float b0 = bp[12], b1 = bp[8], b2 = bp[4], b3 = bp[0];
-    for (int gi = 1; gi < ng; ++gi) {
-      ap += 16;
-      bp -= 18;
-      const float na0 = ap[0], na1 = ap[4], na2 = ap[8], na3 = ap[12];
-      const float nb0 = bp[12], nb1 = bp[8], nb2 = bp[4], nb3 = bp[0];
+    float c0 = ap[16], c1 = ap[20], c2 = ap[24], c3 = ap[28];
+    float d0 = bp[-6], d1 = bp[-10], d2 = bp[-14], d3 = bp[-18];
+    int gi = 0;
+    for (; gi + 2 <= ng; gi += 2) {
+      ap += 32;
+      bp -= 36;
+      // sched_barrier(0): keep hipcc from sinking the prefetches back next to their consumers
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc2, 0, 0, 0);
-      a0 = na0; a1 = na1; a2 = na2; a3 = na3;
-      b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = ap[0]; a1 = ap[4]; a2 = ap[8]; a3 = ap[12];
+      b0 = bp[12]; b1 = bp[8]; b2 = bp[4]; b3 = bp[0];
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c0, d0, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1, d1, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c2, d2, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c3, d3, acc2, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      c0 = ap[16]; c1 = ap[20]; c2 = ap[24]; c3 = ap[28];
+      d0 = bp[-6]; d1 = bp[-10]; d2 = bp[-14]; d3 = bp[-18];
+      __builtin_amdgcn_sched_barrier(0);
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc2, 0, 0, 0);
+    if (gi < ng) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc2, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
@@ -227,13 +265,13 @@ static FirGeom fir_geom(int F, int hop, int N, int tile) {
   g.CS = g.CH + FIR_G;
   g.NJ = (tile + 2 * g.D - 2) / hop + 3;
   int last = g.NJ * g.CS + FIR_G;
-  g.WWORDS = (last + 2 * (last >> 4) + 2 + 31) & ~31;
+  g.WWORDS = (last + 2 * (last >> 4) + 8 + 31) & ~31;
   return g;
 }
 
 size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves) {
   FirGeom g = fir_geom(F, hop, N, waves * 256);
-  return ((size_t)g.WWORDS + (size_t)g.NJ * g.HLEN) * sizeof(float);
+  return ((size_t)g.WWORDS + (size_t)g.NJ * g.HLEN + FIR_TAIL) * sizeof(float);
 }
 
 // impl: 0 = auto, 1 = simple, 2 = mfma with 4 waves (1024 outputs) per workgroup, 3 = mfma with 8 waves.
@@ -243,7 +281,7 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
   const long T = (long)F * hop;
   if (B == 0 || T == 0) return 0;
   if (N & 1) return -1;
-  auto fits = [&](int waves) { return fir_mfma_lds_bytes(F, hop, N, waves) <= 64 * 1024; };
+  auto fits = [&](int waves) { return N <= 1022 && fir_mfma_lds_bytes(F, hop, N, waves) <= 64 * 1024; };
   if (impl == 0) impl = fits(4) ? 2 : 1;
   if ((impl == 2 && !fits(4)) || (impl == 3 && !fits(8))) return -1;
   if (impl == 2) {
