@@ -213,6 +213,21 @@ def test_fft_convolve_shapes(dev, B, F, hop, N):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("impl", [2, 3])
+def test_fft_convolve_persistent_loop(dev, impl, monkeypatch):
+    """few resident workgroups, many tiles each: exercises the tile loop and the register prefetch of tile i+1"""
+    from ddsp_svc_amd import core
+    monkeypatch.setenv("DDSP_HIP_FIR_MAX_SLOTS", "1")
+    rng = np.random.default_rng(77)
+    B, F, hop, N = 3, 21, 512, 254
+    audio = (rng.random((B, F * hop)) * 2 - 1).astype(np.float32)
+    ir = rng.standard_normal((B, F, N)).astype(np.float32) / np.sqrt(N)
+    ref = O.ltv_fir_blockfft(audio, ir)
+    y = N_(core.fft_convolve(T_(audio, dev), T_(ir, dev), impl=impl))
+    assert rms(y - ref) <= 2e-6 * rms(ref)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_fft_convolve_errors(dev):
     from ddsp_svc_amd import core
     a = torch.zeros(2, 1024, device=dev)

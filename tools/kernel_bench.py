@@ -36,7 +36,7 @@ def main():
     y = torch.empty(B, T, device=dev)
     res = {}
     flops = 4.0 * N * B * T
-    for impl in (2, 3):
+    for impl in [2, 3] + [int(v) for v in os.environ.get('FIR_EXTRA', '').split()]:
         ms = timeit(lambda: _ffi.check(L.ddsp_hip_fft_convolve(x.data_ptr(), 0, taps.data_ptr(), None, y.data_ptr(), None,
                                                                B, F, HOP, N, impl, st)))
         res["fir_impl%d_ms" % impl] = ms
