@@ -117,25 +117,37 @@ __global__ void __launch_bounds__(256) k_sins_bank(const float* __restrict__ f0_
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   FramePhase<SPL> ph;
   frame_phase<SPL>(f0_row, f, hop, up, cfg, phase0[fr], ip, lane, ph);
-  float phase[SPL], w0[SPL], w1[SPL], acc[SPL];
+  // sum_k sin(fl32(phase*k)) * (w0*A0[k] + w1*A1[k]) is accumulated as w0*S0 + w1*S1 with S_i = sum_k sin(.)*A_i[k]:
+  // two fmas per harmonic and sample instead of an interpolation plus an fma (same sum, rounding differs at 1e-7).
+  // Samples are processed in pairs so that the multiplies and fmas issue as packed-f32 instructions
+  // (v_pk_mul_f32 / v_pk_fma_f32): per harmonic and pair 4 packed + 2 rndne + 2 v_sin + 2 packed accumulations.
+  f32x2 phase[SPL / 2], s0[SPL / 2], s1[SPL / 2];
 #pragma unroll
-  for (int r = 0; r < SPL; ++r) {
-    phase[r] = kTwoPiF * ph.x[r];
-    int i0, i1;
-    up.locate((long)f * hop + lane * SPL + r, i0, i1, w0[r], w1[r]);
-    acc[r] = 0.f;
+  for (int r = 0; r < SPL / 2; ++r) {
+    phase[r] = f32x2{kTwoPiF * ph.x[2 * r], kTwoPiF * ph.x[2 * r + 1]};     // vocoder.py:574
+    s0[r] = f32x2{0.f, 0.f};
+    s1[r] = f32x2{0.f, 0.f};
   }
   const float* ra = rows + wave * H;
   const float* rb = ra + H;
   for (int k = 0; k < H; ++k) {
     const float a0 = ra[k], a1 = rb[k];
     const float kf = (float)(k + 1);
+    const f32x2 a0v = {a0, a0}, a1v = {a1, a1};
 #pragma unroll
-    for (int r = 0; r < SPL; ++r) {
-      float amp = fmaf(w0[r], a0, w1[r] * a1);
-      float s = sinf(phase[r] * kf);
-      acc[r] = fmaf(s, amp, acc[r]);
+    for (int r = 0; r < SPL / 2; ++r) {
+      const f32x2 s = sin_turns2(phase[r] * kf);    // the reference rounds phase*k to float32 first (vocoder.py:590)
+      s0[r] = __builtin_elementwise_fma(s, a0v, s0[r]);
+      s1[r] = __builtin_elementwise_fma(s, a1v, s1[r]);
     }
+  }
+  float acc[SPL];
+#pragma unroll
+  for (int r = 0; r < SPL; ++r) {
+    int i0, i1;
+    float w0, w1;
+    up.locate((long)f * hop + lane * SPL + r, i0, i1, w0, w1);
+    acc[r] = fmaf(w0, s0[r >> 1][r & 1], w1 * s1[r >> 1][r & 1]);
   }
   store_frame<SPL>(out + fr * (long)hop, hop, lane, acc);
 }

@@ -22,25 +22,34 @@ enum { IR_ACT_NONE = 0, IR_ACT_EXP = 1 };
 //   TE[k][m] =  (c_k/N) cos(2 pi k m / N)   c_0 = c_{n-1} = 1, else 2           k,m in [0,n)
 //   TO[k][m] = -(2/N)   sin(2 pi k m / N)   rows 0 and n-1 are zero: irfft ignores Im(DC), Im(Nyquist)
 //   HANN[j]  = 0.5 - 0.5 cos(2 pi j / N)    periodic Hann, j in [0,N)
-// layout: TE (n*n floats) | TO (n*n floats) | HANN (N floats)
+// layout: TE | TO | HANN; TE and TO are stored [KP][NP] with KP = n rounded up to the k-chunk (16) and
+// NP = n rounded up to the column tile (256), zero outside [0,n) x [0,n), so the contraction kernel
+// streams them with unguarded 16-byte loads.
 // ------------------------------------------------------------------------------------------------
+constexpr int GM = 64, GN = 256, KC = 16;
+__host__ __device__ inline long ir_kp(int n) { return ((long)n + KC - 1) / KC * KC; }
+__host__ __device__ inline long ir_np(int n) { return ((long)n + GN - 1) / GN * GN; }
+
 __global__ void __launch_bounds__(256) k_ir_table(int n, float* __restrict__ table) {
   const long N = 2L * (n - 1);
-  const long nn = (long)n * n;
-  const long total = 2 * nn + N;
+  const long KP = ir_kp(n), NP = ir_np(n);
+  const long plane = KP * NP;
+  const long total = 2 * plane + N;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    float v;
-    if (i < 2 * nn) {
-      const bool odd = i >= nn;
-      const long e = odd ? i - nn : i;
-      const long k = e / n, m = e % n;
-      const double frac = 2.0 * (double)((k * m) % N) / (double)N;       // angle / pi, reduced exactly
-      const bool edge = (k == 0) || (k == n - 1);
-      if (!odd) v = (float)((edge ? 1.0 : 2.0) / (double)N * cospi(frac));
-      else v = edge ? 0.0f : (float)(-2.0 / (double)N * sinpi(frac));
+    float v = 0.f;
+    if (i < 2 * plane) {
+      const bool odd = i >= plane;
+      const long e = odd ? i - plane : i;
+      const long k = e / NP, m = e % NP;
+      if (k < n && m < n) {
+        const double frac = 2.0 * (double)((k * m) % N) / (double)N;     // angle / pi, reduced exactly
+        const bool edge = (k == 0) || (k == n - 1);
+        if (!odd) v = (float)((edge ? 1.0 : 2.0) / (double)N * cospi(frac));
+        else v = edge ? 0.0f : (float)(-2.0 / (double)N * sinpi(frac));
+      }
     } else {
-      const long j = i - 2 * nn;
+      const long j = i - 2 * plane;
       v = (float)(0.5 - 0.5 * cospi(2.0 * (double)j / (double)N));
     }
     table[i] = v;
@@ -86,15 +95,19 @@ __global__ void __launch_bounds__(256) k_half_width(const float* __restrict__ f0
 }
 
 // ------------------------------------------------------------------------------------------------
-// taps = window( roll( X * T ) ):  64x64 output tile per workgroup, 4 waves of one 32x32 MFMA tile
-// each, K streamed through LDS in chunks of 32.
+// taps = window( roll( X * T ) ).  Workgroup tile = 64 frames x 256 taps-columns (all of m = 0..N/2 for
+// n_mag <= 256, so every control row is read from HBM exactly once), 4 waves of 64x64 = 2x2 MFMA
+// 32x32x2 accumulators each; K is streamed in chunks of 16 through a double-buffered LDS stage: the
+// global loads of chunk c+1 are in flight (registers) while chunk c is contracted, one barrier per chunk.
 //   a_re / a_im : [rows, n] with row stride ld_* (raw control if ACT_EXP, else the response itself)
 //   E = sum_k re_k TE[k][m],  O = sum_k im_k TO[k][m];  zero-phase taps: z[m] = E+O, z[N-m] = E-O
 //   causal form: taps[N/2 + m] = z[m] (m < N/2), taps[N/2 - m] = z[N-m] (m >= 1)   (roll by N/2)
+// Within a chunk the MFMA k index is permuted (step s of lane-half h takes k = 8h + s) so a lane's eight
+// A values are two contiguous 16-byte LDS reads.
 // ------------------------------------------------------------------------------------------------
-constexpr int GM = 64, GN = 64, GK = 32;
-constexpr int LDA = GM + 1;    // A is stored k-major ([k][row]); +1 keeps the transposing stores conflict-free
-constexpr int LDB = GN;
+constexpr int LDA = 20;          // floats per A row in LDS (16 + pad; rows stay 16-byte aligned)
+constexpr int LDB = GN + 4;      // floats per B row in LDS: rows 8 apart land 32 banks apart
+constexpr int IR_STAGE = GM * LDA + KC * LDB;     // floats per pipeline stage
 
 template <int ACT>
 __device__ __forceinline__ float ir_activate(float v, float scale) {
@@ -102,96 +115,169 @@ __device__ __forceinline__ float ir_activate(float v, float scale) {
   return v * scale;
 }
 
+// cos(a) for the dynamic window, |a| < ~10: same reduction as sin_turns, hardware cosine (revolutions)
+__device__ __forceinline__ float cos_turns(float a) {
+  const float inv_hi = 0.15915494f, inv_lo = 6.4206383e-9f;
+  float nn = rintf(a * inv_hi);
+  float r = fmaf(a, inv_hi, -nn);
+  r = fmaf(a, inv_lo, r);
+  return __builtin_amdgcn_cosf(r);
+}
+
 template <int ACT, bool HAS_IM>
-__global__ void __launch_bounds__(256) k_ir_gemm(const float* __restrict__ a_re, long ld_re,
+__global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_re, long ld_re,
                                                  const float* __restrict__ a_im, long ld_im, float scale,
                                                  const float* __restrict__ table, int mode,
                                                  const float* __restrict__ half_width, long rows, int n,
-                                                 float* __restrict__ taps) {
-  __shared__ float As[GK * LDA];
-  __shared__ float Bs[GK * LDB];
+                                                 float* __restrict__ taps, int a_vec_ok) {
+  __shared__ __attribute__((aligned(16))) float stage[2 * IR_STAGE];
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, l = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = 64-column group
+  const int l = tid & 63;
+  const int li = l & 31, h = l >> 5;
   const long row0 = (long)blockIdx.x * GM;
   const int col0 = blockIdx.y * GN;
   const int N = 2 * (n - 1);
-  const long nn = (long)n * n;
+  const int KP = (int)ir_kp(n);
+  const long NP = ir_np(n);
+  const long plane = (long)KP * NP;
+  const int nch = KP / KC;
+  const int total_ch = HAS_IM ? 2 * nch : nch;
 
-  f32x16 accE, accO;
+  f32x16 accE[2][2], accO[2][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { accE[i] = 0.f; accO[i] = 0.f; }
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accE[rb][cb][i] = 0.f; accO[rb][cb][i] = 0.f; }
 
-  const int a_kk = tid & 31, a_r0 = tid >> 5;          // A staging: 32 consecutive k per row, 8 rows per sweep
-  const int b_mm = tid & 63, b_k0 = tid >> 6;          // B staging: 64 consecutive m per k, 4 k per sweep
+  // staging roles: A -- thread (row = tid/4, 4 consecutive k); B -- thread (k = tid/64 + 4j, 4 consecutive columns)
+  const int a_row = tid >> 2, a_kq = (tid & 3) * 4;
+  const int b_k = tid >> 6, b_c4 = (tid & 63) * 4;
+  struct Chunk { float4 a, b0, b1, b2, b3; };
 
-  for (int part = 0; part < (HAS_IM ? 2 : 1); ++part) {
+  auto fetch = [&](int cc) -> Chunk {
+    const int part = (HAS_IM && cc >= nch) ? 1 : 0;
+    const int k0 = (cc - part * nch) * KC;
     const float* A = part ? a_im : a_re;
     const long ld = part ? ld_im : ld_re;
-    const float* Tb = table + (part ? nn : 0);
-    for (int k0 = 0; k0 < n; k0 += GK) {
-      __syncthreads();                                  // previous chunk fully consumed
-#pragma unroll
-      for (int q = 0; q < GM / 8; ++q) {
-        const int rr = a_r0 + 8 * q;
-        const long r = row0 + rr;
-        const int k = k0 + a_kk;
-        float v = 0.f;
-        if (r < rows && k < n) v = ir_activate<ACT>(A[r * ld + k], scale);
-        As[a_kk * LDA + rr] = v;
-      }
-#pragma unroll
-      for (int q = 0; q < GK / 4; ++q) {
-        const int kk = b_k0 + 4 * q;
-        const int k = k0 + kk;
-        const int m = col0 + b_mm;
-        Bs[kk * LDB + b_mm] = (k < n && m < n) ? Tb[(long)k * n + m] : 0.f;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < GK; ks += 2) {
-        const float av = As[(ks + (l >> 5)) * LDA + wr * 32 + (l & 31)];
-        const float bv = Bs[(ks + (l >> 5)) * LDB + wc * 32 + (l & 31)];
-        if (part == 0) accE = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accE, 0, 0, 0);
-        else accO = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accO, 0, 0, 0);
+    const long r = row0 + a_row;
+    const int k = k0 + a_kq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const float* src = A + r * ld + k;
+      if (a_vec_ok && k + 3 < n) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (k < n) v.x = src[0];
+        if (k + 1 < n) v.y = src[1];
+        if (k + 2 < n) v.z = src[2];
+        if (k + 3 < n) v.w = src[3];
       }
     }
+    Chunk c;
+    c.a = v;
+    const float* Tb = table + (part ? plane : 0) + (long)(k0 + b_k) * NP + col0 + b_c4;
+    c.b0 = *reinterpret_cast<const float4*>(Tb);
+    c.b1 = *reinterpret_cast<const float4*>(Tb + 4 * NP);
+    c.b2 = *reinterpret_cast<const float4*>(Tb + 8 * NP);
+    c.b3 = *reinterpret_cast<const float4*>(Tb + 12 * NP);
+    return c;
+  };
+  // the activation is applied here, after the MFMAs of the previous chunk, so the contraction never waits on
+  // the global load it overlaps.  Out-of-range k stay exactly zero (exp(garbage)*0 must not become NaN).
+  auto park = [&](int buf, int cc, const Chunk& c) {
+    float* As = stage + buf * IR_STAGE;
+    float* Bs = As + GM * LDA;
+    const int part = (HAS_IM && cc >= nch) ? 1 : 0;
+    const int k = (cc - part * nch) * KC + a_kq;
+    const bool live = row0 + a_row < rows;
+    float4 v;
+    v.x = (live && k < n) ? ir_activate<ACT>(c.a.x, scale) : 0.f;
+    v.y = (live && k + 1 < n) ? ir_activate<ACT>(c.a.y, scale) : 0.f;
+    v.z = (live && k + 2 < n) ? ir_activate<ACT>(c.a.z, scale) : 0.f;
+    v.w = (live && k + 3 < n) ? ir_activate<ACT>(c.a.w, scale) : 0.f;
+    *reinterpret_cast<float4*>(As + a_row * LDA + a_kq) = v;
+    *reinterpret_cast<float4*>(Bs + (b_k + 0) * LDB + b_c4) = c.b0;
+    *reinterpret_cast<float4*>(Bs + (b_k + 4) * LDB + b_c4) = c.b1;
+    *reinterpret_cast<float4*>(Bs + (b_k + 8) * LDB + b_c4) = c.b2;
+    *reinterpret_cast<float4*>(Bs + (b_k + 12) * LDB + b_c4) = c.b3;
+  };
+  auto contract = [&](int buf, f32x16 (&acc)[2][2]) {
+    const float* As = stage + buf * IR_STAGE;
+    const float* Bs = As + GM * LDA;
+    float av[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float4 lo = *reinterpret_cast<const float4*>(As + (rb * 32 + li) * LDA + 8 * h);
+      const float4 hi = *reinterpret_cast<const float4*>(As + (rb * 32 + li) * LDA + 8 * h + 4);
+      av[rb][0] = lo.x; av[rb][1] = lo.y; av[rb][2] = lo.z; av[rb][3] = lo.w;
+      av[rb][4] = hi.x; av[rb][5] = hi.y; av[rb][6] = hi.z; av[rb][7] = hi.w;
+    }
+    const float* bp = Bs + (8 * h) * LDB + wc * 64 + li;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const float b0 = bp[sidx * LDB], b1 = bp[sidx * LDB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  Chunk nxt = fetch(0);
+  park(0, 0, nxt);
+  __syncthreads();
+  for (int cc = 0; cc < total_ch; ++cc) {
+    const bool more = cc + 1 < total_ch;
+    if (more) nxt = fetch(cc + 1);
+    if (!HAS_IM || cc < nch) contract(cc & 1, accE);
+    else contract(cc & 1, accO);
+    if (more) park((cc + 1) & 1, cc + 1, nxt);
+    __syncthreads();
   }
 
   // epilogue: roll + mirror + window.  C/D layout: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
-  const int m = col0 + wc * 32 + (l & 31);
   const int half = N / 2;
-  const float* hann = table + 2 * nn;
-  if (m > half) return;                                 // also covers m >= n
+  const float* hann = table + 2 * plane;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const long r = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
-    if (r >= rows) continue;
-    const float E = accE[reg];
-    const float O = HAS_IM ? accO[reg] : 0.f;
-    const float hw = (mode == IR_MODE_DYNAMIC) ? half_width[r] : 1.f;
-    float* dst = taps + r * (long)N;
+  for (int cb = 0; cb < 2; ++cb) {
+    const int m = col0 + wc * 64 + cb * 32 + li;
+    if (m > half) continue;                             // also covers m >= n
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      if (side == 0 && m >= half) continue;             // z[N/2] lands only at taps[0]
-      if (side == 1 && m == 0) continue;                // z[0] lands only at taps[N/2]
-      const int j = side == 0 ? half + m : half - m;
-      const float z = side == 0 ? E + O : E - O;
-      float w = 1.f;
-      if (mode == IR_MODE_HANN) {
-        w = hann[j];
-      } else if (mode == IR_MODE_DYNAMIC) {
-        float u = (float)(j - half) / hw;               // core.py:244
-        if (u > 1.0f) u = 0.0f;                         // core.py:245 -- only the upper side is clamped
-        w = (1.0f + cosf(kPiF * u)) / 2.0f;             // core.py:246
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long r = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (r >= rows) continue;
+        const float E = accE[rb][cb][reg];
+        const float O = HAS_IM ? accO[rb][cb][reg] : 0.f;
+        const float hw = (mode == IR_MODE_DYNAMIC) ? half_width[r] : 1.f;
+        float* dst = taps + r * (long)N;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          if (side == 0 && m >= half) continue;         // z[N/2] lands only at taps[0]
+          if (side == 1 && m == 0) continue;            // z[0] lands only at taps[N/2]
+          const int j = side == 0 ? half + m : half - m;
+          const float z = side == 0 ? E + O : E - O;
+          float w = 1.f;
+          if (mode == IR_MODE_HANN) {
+            w = hann[j];
+          } else if (mode == IR_MODE_DYNAMIC) {
+            float u = (float)(j - half) / hw;           // core.py:244
+            if (u > 1.0f) u = 0.0f;                     // core.py:245 -- only the upper side is clamped
+            w = (1.0f + cos_turns(kPiF * u)) / 2.0f;    // core.py:246
+          }
+          dst[j] = z * w;
+        }
       }
-      dst[j] = z * w;
     }
   }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-size_t ir_table_floats(int n) { return (size_t)2 * n * n + 2 * (size_t)(n - 1); }
+size_t ir_table_floats(int n) { return (size_t)(2 * ir_kp(n) * ir_np(n)) + 2 * (size_t)(n - 1); }
 
 void launch_ir_table(int n, float* table, hipStream_t st) {
   long total = (long)ir_table_floats(n);
@@ -214,17 +300,19 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
                     const float* table, int mode, const float* half_width, long rows, int n, float* taps,
                     hipStream_t st) {
   if (rows == 0) return;
-  dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)((n + GN - 1) / GN)), block(256);
+  dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)(ir_np(n) / GN)), block(256);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec = (al16(a_re) && (ld_re & 3) == 0 && (!a_im || (al16(a_im) && (ld_im & 3) == 0))) ? 1 : 0;
   if (a_im) {
     if (act == IR_ACT_EXP)
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps);
+      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
     else
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps);
+      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
   } else {
     if (act == IR_ACT_EXP)
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps);
+      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
     else
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps);
+      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
   }
 }
 

@@ -209,6 +209,8 @@ static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; retu
 static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
 static inline double __fma_rn(double a, double b, double c) { return fma(a, b, c); }
+static inline float __builtin_amdgcn_sinf(float turns) { return (float)sin(2.0 * M_PI * (double)turns); }   // v_sin_f32
+static inline float __builtin_amdgcn_cosf(float turns) { return (float)cos(2.0 * M_PI * (double)turns); }   // v_cos_f32
 #define __sinf(x) sinf(x)
 #define __cosf(x) cosf(x)
 #define __expf(x) expf(x)
