@@ -60,7 +60,24 @@ def _cpu_worker(args):
     return float(_np.abs(r["signal"]).max())
 
 
-def cpu_baseline(kind, F, sizes, budget_s=20.0):
+def hbm_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC summary (tools/gpu_traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes over this same workload, gfx950 read correction applied), or None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_hbm_traffic.json"):
+            try:
+                d = json.load(open(os.path.join(pdir, name)))
+            except Exception:
+                continue
+            for k, v in d.items():
+                if k.startswith(kernel):
+                    best = {"bytes": v["hbm_bytes"], "read": v["read_bytes"], "write": v["write_bytes"], "source": "profiles/" + name}
+    return best
+
+
+def cpu_baseline(kind, F, sizes, budget_s=12.0):
     """Oracle timed on the host: one 10 s utterance per worker process, rounds until ~budget."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -70,11 +87,12 @@ def cpu_baseline(kind, F, sizes, budget_s=20.0):
         pool.map(_cpu_worker, [(1000 + i, 8, kind, sizes) for i in range(cores)])     # warm the workers
         t0 = time.perf_counter()
         rounds = 0
-        while True:
+        while True:                                 # whole rounds (one utterance per core) until ~budget_s of wall time
             pool.map(_cpu_worker, [(rounds * cores + i, F, kind, sizes) for i in range(cores)])
             rounds += 1
             done += cores
-            if time.perf_counter() - t0 > budget_s * 0.6 or rounds >= 4:
+            el = time.perf_counter() - t0
+            if el + el / rounds > budget_s or rounds >= 64:
                 break
         wall = time.perf_counter() - t0
     return {"value": done * F * HOP / wall, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -177,6 +195,8 @@ def main():
     fir_flops = 4.0 * N * B * T                      # 2N multiply-adds per output sample (two tap frames per input sample)
     achieved = fir_flops / (fir_ms * 1e-3) / 1e12
     fir_launches = 3 if a.model == "combsub" else 2
+    fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
+    traffic = hbm_traffic("k_fir_mfma") if (B, F, n) == (32, 862, 256) else None
 
     if rank == 0:
         total = B * world * T * a.steps
@@ -195,8 +215,12 @@ def main():
                                    "signal only" % (a.model, B, a.seconds, F, T, n, n, n),
                        "batch_per_gpu": B, "frames": F, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
             "roofline": {"kernel": "k_fir_mfma", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": None, "avg_ms": fir_ms, "launches_per_step": fir_launches,
-                         "algorithmic_flops_per_launch": fir_flops},
+                         "frac": achieved / 157.3, "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_detail": traffic, "algorithmic_bytes_per_launch": fir_bytes,
+                         "avg_ms": fir_ms, "launches_per_step": fir_launches,
+                         "algorithmic_flops_per_launch": fir_flops,
+                         "note": "f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak at 2.4 GHz; the kernel runs at ~2.05 GHz "
+                                 "under load and issues 1.29x the algorithmic MFMAs (DESIGN.md section 5)"},
             "roofline_step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes,
                                   "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},

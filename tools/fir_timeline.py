@@ -49,6 +49,20 @@ for i, nm in enumerate(names):
         print("%-22s mean %9.0f  p10 %9.0f  p50 %9.0f  p90 %9.0f  (n=%d)" % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90), d.size))
 tot = (t[:, :, 5] - t[:, :, 0])[valid & (t[:, :, 5] > 0)]
 print("tile total             mean %9.0f" % tot.mean())
-first = t[:, 0, 0][t[:, 0, 0] > 0]
-last = t[:, :, 5].max()
-print("kernel span (cycles of the s_memtime clock): %.0f" % (last - first.min()))
+# every XCD has its own counter epoch: spans are only meaningful per workgroup
+span = []
+for w in range(t.shape[0]):
+    v = t[w][t[w] > 0]
+    if v.size:
+        span.append(v.max() - v.min())
+span = np.array(span)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+L.ddsp_hip_debug_set_timeline(None, st)
+e0.record()
+for _ in range(10):
+    L.ddsp_hip_fft_convolve(x.data_ptr(), 0, taps.data_ptr(), None, y.data_ptr(), None, B, F, HOP, N, impl, st)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("per-workgroup span: mean %.0f  max %.0f counter ticks; kernel %.4f ms -> counter rate >= %.3f GHz if it is the shader clock"
+      % (span.mean(), span.max(), ms, span.max() / ms / 1e6))
