@@ -1,0 +1,162 @@
+"""Module-level drop-in tests for ``ddsp_svc_amd.vocoder`` (reference: ddsp/vocoder.py:532-611, 788-862).
+
+Two layers:
+  * with a small stand-in for Unit2Control (runs everywhere, both backends): constructor / buffers /
+    state_dict keys / forward signature and return structure, and the DSP result against the oracle on
+    the controls the stand-in produced;
+  * against the REFERENCE modules themselves (only where /root/reference is importable, i.e. the build
+    container): same weights, same inputs, same injected noise -> same waveform.
+"""
+import os
+import sys
+from unittest import mock
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddsp_oracle as O
+from tests.backends import BACKENDS, dev  # noqa: F401  (fixture)
+
+SR, HOP = 44100, 512
+REF = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+class TinyUnit2Control(torch.nn.Module):
+    """Stand-in with Unit2Control's interface (ddsp/unit2control.py:26-109): forward(units, f0, phase,
+    volume, spk_id, spk_mix_dict) -> (dict of [B,F,n] views of one tensor, hidden [B,F,256])."""
+
+    def __init__(self, n_unit, n_spk, output_splits):
+        super().__init__()
+        self.output_splits = output_splits
+        self.proj = torch.nn.Linear(n_unit + 3, 256)
+        self.dense_out = torch.nn.Linear(256, sum(output_splits.values()))
+
+    def forward(self, units, f0, phase, volume, spk_id=None, spk_mix_dict=None, aug_shift=None):
+        x = torch.tanh(self.proj(torch.cat([units, (1 + f0 / 700).log(), phase / np.pi, volume], -1)))
+        e = self.dense_out(x)
+        return dict(zip(self.output_splits, torch.split(e, list(self.output_splits.values()), dim=-1))), x
+
+
+def _inputs(B, F, n_unit, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=seed + 3))
+    f0[0] = torch.clamp(f0[0] * 2.2, 65, 800)                   # dynamic-window quirk region (f0 > 259 Hz)
+    units = torch.randn(B, F, n_unit, generator=g)
+    vol = torch.rand(B, F, 1, generator=g) * 0.1
+    u = torch.rand(B, F * HOP, generator=g)
+    return units.to(device), f0.to(device), vol.to(device), u.to(device)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_dropin_module_structure_and_dsp(dev, kind, monkeypatch):
+    from ddsp_svc_amd import vocoder as V
+    torch.manual_seed(0)
+    B, F, n_unit = 2, 7, 12
+    if kind == "combsub":
+        m = V.CombSub(SR, HOP, 65, 33, 17, n_unit=n_unit, n_spk=1, unit2ctrl_factory=TinyUnit2Control)
+        keys = ("group_delay", "harmonic_magnitude", "noise_magnitude")
+    else:
+        m = V.Sins(SR, HOP, 24, 65, 17, n_unit=n_unit, n_spk=1, unit2ctrl_factory=TinyUnit2Control)
+        keys = ("amplitudes", "group_delay", "noise_magnitude")
+    m = m.to(dev).eval()
+    sd = m.state_dict()
+    assert "sampling_rate" in sd and "block_size" in sd and sd["sampling_rate"].dim() == 0      # vocoder.py:546-547
+    assert any(k.startswith("unit2ctrl.") for k in sd)
+    assert tuple(m.unit2ctrl.output_splits) == keys                                             # vocoder.py:549-554 / 804-808
+    units, f0, vol, u = _inputs(B, F, n_unit, dev)
+    captured = {}
+    m.unit2ctrl.register_forward_hook(lambda mod, i, o: captured.update(ctrls=o[0], phase=i[2]))
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: u)                                       # the rand_like draw
+    with torch.no_grad():
+        signal, hidden, (harmonic, noise) = m(units, f0, vol, spk_id=None, spk_mix_dict=None, initial_phase=None,
+                                              infer=True)
+    assert signal.shape == (B, F * HOP) and hidden.shape == (B, F, 256)
+    assert harmonic.shape == signal.shape and noise.shape == signal.shape
+    # phase_frames handed to Unit2Control == 2*pi*x[:, ::hop] of the oracle
+    f0n = f0.cpu().numpy()
+    _, pf = O.wrapped_phase(f0n, SR, HOP)
+    d = captured["phase"].cpu().numpy()[..., 0] - pf
+    d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+    assert np.abs(d).max() <= 5e-7
+    c = [captured["ctrls"][k].detach().cpu().numpy() for k in keys]
+    nz = (u.cpu().numpy() * np.float32(2) - np.float32(1)).astype(np.float32)
+    ref = O.combsub_dsp(f0n, c[0], c[1], c[2], nz, SR, HOP) if kind == "combsub" else O.sins_dsp(f0n, c[0], c[1], c[2], nz, SR, HOP)
+    for got, key in ((signal, "signal"), (harmonic, "harmonic"), (noise, "noise")):
+        e = rms(got.cpu().numpy() - ref[key])
+        assert e <= 1e-5 * rms(ref[key]) and e <= 1e-4, (key, e)
+    # return_components=False skips the tuple (callers discard it: solver.py:37, main.py:259)
+    m.return_components = False
+    with torch.no_grad():
+        s2, _, (h2, n2) = m(units, f0, vol)
+    assert h2 is None and n2 is None
+    assert rms(s2.cpu().numpy() - signal.cpu().numpy()) <= 1e-7
+    # forward-only: a control that requires grad is refused loudly instead of silently dropping the graph
+    with pytest.raises(NotImplementedError):
+        m(units, f0, vol)
+
+
+def _import_reference():
+    if not os.path.isdir(os.path.join(REF, "ddsp")):
+        pytest.skip("reference checkout not present (only in the build container)")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in ["transformers", "pyworld", "parselmouth", "torchcrepe", "resampy", "fairseq", "torchaudio",
+                 "torchaudio.transforms", "gin", "local_attention", "librosa", "librosa.sequence", "librosa.util",
+                 "librosa.filters", "librosa.core", "soundfile"]:
+        sys.modules.setdefault(name, MagicMock())
+    import ddsp.core as rcore
+    import ddsp.vocoder as rvoc
+    return rcore, rvoc
+
+
+@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_against_reference_module(dev, kind):
+    """Same weights (strict state_dict load), inputs and noise -> the reference's waveform."""
+    rcore, rvoc = _import_reference()
+    ref_cls = {"combsub": getattr(rvoc, "_reference_CombSub", rvoc.CombSub),
+               "sins": getattr(rvoc, "_reference_Sins", rvoc.Sins)}[kind]
+    from ddsp_svc_amd import vocoder as V
+    torch.manual_seed(1)
+    B, F, n_unit = 2, 9, 16
+    args = (SR, HOP, 65, 33, 65) if kind == "combsub" else (SR, HOP, 40, 65, 33)
+    ref = ref_cls(*args, n_unit=n_unit, n_spk=1).eval()
+    ours = (V.CombSub if kind == "combsub" else V.Sins)(*args, n_unit=n_unit, n_spk=1).eval()   # real Unit2Control
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    units, f0, vol, u = _inputs(B, F, n_unit, torch.device("cpu"), seed=5)
+    with torch.no_grad():
+        with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)):
+            r_sig, r_hid, (r_h, r_n) = ref(units, f0, vol, infer=True)
+        with mock.patch("torch.rand", side_effect=lambda *a, **k: u):
+            o_sig, o_hid, (o_h, o_n) = ours(units, f0, vol, infer=True)
+    assert rms((o_hid - r_hid).numpy()) <= 1e-6 * max(rms(r_hid.numpy()), 1e-12) + 1e-7
+    for got, want, name in ((o_sig, r_sig, "signal"), (o_h, r_h, "harmonic"), (o_n, r_n, "noise")):
+        e = rms((got - want).numpy())
+        assert e <= 2e-5 * rms(want.numpy()) and e <= 1e-4, (name, e, rms(want.numpy()))
+
+
+def test_patch_reference_swaps_classes_and_keeps_cpu_core():
+    rcore, rvoc = _import_reference()
+    from ddsp_svc_amd import vocoder as V
+    if not hasattr(rvoc, "_reference_CombSub"):
+        rvoc._reference_CombSub, rvoc._reference_Sins = rvoc.CombSub, rvoc.Sins
+    try:
+        V.patch_reference()
+        assert rvoc.Sins is V.Sins and rvoc.CombSub is V.CombSub
+        sig = torch.rand(1, 4, 2)
+        out = rcore.upsample(sig, 8)                         # CPU tensors keep the reference implementation
+        assert out.shape == (1, 32, 2)
+        np.testing.assert_array_equal(out.numpy(), O.upsample(sig.numpy(), 8))
+    finally:
+        rvoc.Sins, rvoc.CombSub = rvoc._reference_Sins, rvoc._reference_CombSub
+        for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response"):
+            if hasattr(rcore, "_reference_" + name):
+                setattr(rcore, name, getattr(rcore, "_reference_" + name))
+        rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter
