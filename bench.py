@@ -171,32 +171,43 @@ def main():
         gather_ms = (time.perf_counter() - t1) * 1e3
         del full
 
-    # ---- dominant kernel alone: the MFMA time-varying FIR, N = 2(n-1) taps, events on the launch stream ----
+    # ---- dominant kernel alone: the time-varying FIR (N = 2(n-1) taps), events on the launch stream.  Two forms ship:
+    # the FFT-domain block convolution (k_fir_fft, what the step uses for hop 512 / N <= 512) and the direct form on
+    # the f32 MFMA pipe (k_fir_mfma, every other shape); both are timed so either roofline can be read. ----
     N = 2 * (n - 1)
     taps = torch.randn(B, F, N, device=device) / N ** 0.5
     y = torch.empty(B, T, device=device)
     L = _ffi.lib()
     st_ptr = torch.cuda.current_stream().cuda_stream
 
-    def fir_once():
-        _ffi.check(L.ddsp_hip_fft_convolve(noise.data_ptr(), 0, taps.data_ptr(), None, y.data_ptr(), None,
-                                           B, F, HOP, N, a.fir_impl, st_ptr))
-    for _ in range(3):
-        fir_once()
-    torch.cuda.synchronize()
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fir_once()
-    e1.record()
-    torch.cuda.synchronize()
-    fir_ms = e0.elapsed_time(e1) / reps
-    fir_flops = 4.0 * N * B * T                      # 2N multiply-adds per output sample (two tap frames per input sample)
-    achieved = fir_flops / (fir_ms * 1e-3) / 1e12
+    def time_fir(impl, reps=20):
+        def once():
+            return L.ddsp_hip_fft_convolve(noise.data_ptr(), 0, taps.data_ptr(), None, y.data_ptr(), None,
+                                           B, F, HOP, N, impl, st_ptr)
+        if once() != 0:
+            return None
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    used_impl = a.fir_impl if a.fir_impl else (4 if N <= 512 else 3)
+    fir_ms = time_fir(used_impl)
+    mfma_ms = time_fir(3) if used_impl != 3 else fir_ms
+    fir_flops = 4.0 * N * B * T                      # direct form: 2N multiply-adds per output sample
     fir_launches = 3 if a.model == "combsub" else 2
     fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
-    traffic = hbm_traffic("k_fir_mfma") if (B, F, n) == (32, 862, 256) else None
+    kname = "k_fir_fft" if used_impl == 4 else "k_fir_mfma"
+    traffic = hbm_traffic(kname) if (B, F, n) == (32, 862, 256) else None
+    # arithmetic the FFT form actually executes: per frame pair three 2048-point complex FFTs (5 N log2 N) + products
+    pairs = (F + 2) // 2
+    fft_flops = B * pairs * (3 * 5.0 * 2048 * 11 + 2048 * 2 * 10.0)
 
     if rank == 0:
         total = B * world * T * a.steps
@@ -214,13 +225,28 @@ def main():
                                    "DSP path (HOT-1 + HOT-2) from resident f0 / raw controls ~N(0,1) / uniform noise, "
                                    "signal only" % (a.model, B, a.seconds, F, T, n, n, n),
                        "batch_per_gpu": B, "frames": F, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
-            "roofline": {"kernel": "k_fir_mfma", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": traffic["bytes"] if traffic else None,
-                         "traffic_detail": traffic, "algorithmic_bytes_per_launch": fir_bytes,
-                         "avg_ms": fir_ms, "launches_per_step": fir_launches,
-                         "algorithmic_flops_per_launch": fir_flops,
-                         "note": "f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak at 2.4 GHz; the kernel runs at ~2.05 GHz "
-                                 "under load and issues 1.29x the algorithmic MFMAs (DESIGN.md section 5)"},
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": fir_bytes / (fir_ms * 1e-3) / 1e9, "peak": 8000.0,
+                         "unit": "GB/s", "frac": fir_bytes / (fir_ms * 1e-3) / 1e9 / 8000.0,
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+                         "algorithmic_bytes_per_launch": fir_bytes, "avg_ms": fir_ms, "launches_per_step": fir_launches,
+                         "note": "north-star roofline (algorithmic HBM bytes / time).  The kernel is NOT HBM-bound: see "
+                                 "roofline_compute for the roof that binds it (DESIGN.md section 5)"},
+            "roofline_compute": (
+                {"kernel": "k_fir_fft", "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
+                 "achieved": fft_flops / (fir_ms * 1e-3) / 1e12, "frac": fft_flops / (fir_ms * 1e-3) / 1e12 / 157.3,
+                 "executed_flops_per_launch": fft_flops,
+                 "direct_form_equivalent_TFLOPs": fir_flops / (fir_ms * 1e-3) / 1e12,
+                 "note": "vector f32 peak counts packed FMA; FFT butterflies are add/sub/mul (no FMA) so the attainable "
+                         "issue rate is at most half of it"} if used_impl == 4 else
+                {"kernel": "k_fir_mfma", "bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                 "achieved": fir_flops / (fir_ms * 1e-3) / 1e12, "frac": fir_flops / (fir_ms * 1e-3) / 1e12 / 157.3,
+                 "algorithmic_flops_per_launch": fir_flops}),
+            "roofline_mfma_direct_form": {"kernel": "k_fir_mfma", "bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                                          "achieved": fir_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None,
+                                          "frac": fir_flops / (mfma_ms * 1e-3) / 1e12 / 157.3 if mfma_ms else None,
+                                          "avg_ms": mfma_ms, "algorithmic_flops_per_launch": fir_flops,
+                                          "note": "the direct form on v_mfma_f32_16x16x4_f32, used for shapes outside the "
+                                                  "FFT form; ~2.05 GHz under load, 1.29x issued/algorithmic MFMAs"},
             "roofline_step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes,
                                   "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},

@@ -15,6 +15,7 @@
 // with inner dimension N+15 >= 16: it runs on the f32 MFMA pipe (v_mfma_f32_16x16x4_f32, exact
 // f32 fmaf chains), one 16x16 accumulator per wave, both operands read from LDS.
 #include "ddsp_common.h"
+#include "kernels.h"
 #include <stdlib.h>
 
 namespace ddsp {
@@ -393,7 +394,8 @@ size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves) {
   return ((size_t)g.WWORDS + (size_t)g.NJ * g.HLEN + FIR_TAIL) * sizeof(float);
 }
 
-// impl: 0 = auto, 1 = simple, 2 = mfma with 4 waves (1024 outputs) per tile, 3 = mfma with 8 waves.
+// impl: 0 = auto, 1 = simple, 2 = mfma with 4 waves (1024 outputs) per tile, 3 = mfma with 8 waves,
+// 4 = FFT-domain block convolution (fir_fft.hip; hop 512, N <= 512).
 // Returns the implementation used, or <0 when the requested kernel cannot take the shape.
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                int B, int F, int hop, int N, int impl, hipStream_t st) {
@@ -405,6 +407,9 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
   const bool vec_ok = hop >= 16 && (hop & 3) == 0 && N >= 4 && N <= 1022 && T < (1L << 30) && al(x, 16) && al(out, 16) &&
                       al(taps, 8) && (!addend || al(addend, 16)) && (!out_plain || al(out_plain, 16));
   auto fits = [&](int waves) { return vec_ok && fir_mfma_lds_bytes(F, hop, N, waves) <= 64 * 1024; };
+  // auto: the FFT form where it applies (hop 512, N <= 512), else the MFMA direct form, else the simple kernel
+  if (impl == 0 && hop == 512 && N <= 512) impl = 4;
+  if (impl == 4) return launch_fir_fft(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
   if (impl == 0) impl = fits(8) ? 3 : fits(4) ? 2 : 1;
   if ((impl == 2 && !fits(4)) || (impl == 3 && !fits(8))) return -1;
   if (impl == 2 || impl == 3) {

@@ -24,4 +24,6 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
 size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves);
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                int B, int F, int hop, int N, int impl, hipStream_t st);
+int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
+                   int B, int F, int hop, int N, hipStream_t st);
 }  // namespace ddsp
