@@ -1,14 +1,17 @@
-// 2048-point complex FFT for one 128-thread workgroup (2 waves), 16 points per thread, data in
-// registers, two LDS exchanges.  Building block of the FFT-domain time-varying FIR (fir_fft.hip).
+// 2048-point complex FFT for one 256-thread workgroup (4 waves), 8 points per thread, data in registers,
+// three LDS exchanges through two ping-pong buffers.  Building block of the FFT-domain time-varying FIR.
 //
-// Decimation in frequency with N = 16 * 16 * 8:  n = 128 n1 + 8 n2 + n3,  k = k1 + 16 k2 + 256 k3
-//   pass 1  thread p = 8 n2 + n3 holds z[128 n1 + p]: 16-point DFT over n1, times W_2048^(p k1)
-//   pass 2  thread q = 8 k1 + n3 gathers n2 = 0..15:   16-point DFT over n2, times W_128^(n3 k2)
-//   pass 3  thread r = (k1 = r & 15, k2 = (r >> 4) + 8 s), s = 0,1: two 8-point DFTs over n3
-// so thread r ends with Z[r + 128 s + 256 k3] = Z[128 m + r], m = s + 2 k3: the same "slot m, lane r"
-// layout the input had.  Natural-order LDS traffic (k = 128 m + r) is therefore conflict-free, and the
-// inverse transform (conjugate, forward, conjugate) chains without any reordering.
-// Complex values are f32x2 so adds / multiplies become packed-f32 instructions.
+// Decimation in frequency with N = 8 * 8 * 8 * 4:
+//      n = 256 n1 + 32 n2 + 4 n3 + n4,      k = k1 + 8 k2 + 64 k3 + 512 k4
+//   pass 1  thread p = tid holds z[256 n1 + p]:            DFT8 over n1, times W_2048^(p k1)       -> A[k1][p]
+//   pass 2  thread (k1 = tid >> 5, c = tid & 31 = 4 n3 + n4): DFT8 over n2, times W_256^(c k2)       -> B[n3][k2][k1^n3][n4]
+//   pass 3  thread tid = n4 + 4 k1 + 32 k2:                  DFT8 over n3, times W_32^(n4 k3)        -> A[k3][k2][k1][n4]
+//   pass 4  thread r = k1 + 8 k2 + 64 (k3 & 3), s = k3 >> 2 = 0,1: two DFT4 over n4
+// so thread r ends with Z[r + 256 s + 512 k4] = Z[256 m + r], m = s + 2 k4: the same "slot m, lane r" layout
+// the input had.  Natural-order LDS traffic (k = 256 m + r) is conflict-free and the inverse transform
+// (conjugate, forward, conjugate) chains without reordering.  Every exchange is written and read with lane-
+// consecutive addresses except the pass-2 stores, whose rows are XOR-swizzled by n3 (at most 2-way conflicts).
+// Complex values are f32x2 so adds / multiplies become packed-f32 instructions (v_pk_add/mul/fma_f32).
 #pragma once
 #include "ddsp_common.h"
 
@@ -16,120 +19,189 @@ namespace ddsp {
 namespace fft {
 
 constexpr int N = 2048;
-constexpr int THREADS = 128;
-constexpr int ROW = 136;                 // exchange row stride in complex words (128 + 8: rows 8 banks-pairs apart)
-constexpr int EX_WORDS = 16 * ROW;       // complex words in the exchange buffer (>= N)
+constexpr int THREADS = 256;
+constexpr int SLOTS = N / THREADS;       // complex points per thread
+constexpr int EX_WORDS = N;              // complex words per exchange buffer
 
+// Complex helpers.  A complex number is one 64-bit VGPR pair; rotations by +-i, conjugation and the cross terms
+// of a complex product are operand swizzles (op_sel / op_sel_hi) and sign bits (neg_lo / neg_hi) of the packed
+// instructions, written out as inline assembly in the device pass because the compiler otherwise materialises
+// them with v_mov / v_xor.  The host pass (and the CPU emulator of the test-suite) sees the plain C++ form.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DDSP_PK2(res, text, a, b) asm(text : "=v"(res) : "v"(a), "v"(b))
+#define DDSP_PK3(res, text, a, b, c) asm(text : "=v"(res) : "v"(a), "v"(b), "v"(c))
+#endif
+
+// a * b
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 t, r;
+  DDSP_PK2(t, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]", a, b);                                     // (ax bx, ax by)
+  DDSP_PK3(r, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", a, b, t);  // + (-ay by, ay bx)
+  return r;
+#else
   const f32x2 t = f32x2{a.x, a.x} * b;
   return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-b.y, b.x}, t);
+#endif
 }
-__device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }     // a * (-i)
+// t + (-i) d
+__device__ __forceinline__ f32x2 add_mi(f32x2 t, f32x2 d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]", t, d);
+  return r;
+#else
+  return t + f32x2{d.y, -d.x};
+#endif
+}
+// t - (-i) d
+__device__ __forceinline__ f32x2 sub_mi(f32x2 t, f32x2 d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]", t, d);
+  return r;
+#else
+  return t - f32x2{d.y, -d.x};
+#endif
+}
+// a + conj(z)  and  a - conj(z)
+__device__ __forceinline__ f32x2 add_conj(f32x2 a, f32x2 z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]", a, z);
+  return r;
+#else
+  return f32x2{a.x + z.x, a.y - z.y};
+#endif
+}
+__device__ __forceinline__ f32x2 sub_conj(f32x2 a, f32x2 z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]", a, z);
+  return r;
+#else
+  return f32x2{a.x - z.x, a.y + z.y};
+#endif
+}
+// (p.y * q.x, p.x * q.y): swap the halves of p, scale per half
+__device__ __forceinline__ f32x2 swap_scale(f32x2 p, f32x2 q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]", p, q);
+  return r;
+#else
+  return f32x2{p.y * q.x, p.x * q.y};
+#endif
+}
+// (v.x - g.y, -v.y - g.x) = conj(v) - i conj(g)
+__device__ __forceinline__ f32x2 conj_minus_i_conj(f32x2 v, f32x2 g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK2(r, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]", v, g);
+  return r;
+#else
+  return f32x2{v.x - g.y, -v.y - g.x};
+#endif
+}
 __device__ __forceinline__ f32x2 cconj(f32x2 a) { return f32x2{a.x, -a.y}; }
 
 // forward 4-point DFT (W4 = -i), in place: (a0,a1,a2,a3) -> (X0,X1,X2,X3)
 __device__ __forceinline__ void dft4(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3) {
-  const f32x2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+  const f32x2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
   a0 = t0 + t2;
   a2 = t0 - t2;
-  a1 = t1 + t3;
-  a3 = t1 - t3;
+  a1 = add_mi(t1, d);
+  a3 = sub_mi(t1, d);
+}
+// the same with input a2 still to be multiplied by -i (folded into the first butterfly)
+__device__ __forceinline__ void dft4_rot2(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3) {
+  const f32x2 t0 = add_mi(a0, a2), t1 = sub_mi(a0, a2), t2 = a1 + a3, d = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_mi(t1, d);
+  a3 = sub_mi(t1, d);
 }
 
-// forward 16-point DFT in place: v[n] -> v[k]
-__device__ __forceinline__ void dft16(f32x2 (&v)[16]) {
-  const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);        // v[4 k' + b] = T[k'][b]
-  // T[k'][b] *= W16^(b k')
-  v[4 + 1] = cmul(v[4 + 1], f32x2{C1, -S1});
-  v[4 + 2] = cmul(v[4 + 2], f32x2{H, -H});
-  v[4 + 3] = cmul(v[4 + 3], f32x2{S1, -C1});
-  v[8 + 1] = cmul(v[8 + 1], f32x2{H, -H});
-  v[8 + 2] = mul_mi(v[8 + 2]);
-  v[8 + 3] = cmul(v[8 + 3], f32x2{-H, -H});
-  v[12 + 1] = cmul(v[12 + 1], f32x2{S1, -C1});
-  v[12 + 2] = cmul(v[12 + 2], f32x2{-H, -H});
-  v[12 + 3] = cmul(v[12 + 3], f32x2{-C1, S1});
-#pragma unroll
-  for (int k = 0; k < 4; ++k) dft4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);   // -> X[k + 4 j] at v[4k + j]
-  // transpose the 4x4 index so that v[k] = X[k]
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int j = k + 1; j < 4; ++j) {
-      const f32x2 t = v[4 * k + j];
-      v[4 * k + j] = v[4 * j + k];
-      v[4 * j + k] = t;
-    }
-}
-
-// forward 8-point DFT in place on v[0..7]
+// forward 8-point DFT in place on v[0..7]  (n = 4 a + b, k = a' + 2 b')
 __device__ __forceinline__ void dft8(f32x2* v) {
   const float H = 0.70710678118654752f;
-  f32x2 e0 = v[0] + v[4], e1 = v[1] + v[5], e2 = v[2] + v[6], e3 = v[3] + v[7];     // k' = 0
-  f32x2 o0 = v[0] - v[4], o1 = v[1] - v[5], o2 = v[2] - v[6], o3 = v[3] - v[7];     // k' = 1, then * W8^b
+  f32x2 e0 = v[0] + v[4], e1 = v[1] + v[5], e2 = v[2] + v[6], e3 = v[3] + v[7];     // a' = 0
+  f32x2 o0 = v[0] - v[4], o1 = v[1] - v[5], o2 = v[2] - v[6], o3 = v[3] - v[7];     // a' = 1, then * W8^b
   o1 = cmul(o1, f32x2{H, -H});
-  o2 = mul_mi(o2);
   o3 = cmul(o3, f32x2{-H, -H});
   dft4(e0, e1, e2, e3);                    // X[0], X[2], X[4], X[6]
-  dft4(o0, o1, o2, o3);                    // X[1], X[3], X[5], X[7]
+  dft4_rot2(o0, o1, o2, o3);               // X[1], X[3], X[5], X[7]   (o2 * W8^2 = o2 * -i inside)
   v[0] = e0; v[2] = e1; v[4] = e2; v[6] = e3;
   v[1] = o0; v[3] = o1; v[5] = o2; v[7] = o3;
 }
 
-// per-thread twiddles, computed once per workgroup lifetime
+// per-thread twiddles, computed once per workgroup lifetime (exact arguments: multiples of 2^-10)
 struct Twiddles {
-  f32x2 w1[16];      // W_2048^(p k1),      p = tid            (pass 1)
-  f32x2 w2[16];      // W_128^(n3 k2),      n3 = tid & 7       (pass 2)
+  f32x2 w1[8];       // W_2048^(p k),   p = tid
+  f32x2 w2[8];       // W_256^(c k),    c = tid & 31
+  f32x2 w3[8];       // W_32^(n4 k),    n4 = tid & 3
   __device__ __forceinline__ void init(int tid) {
-    const int n3 = tid & 7;
+    const int c = tid & 31, n4 = tid & 3;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float s, c;
-      sincospif(-(float)((tid * k) & 2047) / 1024.0f, &s, &c);       // exact argument: m/1024, m < 2048
-      w1[k] = f32x2{c, s};
-      sincospif(-(float)((n3 * k) & 127) / 64.0f, &s, &c);
-      w2[k] = f32x2{c, s};
+    for (int k = 0; k < 8; ++k) {
+      float s, co;
+      sincospif(-(float)((tid * k) & 2047) / 1024.0f, &s, &co);
+      w1[k] = f32x2{co, s};
+      sincospif(-(float)((c * k) & 255) / 128.0f, &s, &co);
+      w2[k] = f32x2{co, s};
+      sincospif(-(float)((n4 * k) & 31) / 16.0f, &s, &co);
+      w3[k] = f32x2{co, s};
     }
   }
 };
 
-// v[n1] = z[128 n1 + tid]  ->  v[m] = Z[128 m + tid].  ex: EX_WORDS complex words of LDS, free on entry
-// (every thread past its last read of it) and free again on return.
-__device__ __forceinline__ void forward(f32x2 (&v)[16], const Twiddles& tw, f32x2* ex, int tid) {
-  dft16(v);
+// v[n1] = z[256 n1 + tid]  ->  v[m] = Z[256 m + tid].
+// Buffers: A must be free of readers on entry; on return A may still be read by slower waves (pass 4) and B
+// is free.  A caller that next WRITES B and synchronises before touching A again needs no extra barrier.
+__device__ __forceinline__ void forward(f32x2 (&v)[8], const Twiddles& tw, f32x2* A, f32x2* B, int tid) {
+  dft8(v);
 #pragma unroll
-  for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.w1[k]);
+  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) ex[k * ROW + tid] = v[k];                 // [k1][p]
+  for (int k = 0; k < 8; ++k) A[k * 256 + tid] = v[k];                          // [k1][p]
   __syncthreads();
-  const int k1 = tid >> 3, n3 = tid & 7;
+  {
+    const int k1 = tid >> 5, c = tid & 31;
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) v[n2] = ex[k1 * ROW + n2 * 8 + n3];
-  __syncthreads();                                                       // rows are rewritten in place below
-  dft16(v);
+    for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * 256 + n2 * 32 + c];
+    dft8(v);
 #pragma unroll
-  for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.w2[k]);
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+    const int n3 = c >> 2, n4 = c & 3;
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) ex[k1 * ROW + k2 * 8 + n3] = v[k2];    // [k1][k2][n3]
+    for (int k2 = 0; k2 < 8; ++k2) B[n3 * 256 + ((k2 * 32 + k1 * 4 + n4) ^ (n3 * 4))] = v[k2];   // [n3][k2][k1 ^ n3][n4]
+  }
   __syncthreads();
-  const int r1 = tid & 15, r2 = tid >> 4;
+  {
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * 256 + (tid ^ (n3 * 4))];      // tid = n4 + 4 k1 + 32 k2
+    dft8(v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[8 * s + j] = ex[r1 * ROW + (r2 + 8 * s) * 8 + j];
-  __syncthreads();                                                       // exchange buffer free again
-  dft8(&v[0]);
-  dft8(&v[8]);
-  // v[8 s + k3] = Z[tid + 128 s + 256 k3]  ->  slot m = s + 2 k3
-  f32x2 t[16];
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int k3 = 0; k3 < 8; ++k3) A[k3 * 256 + tid] = v[k3];                   // [k3][k2][k1][n4], k1 = (tid>>2)&7, k2 = tid>>5
+  }
+  __syncthreads();
+  {
+    // r = k1' + 8 k2' + 64 k3lo reads (k1', k2', k3 = k3lo + 4 s): word k3 * 256 + (k2' * 32 + k1' * 4) + n4
+    const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
+    const f32x2* src = A + k2 * 32 + k1 * 4;
+    f32x2 t[8];
 #pragma unroll
-    for (int k3 = 0; k3 < 8; ++k3) t[s + 2 * k3] = v[8 * s + k3];
+    for (int s = 0; s < 2; ++s) {
+      f32x2 a0 = src[(k3lo + 4 * s) * 256 + 0], a1 = src[(k3lo + 4 * s) * 256 + 1];
+      f32x2 a2 = src[(k3lo + 4 * s) * 256 + 2], a3 = src[(k3lo + 4 * s) * 256 + 3];
+      dft4(a0, a1, a2, a3);                                                       // k4 = 0..3 -> slot m = s + 2 k4
+      t[s] = a0; t[s + 2] = a1; t[s + 4] = a2; t[s + 6] = a3;
+    }
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = t[m];
+    for (int m = 0; m < 8; ++m) v[m] = t[m];
+  }
 }
 
 }  // namespace fft

@@ -8,7 +8,7 @@
 // N <= 512 the linear convolution (<= 1535 samples) fits a 2048-point transform without time aliasing
 // (core.py:165 pads to 1533) and two consecutive frames fit the 2048-sample overlap-add ring.
 //
-// Per PAIR of frames (j, j+1) a 128-thread workgroup runs three 2048-point complex FFTs (fft2048.h):
+// Per PAIR of frames (j, j+1) a 256-thread workgroup runs three 2048-point complex FFTs (fft2048.h):
 //   Z_j   = FFT(chunk_j + i * s_j * taps_j)        two real sequences per transform; s_j = power of two that
 //   Z_j+1 = FFT(chunk_j+1 + i * s_j+1 * taps_j+1)   balances their magnitudes (exact to undo)
 //   G[k]  = (Z[k] + conj Z[-k]) (Z[k] - conj Z[-k]) / 4i  = X[k] H[k]          (Hermitian by construction)
@@ -25,7 +25,6 @@
 
 namespace ddsp {
 
-using fft::cconj;
 using fft::cmul;
 
 constexpr int FF_HOP = 512;
@@ -37,20 +36,21 @@ struct FirFftGeom {
   int runs_per_utt;       // ceil(pairs / run)
 };
 
-// G = X H from the packed spectrum: a = Z[k], b = conj(Z[-k]);  X = (a + b)/2, H = (a - b)/2i
-__device__ __forceinline__ f32x2 packed_product(f32x2 a, f32x2 zneg) {
-  const f32x2 b = cconj(zneg);
-  const f32x2 p = cmul(a + b, a - b);                // = 4i X H
-  return f32x2{0.25f * p.y, -0.25f * p.x};           // / 4i
+// G = X H from the packed spectrum: a = Z[k], zneg = Z[-k], b = conj(zneg);  X = (a + b)/2, H = (a - b)/2i,
+// so (a + b)(a - b) = 4i X H and G = p / 4i = (p.y, -p.x) / 4; q = (s/4, -s/4) also undoes the tap scaling.
+__device__ __forceinline__ f32x2 packed_product(f32x2 a, f32x2 zneg, f32x2 q) {
+  const f32x2 p = cmul(fft::add_conj(a, zneg), fft::sub_conj(a, zneg));
+  return fft::swap_scale(p, q);
 }
 
-__global__ void __launch_bounds__(fft::THREADS) k_fir_fft(const float* __restrict__ x, int x_is_u01,
+__global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __restrict__ x, int x_is_u01,
                                                           const float* __restrict__ taps,
                                                           const float* __restrict__ addend, float* __restrict__ out,
                                                           float* __restrict__ out_plain, FirFftGeom g) {
-  __shared__ __attribute__((aligned(16))) f32x2 ex[fft::EX_WORDS];
-  __shared__ float ring[fft::N];
-  __shared__ float red[4];
+  constexpr int S = fft::SLOTS;                               // 8 complex points per thread, point k = 256 m + tid
+  __shared__ __attribute__((aligned(16))) f32x2 exA[fft::EX_WORDS];
+  __shared__ __attribute__((aligned(16))) f32x2 exB[fft::EX_WORDS];
+  __shared__ float ring[fft::N];             // 2 x 16 KB + 8 KB = 40 KB exactly: four workgroups per CU
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -66,53 +66,66 @@ __global__ void __launch_bounds__(fft::THREADS) k_fir_fft(const float* __restric
   fft::Twiddles tw;
   tw.init(tid);
 #pragma unroll
-  for (int m = 0; m < 16; ++m) ring[128 * m + tid] = 0.f;
+  for (int m = 0; m < S; ++m) ring[256 * m + tid] = 0.f;
 
-  for (int pr = (p_first > 0 ? p_first - 1 : 0); pr < p_last; ++pr) {
-    f32x2 V[16];
+  // inputs of one frame: 4 chunk samples (already Bartlett-weighted) and 2 taps per thread
+  struct Frame { float xv[4], hv[2]; };
+  auto load_frame = [&](int j) -> Frame {
+    Frame f;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) V[m] = f32x2{0.f, 0.f};
+    for (int m = 0; m < 4; ++m) f.xv[m] = 0.f;
+    f.hv[0] = f.hv[1] = 0.f;
+    if (j <= g.F) {                                           // j == F + 1 only pads an odd frame count
+      const int s0 = (j - 1) * FF_HOP;
+      const int row = j < g.F ? j : g.F - 1;                  // core.py:167
+      const float* tr = tb + (long)row * g.N;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (256 * m + tid < g.N) f.hv[m] = tr[256 * m + tid];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int n = 256 * m + tid;
+        const int sidx = s0 + n;
+        if (sidx >= 0 && sidx < g.T) {
+          float xv = xb[sidx];
+          if (x_is_u01) xv = fmaf(2.0f, xv, -1.0f);           // noise = rand*2-1 (vocoder.py:603,854)
+          const float lam = (float)(n & (FF_HOP - 1)) * inv_hop;
+          f.xv[m] = (n < FF_HOP ? lam : 1.0f - lam) * xv;     // periodic Bartlett (core.py:161)
+        }
+      }
+    }
+    return f;
+  };
+
+  const int pr0 = p_first > 0 ? p_first - 1 : 0;
+  Frame nxt = load_frame(2 * pr0);
+  for (int pr = pr0; pr < p_last; ++pr) {
+    f32x2 V[S];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int j = 2 * pr + h;                               // frame index; j == F + 1 only pads an odd frame count
-      f32x2 z[16];
+      const Frame cur = nxt;
+      // the next frame's global loads are issued now and land while this frame is transformed
+      nxt = load_frame(2 * pr + h + 1);
       float mx = 0.f, mh = 0.f;
-      if (j <= g.F) {
-        const int s0 = (j - 1) * FF_HOP;
-        const int row = j < g.F ? j : g.F - 1;
-        const float* tr = tb + (long)row * g.N;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          const int n = 128 * m + tid;
-          float xv = 0.f, hv = 0.f;
-          if (m < 4 && n < g.N) hv = tr[n];                   // N <= 512
-          if (m < 8) {                                        // chunk: 2 hop = 1024 samples
-            const int s = s0 + n;
-            if (s >= 0 && s < g.T) {
-              xv = xb[s];
-              if (x_is_u01) xv = fmaf(2.0f, xv, -1.0f);       // noise = rand*2-1 (vocoder.py:603,854)
-              const float lam = (float)(n & (FF_HOP - 1)) * inv_hop;
-              xv = (n < FF_HOP ? lam : 1.0f - lam) * xv;      // periodic Bartlett (core.py:161)
-            }
-          }
-          z[m] = f32x2{xv, hv};
-          mx = fmaxf(mx, fabsf(xv));
-          mh = fmaxf(mh, fabsf(hv));
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) z[m] = f32x2{0.f, 0.f};
-      }
+      for (int m = 0; m < 4; ++m) mx = fmaxf(mx, fabsf(cur.xv[m]));
+      mh = fmaxf(fabsf(cur.hv[0]), fabsf(cur.hv[1]));
       // workgroup-wide maxima -> power-of-two balance factor for the tap sequence
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, d));
-        mh = fmaxf(mh, __shfl_xor(mh, d));
+      mx = wave_max_nonneg(mx);
+      mh = wave_max_nonneg(mh);
+      // the four waves meet through 8 ring slots at the far end of the window: they belong to samples this pair
+      // only reaches with its second overlap-add, and are zeroed again before that (see below)
+      float* red = ring;
+      const int rbase = (2 * pr - 1) * FF_HOP - D + fft::N - 8;
+      if ((tid & 63) == 0) {
+        red[(rbase + (tid >> 6) * 2) & (fft::N - 1)] = mx;
+        red[(rbase + (tid >> 6) * 2 + 1) & (fft::N - 1)] = mh;
       }
-      if ((tid & 63) == 0) { red[(tid >> 6) * 2] = mx; red[(tid >> 6) * 2 + 1] = mh; }
       __syncthreads();
-      mx = fmaxf(red[0], red[2]);
-      mh = fmaxf(red[1], red[3]);
+      mx = fmaxf(fmaxf(red[rbase & (fft::N - 1)], red[(rbase + 2) & (fft::N - 1)]),
+                 fmaxf(red[(rbase + 4) & (fft::N - 1)], red[(rbase + 6) & (fft::N - 1)]));
+      mh = fmaxf(fmaxf(red[(rbase + 1) & (fft::N - 1)], red[(rbase + 3) & (fft::N - 1)]),
+                 fmaxf(red[(rbase + 5) & (fft::N - 1)], red[(rbase + 7) & (fft::N - 1)]));
       float sc = 1.0f, isc = 1.0f;
       if (mx > 0.f && mh > 0.f) {
         int e = ilogbf(mx) - ilogbf(mh);
@@ -120,46 +133,50 @@ __global__ void __launch_bounds__(fft::THREADS) k_fir_fft(const float* __restric
         sc = ldexpf(1.0f, e);
         isc = ldexpf(1.0f, -e);
       }
+      const f32x2 q = {0.25f * isc, -0.25f * isc};
+      f32x2 z[S];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) z[m].y *= sc;               // N <= 512: the taps live in slots 0..3
-      fft::forward(z, tw, ex, tid);
-      // natural order to LDS, then G[k] from Z[k] and Z[-k]
+      for (int m = 0; m < S; ++m) z[m] = f32x2{m < 4 ? cur.xv[m] : 0.f, m < 2 ? cur.hv[m] * sc : 0.f};
+      fft::forward(z, tw, exA, exB, tid);
+      // natural order to LDS (buffer B is free), then G[k] from Z[k] and Z[-k]
 #pragma unroll
-      for (int m = 0; m < 16; ++m) ex[128 * m + tid] = z[m];
+      for (int m = 0; m < S; ++m) exB[256 * m + tid] = z[m];
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int k = 128 * m + tid;
-        const f32x2 G = packed_product(z[m], ex[(fft::N - k) & (fft::N - 1)]) * isc;
+      for (int m = 0; m < S; ++m) {
+        const int k = 256 * m + tid;
+        const f32x2 G = packed_product(z[m], exB[(fft::N - k) & (fft::N - 1)], q);
         // V = G_j + i G_j+1, conjugated for the inverse-by-forward trick:  conj(V) = conj(G_j) - i conj(G_j+1)
-        if (h == 0) V[m] = cconj(G);
-        else V[m] = V[m] + f32x2{-G.y, -G.x};                 // -i * conj(G) = -i (Gx - i Gy) = (-Gy, -Gx)
+        if (h == 0) V[m] = G;
+        else V[m] = fft::conj_minus_i_conj(V[m], G);
       }
-      __syncthreads();                                        // ex free for the next transform
+      // no barrier here: the next transform first writes A (whose pass-4 readers all passed the barrier above)
+      // and touches B only after its own first barrier
     }
-    fft::forward(V, tw, ex, tid);
+    fft::forward(V, tw, exA, exB, tid);
     // ifft(V) = conj(FFT(conj V)) / 2048:  out_j = Re / 2048,  out_j+1 = -Im / 2048
     const int a0 = (2 * pr - 1) * FF_HOP - D;                 // output position of frame 2 pr's first sample
     const float scale = 1.0f / 2048.0f;
 #pragma unroll
-    for (int m = 0; m < 12; ++m) {                            // the linear convolution ends at 2 hop + N - 2 < 1536
-      const int n = 128 * m + tid;
+    for (int m = 0; m < 6; ++m) {                             // the linear convolution ends at 2 hop + N - 2 < 1536
+      const int n = 256 * m + tid;
       ring[(a0 + n) & (fft::N - 1)] += V[m].x * scale;
     }
+    if (tid < 8) ring[(a0 + fft::N - 8 + tid) & (fft::N - 1)] = 0.f;     // the borrowed reduction slots
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 12; ++m) {
-      const int n = 128 * m + tid;
+    for (int m = 0; m < 6; ++m) {
+      const int n = 256 * m + tid;
       ring[(a0 + FF_HOP + n) & (fft::N - 1)] -= V[m].y * scale;
     }
     __syncthreads();
     // samples [a0, a0 + 2 hop) are complete once both frames are in; the last pair also flushes the tail
     const bool own = pr >= p_first;
-    const int n_emit = (pr == g.pairs - 1) ? 16 : 8;
+    const int n_emit = (pr == g.pairs - 1) ? 8 : 4;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < S; ++m) {
       if (m < n_emit) {
-        const int t = a0 + 128 * m + tid;
+        const int t = a0 + 256 * m + tid;
         const int ri = t & (fft::N - 1);
         const float v = ring[ri];
         ring[ri] = 0.f;
@@ -169,7 +186,7 @@ __global__ void __launch_bounds__(fft::THREADS) k_fir_fft(const float* __restric
         }
       }
     }
-    __syncthreads();
+    // the zeroed ring slots are next written after the barriers inside the coming transforms
   }
 }
 
@@ -181,7 +198,7 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 2) / 2;
   // run length (own pairs per workgroup): as many workgroups as the chip holds at once (4 per CU at this
-  // kernel's register budget), so all of them run in one round with equal work; every run pays one warm-up pair
+  // kernel's LDS budget), so all of them run in one round with equal work; every run pays one warm-up pair
   const long slots = 4 * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;

@@ -151,6 +151,20 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane_emu(T v) {
   return hipemu::peek<T>(s, 0);
 }
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
+// DPP subset used by the kernels: quad_perm (ctrl < 0x100), row_half_mirror (0x141), row_mirror (0x140); full masks
+static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+  auto s = hipemu::exchange(src);
+  int l = hipemu::g.cur->lane, from;
+  if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+  else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+  else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+  else { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  return hipemu::peek<int>(s, from);
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) {
+  auto s = hipemu::exchange(v);
+  return hipemu::peek<int>(s, lane);
+}
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
