@@ -84,21 +84,17 @@ __device__ __forceinline__ double wave_excl_scan(double v, int lane) {
   return inc - v;
 }
 
-// maximum of a non-negative float over the 64 lanes of a wave, returned wave-uniform.  Four DPP butterflies
-// (quad_perm, quad_perm, row_half_mirror, row_mirror) give every lane its 16-lane row maximum on the VALU --
-// no LDS crossbar as __shfl_xor would use -- then four readlanes and scalar max (bit patterns of non-negative
-// floats order like unsigned integers).
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-  int x = __float_as_int(v);
-  int y;
-  y = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;     // quad_perm [1,0,3,2]
-  y = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;     // quad_perm [2,3,0,1]
-  y = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;    // row_half_mirror
-  y = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;    // row_mirror
-  const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
-  const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
-  const int ab = a > b ? a : b, cd = c > d ? c : d;
-  return __int_as_float(ab > cd ? ab : cd);
+// sum of a float over the 64 lanes of a wave, returned wave-uniform.  Four DPP butterflies (quad_perm,
+// quad_perm, row_half_mirror, row_mirror) give every lane its 16-lane row sum on the VALU -- no LDS crossbar as
+// __shfl_xor would use -- then four readlanes.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));    // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));    // row_mirror
+  const int x = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(x, 0)) + __int_as_float(__builtin_amdgcn_readlane(x, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(x, 32)) + __int_as_float(__builtin_amdgcn_readlane(x, 48)));
 }
 
 // torch.sinc on a float32 tensor: sin(fl32(pi32*z)) / fl32(pi32*z), 1 at z == 0 (vocoder.py:839)

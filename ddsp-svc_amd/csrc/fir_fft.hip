@@ -106,29 +106,30 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
       const Frame cur = nxt;
       // the next frame's global loads are issued now and land while this frame is transformed
       nxt = load_frame(2 * pr + h + 1);
-      float mx = 0.f, mh = 0.f;
+      // energies of the two sequences -> power-of-two balance factor for the taps (their spectra then have the
+      // same mean magnitude; a packed transform rounds relative to the larger one)
+      float sx = 0.f, sh = 0.f;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) mx = fmaxf(mx, fabsf(cur.xv[m]));
-      mh = fmaxf(fabsf(cur.hv[0]), fabsf(cur.hv[1]));
-      // workgroup-wide maxima -> power-of-two balance factor for the tap sequence
-      mx = wave_max_nonneg(mx);
-      mh = wave_max_nonneg(mh);
+      for (int m = 0; m < 4; ++m) sx = fmaf(cur.xv[m], cur.xv[m], sx);
+      sh = fmaf(cur.hv[0], cur.hv[0], cur.hv[1] * cur.hv[1]);
+      sx = wave_sum_dpp(sx);
+      sh = wave_sum_dpp(sh);
       // the four waves meet through 8 ring slots at the far end of the window: they belong to samples this pair
       // only reaches with its second overlap-add, and are zeroed again before that (see below)
       float* red = ring;
       const int rbase = (2 * pr - 1) * FF_HOP - D + fft::N - 8;
       if ((tid & 63) == 0) {
-        red[(rbase + (tid >> 6) * 2) & (fft::N - 1)] = mx;
-        red[(rbase + (tid >> 6) * 2 + 1) & (fft::N - 1)] = mh;
+        red[(rbase + (tid >> 6) * 2) & (fft::N - 1)] = sx;
+        red[(rbase + (tid >> 6) * 2 + 1) & (fft::N - 1)] = sh;
       }
       __syncthreads();
-      mx = fmaxf(fmaxf(red[rbase & (fft::N - 1)], red[(rbase + 2) & (fft::N - 1)]),
-                 fmaxf(red[(rbase + 4) & (fft::N - 1)], red[(rbase + 6) & (fft::N - 1)]));
-      mh = fmaxf(fmaxf(red[(rbase + 1) & (fft::N - 1)], red[(rbase + 3) & (fft::N - 1)]),
-                 fmaxf(red[(rbase + 5) & (fft::N - 1)], red[(rbase + 7) & (fft::N - 1)]));
+      sx = (red[rbase & (fft::N - 1)] + red[(rbase + 2) & (fft::N - 1)]) +
+           (red[(rbase + 4) & (fft::N - 1)] + red[(rbase + 6) & (fft::N - 1)]);
+      sh = (red[(rbase + 1) & (fft::N - 1)] + red[(rbase + 3) & (fft::N - 1)]) +
+           (red[(rbase + 5) & (fft::N - 1)] + red[(rbase + 7) & (fft::N - 1)]);
       float sc = 1.0f, isc = 1.0f;
-      if (mx > 0.f && mh > 0.f) {
-        int e = ilogbf(mx) - ilogbf(mh);
+      if (sx > 0.f && sh > 0.f && sx < 3e38f && sh < 3e38f) {
+        int e = (ilogbf(sx) - ilogbf(sh)) >> 1;               // sqrt of the energy ratio, as a power of two
         e = e < -60 ? -60 : (e > 60 ? 60 : e);
         sc = ldexpf(1.0f, e);
         isc = ldexpf(1.0f, -e);

@@ -1,0 +1,138 @@
+"""Full-size (BASELINE.json cfg 2 / cfg 3: B = 32 utterances x 10 s, 256/256/256 bins) checks on the MI355X.
+
+The oracle needs minutes for a batch of this size, so parity here goes through size-independent properties of
+the operators plus an oracle comparison of a few utterances cut out of the full batch (utterances are
+independent, so row b of the batched result must equal the single-utterance result).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddsp_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR, HOP = 44100, 512
+B, F, NB = 32, 862, 256
+T, N = F * HOP, 2 * (NB - 1)
+
+
+def rms(a):
+    a = a.double() if torch.is_tensor(a) else torch.as_tensor(a, dtype=torch.float64)
+    return float(a.pow(2).mean().sqrt())
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def batch(cuda):
+    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=1234)).to(cuda)
+    g = torch.Generator().manual_seed(7)
+    ctrl = torch.randn(B, F, 3 * NB, generator=g).to(cuda)
+    noise = (torch.rand(B, T, generator=g) * 2 - 1).to(cuda)
+    return f0, torch.split(ctrl, [NB, NB, NB], dim=-1), noise
+
+
+@pytest.mark.parametrize("impl", [3, 4])
+def test_fir_identity_and_delay(cuda, batch, impl):
+    """taps = unit impulse at N/2 (the delay the crop compensates, core.py:115) -> output == input; an impulse
+    d taps later delays by d with zero fill at the start"""
+    from ddsp_svc_amd import core
+    _, _, x = batch
+    taps = torch.zeros(B, F, N, device=cuda)
+    taps[:, :, N // 2] = 1.0
+    y = core.fft_convolve(x, taps, impl=impl)
+    assert rms(y - x) <= 2e-7 * rms(x)
+    d = 37
+    taps.zero_()
+    taps[:, :, N // 2 + d] = 1.0
+    y = core.fft_convolve(x, taps, impl=impl)
+    assert rms(y[:, d:] - x[:, :-d]) <= 2e-7 * rms(x)
+    assert float(y[:, :d].abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("impl", [3, 4])
+def test_fir_linearity_and_frame_locality(cuda, batch, impl):
+    from ddsp_svc_amd import core
+    _, _, x = batch
+    g = torch.Generator().manual_seed(3)
+    taps = (torch.randn(B, F, N, generator=g) / N ** 0.5).to(cuda)
+    x2 = torch.roll(x, 1, 0)
+    y1, y2 = core.fft_convolve(x, taps, impl=impl), core.fft_convolve(x2, taps, impl=impl)
+    y12 = core.fft_convolve(x + 0.5 * x2, taps, impl=impl)
+    assert rms(y12 - (y1 + 0.5 * y2)) <= 1e-6 * rms(y12)            # linear in the signal
+    t2 = taps.clone()
+    t2[:, 400] += 1.0                                               # one frame's taps ...
+    y3 = core.fft_convolve(x, t2, impl=impl)
+    diff = (y3 - y1).abs().amax(0)
+    lo, hi = 399 * HOP - N // 2, 401 * HOP + N // 2                 # ... reach only its triangle +- N/2 (core.py:158-182)
+    if impl == 3:      # direct form: bit-identical outside the reach
+        assert float(diff[:lo].max()) == 0.0 and float(diff[hi + 1:].max()) == 0.0
+    else:              # FFT form: the frame shares its transforms with its pair partner -> rounding-level leakage
+        assert float(diff[:lo].max()) <= 2e-5 and float(diff[hi + 1:].max()) <= 2e-5      # inside the pair, exact zero beyond
+        assert float(diff[:lo - 2 * HOP].max()) == 0.0 and float(diff[hi + 1 + 2 * HOP:].max()) == 0.0
+    assert float(diff[lo:hi].max()) > 0.1
+
+
+def test_fir_forms_agree(cuda, batch):
+    """FFT-domain kernel vs direct-form MFMA kernel on the full batch, plus the fused 2u-1 / addend options"""
+    from ddsp_svc_amd import _ffi, core
+    _, _, x = batch
+    g = torch.Generator().manual_seed(4)
+    taps = (torch.randn(B, F, N, generator=g) / N ** 0.5 * torch.rand(B, F, 1, generator=g) * 4).to(cuda)
+    y3, y4 = core.fft_convolve(x, taps, impl=3), core.fft_convolve(x, taps, impl=4)
+    assert rms(y3 - y4) <= 1.5e-6 * rms(y3)
+    u = (x + 1) / 2
+    add = torch.roll(x, 5, 1)
+    out, plain = torch.empty_like(x), torch.empty_like(x)
+    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(u.data_ptr(), 1, taps.data_ptr(), add.data_ptr(), out.data_ptr(),
+                                                plain.data_ptr(), B, F, HOP, N, 4, _ffi.stream_of(u)))
+    x_re = torch.addcmul(torch.full_like(u, -1.0), u, torch.full_like(u, 2.0))     # 2u-1 as fma, like the kernel
+    ref = core.fft_convolve(x_re, taps, impl=3)
+    assert rms(plain - ref) <= 1.5e-6 * rms(ref)
+    assert rms(out - (plain + add)) <= 1e-7 * rms(out)
+
+
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_tail_rows_match_oracle_and_batching(cuda, batch, kind):
+    """three utterances of the full batch against the oracle; the batched rows equal the single-utterance runs"""
+    from ddsp_svc_amd import synth
+    f0, (c0, c1, c2), noise = batch
+    fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+    ofn = O.combsub_dsp if kind == "combsub" else O.sins_dsp
+    st = synth.phase(f0, SR, HOP)
+    sig, harm, nz = fn(f0, st, c0, c1, c2, noise, SR, HOP)
+    assert torch.isfinite(sig).all()
+    for b in (0, 13, 31):
+        sl = slice(b, b + 1)
+        ref = ofn(f0[sl].cpu().numpy(), c0[sl].cpu().numpy(), c1[sl].cpu().numpy(), c2[sl].cpu().numpy(),
+                  noise[sl].cpu().numpy(), SR, HOP)
+        for got, key in ((sig, "signal"), (harm, "harmonic"), (nz, "noise")):
+            e = rms(got[sl].cpu() - torch.from_numpy(ref[key]))
+            assert e <= 1e-5 * rms(ref[key]) and e <= 1e-4, (kind, b, key, e, rms(ref[key]))
+        st1 = synth.phase(f0[sl], SR, HOP)
+        one = fn(f0[sl], st1, c0[sl], c1[sl], c2[sl], noise[sl], SR, HOP)[0]
+        assert rms(one - sig[sl]) <= 1e-6 * rms(one)
+
+
+def test_phase_checksum_and_restart(cuda, batch):
+    """phase_frames of the batch against the oracle for every utterance (cheap), and the additivity of the scan:
+    synthesising the second half with initial_phase = phase reached at the split equals the tail of the full run"""
+    from ddsp_svc_amd import synth
+    f0, _, _ = batch
+    st = synth.phase(f0, SR, HOP, want_x=True)
+    _, pf = O.wrapped_phase(f0.cpu().numpy(), SR, HOP)
+    d = st.phase_frames[..., 0].cpu().numpy() - pf
+    d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+    assert np.abs(d).max() <= 5e-7
+    h = F // 2
+    # x just before the split, in radians, as initial_phase of the second half (vocoder.py:569-570)
+    ip = (st.x[:, h * HOP - 1].double() * 2 * np.pi).float()
+    st2 = synth.phase(f0[:, h:].contiguous(), SR, HOP, initial_phase=ip, want_x=True)
+    dx = (st2.x - st.x[:, h * HOP:]).double()
+    dx = dx - dx.round()
+    assert float(dx.abs().max()) <= 2e-6          # float32 hand-over of the phase: ~1e-7 cycles per step of 2*pi rounding
