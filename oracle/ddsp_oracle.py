@@ -339,3 +339,127 @@ def synth_noise(B: int, T: int, seed: int = 99) -> np.ndarray:
     """``2*U[0,1) - 1`` as the reference draws it (vocoder.py:603,854), float32."""
     rng = np.random.default_rng(seed)
     return (rng.random((B, T), dtype=F32) * F32(2.0) - F32(1.0)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# 8-f #1  CombSubFast / CombSubSuperFast: short-time spectral filtering     vocoder.py:613-786
+# --------------------------------------------------------------------------------------
+def fast_source_gen(f0_frames: np.ndarray, sr: float, hop: int):
+    """``CombSubSuperFast.fast_source_gen`` (vocoder.py:639-651): closed-form per-frame phase.
+
+    Everything is float32, op for op, in the reference's order (the buffers ``sampling_rate`` and
+    ``block_size`` are integer 0-dim tensors, so every division is a float32 division by the exactly
+    representable 44100 / 512); the only wide step is ``cumsum`` over frames, for which ATen's CPU
+    kernel keeps a float64 running sum and rounds each output to float32 (the same behaviour
+    ``wrapped_phase(infer=False)`` reproduces).  Returns ``(combtooth [B,T] f64, phase_frames [B,F]
+    f32, rad_acc [B,F] f32)``; the float32 argument of the final ``sinc`` is exact, its sine and
+    divide are evaluated in float64 here.
+    """
+    f0f = np.asarray(f0_frames, dtype=F32)
+    if f0f.ndim == 2:
+        f0f = f0f[:, :, None]
+    B, Fr, _ = f0f.shape
+    n = np.arange(hop, dtype=F32)[None, None, :]
+    n1 = (n + F32(1.0)).astype(F32)
+    s0 = (f0f / F32(sr)).astype(F32)                                               # :641
+    ds0 = np.concatenate([s0[:, 1:] - s0[:, :-1], np.zeros((B, 1, 1), F32)], axis=1).astype(F32)   # :642
+    a = (s0 * n1).astype(F32)
+    h = (F32(0.5) * ds0).astype(F32)
+    b = (((h * n).astype(F32) * n1).astype(F32) / F32(hop)).astype(F32)
+    rad = (a + b).astype(F32)                                                      # :643
+    s0n = (s0 + ((ds0 * n).astype(F32) / F32(hop)).astype(F32)).astype(F32)        # :644
+    last = rad[..., -1:]
+    rad2 = (np.fmod((last + F32(0.5)).astype(F32), F32(1.0)).astype(F32) - F32(0.5)).astype(F32)   # :645
+    acc = np.cumsum(rad2.astype(F64), axis=1).astype(F32)                          # :646 cumsum (f64 running sum)
+    rad_acc = np.fmod(acc, F32(1.0)).astype(F32)
+    shifted = np.concatenate([np.zeros((B, 1, 1), F32), rad_acc[:, :-1]], axis=1)
+    rad = (rad + shifted).astype(F32)                                              # :647
+    rad = (rad - np.rint(rad)).astype(F32)                                         # :648
+    z = (rad / (s0n + F32(1e-5)).astype(F32)).astype(F32)                          # :649
+    p = (PI32 * z).astype(F32).astype(F64)
+    safe = np.where(p == 0.0, 1.0, p)
+    comb = np.where(p == 0.0, 1.0, np.sin(safe) / safe).reshape(B, Fr * hop)
+    phase_frames = (TWO_PI32 * rad[:, :, 0]).astype(F32)                           # :650
+    return comb, phase_frames, rad_acc[:, :, 0]
+
+
+def spectral_filters(c_mag, c_phase, scale: float = 1.0):
+    """vocoder.py:661-664 / :758-761: ``exp(mag + 1j*pi*phase) * scale`` with the last frame appended
+    once more -> complex ``[B,F+1,n]``.  ``c_phase=None`` is the zero-phase noise filter of CombSubFast."""
+    mag = np.exp(np.asarray(c_mag, dtype=F32).astype(F64)) * scale
+    if c_phase is None:
+        H = mag.astype(np.complex128)
+    else:
+        ang = (PI32 * np.asarray(c_phase, dtype=F32)).astype(F32).astype(F64)      # 1j*np.pi*float32 tensor
+        H = mag * (np.cos(ang) + 1j * np.sin(ang))
+    return np.concatenate([H, H[:, -1:]], axis=1)
+
+
+def _frames(sig, win: int, hop: int, pad_mode: str):
+    """centered framing shared by torch.stft(center=True) and CombSubFast's pad+unfold: ``[B,T] ->
+    [B, T//hop + 1, win]`` with win/2 samples of padding on both sides."""
+    sig = np.asarray(sig, dtype=F64)
+    half = win // 2
+    padded = np.pad(sig, ((0, 0), (half, half)), mode=pad_mode)
+    nfr = (padded.shape[1] - win) // hop + 1
+    idx = (np.arange(nfr) * hop)[:, None] + np.arange(win)[None, :]
+    return padded[:, idx]
+
+
+def combsubfast_dsp(f0_frames, c_hmag, c_hphase, c_nmag, noise, sr=44100, hop=512,
+                    initial_phase=None, infer=True):
+    """DSP tail of ``CombSubFast.forward`` (vocoder.py:743-786).  ``noise [B,T]`` is the already scaled
+    uniform(-1,1) draw (:771).  Frames of ``2*hop`` with zero padding (:766), ``sqrt(hann)`` analysis and
+    synthesis window (:726,:767,:780), circular per-frame filtering in the rfft domain (:777),
+    overlap-add and crop (:783-784)."""
+    x, pf = wrapped_phase(f0_frames, sr, hop, initial_phase, infer)
+    comb = combtooth(x, f0_frames, sr, hop)                                         # :764 (same formula as CombSub)
+    win = 2 * hop
+    w = np.sqrt((0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)).astype(F32).astype(F64))
+    w = w.astype(F32).astype(F64)                                                   # the buffer is float32
+    Hs = spectral_filters(c_hmag, c_hphase)                                         # :758-759
+    Hn = spectral_filters(c_nmag, None, 1.0 / 128.0)                                # :760-761
+    cf = np.fft.rfft(_frames(comb, win, hop, "constant") * w, win)                  # :766-768
+    nf = np.fft.rfft(_frames(noise, win, hop, "constant") * w, win)                 # :772-774
+    out = np.fft.irfft(cf * Hs + nf * Hn, win) * w                                  # :777-780
+    B, nfr, _ = out.shape
+    ola = np.zeros((B, (nfr + 1) * hop), dtype=F64)
+    for j in range(nfr):
+        ola[:, j * hop:j * hop + win] += out[:, j]
+    return dict(signal=ola[:, hop:-hop], x=x, phase_frames=pf, exciter=comb)
+
+
+def combsubsuperfast_dsp(f0_frames, c_hmag, c_hphase, c_nmag, c_nphase, noise, sr=44100, hop=512,
+                         win=2048, window=None):
+    """DSP tail of ``CombSubSuperFast.forward`` (vocoder.py:653-710).  ``noise [B,T]`` is the
+    ``randn_like`` draw (:687).  torch.stft (center=True, reflect padding unless the signal is not longer
+    than win/2, periodic Hann) of exciter and noise, complex filters per frame, torch.istft
+    (overlap-add of windowed inverse frames divided by the summed squared window, centre crop)."""
+    comb, pf, _ = fast_source_gen(f0_frames, sr, hop)
+    if window is None:
+        window = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)).astype(F32)   # torch.hann_window
+    w = np.asarray(window, dtype=F32).astype(F64)
+    T = comb.shape[1]
+    mode = "reflect" if T > win // 2 else "constant"                                # :667-670
+    Hs = spectral_filters(c_hmag, c_hphase)                                         # :661-662
+    Hn = spectral_filters(c_nmag, c_nphase, 1.0 / 128.0)                            # :663-664
+    cf = np.fft.rfft(_frames(comb, win, hop, mode) * w, win)                        # :671-679
+    nf = np.fft.rfft(_frames(noise, win, hop, mode) * w, win)                       # :683-691
+    spec = cf * Hs + nf * Hn                                                        # :694
+    out = np.fft.irfft(spec, win) * w                                               # :697-702
+    B, nfr, _ = out.shape
+    total = win + hop * (nfr - 1)
+    ola = np.zeros((B, total), dtype=F64)
+    env = np.zeros(total, dtype=F64)
+    for j in range(nfr):
+        ola[:, j * hop:j * hop + win] += out[:, j]
+        env[j * hop:j * hop + win] += w * w
+    half = win // 2
+    sl = slice(half, half + hop * (nfr - 1))
+    return dict(signal=ola[:, sl] / env[sl], phase_frames=pf, exciter=comb)
+
+
+def synth_gauss(B: int, T: int, seed: int = 77) -> np.ndarray:
+    """standard normal noise as ``randn_like`` draws it (vocoder.py:687), float32."""
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((B, T)).astype(F32)

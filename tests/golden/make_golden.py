@@ -10,6 +10,9 @@ Fixtures (all float32 unless noted):
   filter_*.npz      ddsp.core.frequency_filter, three window modes       core.py:273
   sins_*.npz        Sins.forward with captured controls + injected noise vocoder.py:556-611
   combsub_*.npz     CombSub.forward, same                                vocoder.py:811-862
+  fastsrc.npz       CombSubSuperFast.fast_source_gen                     vocoder.py:639-651
+  csfast_*.npz      CombSubFast.forward, captured controls, injected uniform noise      vocoder.py:735-786
+  cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
 """
 import os
 import sys
@@ -130,6 +133,58 @@ def main():
     np.savez(os.path.join(HERE, "combsub_256.npz"), **run_module("combsub", (256, 256, 256), 2, 24, 17))
     np.savez(os.path.join(HERE, "combsub_128.npz"), **run_module("combsub", (256, 128, 256), 1, 16, 18))
     np.savez(os.path.join(HERE, "combsub_small_train.npz"), **run_module("combsub", (65, 129, 33), 2, 10, 19, infer=False))
+
+    # ---- CombSubFast / CombSubSuperFast ----------------------------------
+    def run_fast(kind, B, Fr, seed, infer=True, gain=4.0):
+        torch.manual_seed(seed)
+        if kind == "fast":
+            model = V.CombSubFast(sr, hop, n_unit=64, n_spk=1).eval()
+        else:
+            model = V.CombSubSuperFast(sr, hop, 2048, n_unit=64, n_spk=1).eval()
+        with torch.no_grad():
+            model.unit2ctrl.dense_out.weight_g.mul_(gain)
+        g = torch.Generator().manual_seed(seed + 1)
+        units = torch.randn(B, Fr, 64, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=seed + 2))
+        f0f[0] = torch.clamp(f0f[0] * 2.2, 65, 800)
+        vol = torch.rand(B, Fr, 1, generator=g) * 0.1
+        if kind == "fast":
+            draw = torch.rand(B, Fr * hop, generator=g)
+            patch = mock.patch("torch.rand_like", side_effect=lambda t: draw.to(t))
+            noise = draw * 2 - 1
+        else:
+            draw = torch.randn(B, Fr * hop, generator=g)
+            patch = mock.patch("torch.randn_like", side_effect=lambda t: draw.to(t))
+            noise = draw
+        cap = {}
+        hk = model.unit2ctrl.register_forward_hook(lambda mod, i, o: cap.update(ctrls=o[0], phase=i[2]))
+        with torch.no_grad(), patch:
+            signal, hidden, _ = model(units, f0f, vol, infer=infer)
+        hk.remove()
+        ctrls = {k: v.detach().numpy() for k, v in cap["ctrls"].items()}
+        out = dict(f0_frames=f0f.numpy(), noise=noise.numpy(), signal=signal.numpy(),
+                   phase_frames=cap["phase"].detach().numpy()[..., 0], window=model.window.numpy(),
+                   **{"ctrl_" + k: v for k, v in ctrls.items()})
+        if kind == "super":
+            with torch.no_grad():
+                comb, pf = model.fast_source_gen(f0f)
+            out["combtooth"] = comb.numpy()
+        return out
+
+    f0f = torch.from_numpy(O.synth_f0(3, 60, sr, hop, seed=31))
+    f0f[1] = torch.clamp(f0f[1] * 2.5, 65, 800)
+    f0f[2, 20:30] = 65.0
+    torch.manual_seed(3)
+    m = V.CombSubSuperFast(sr, hop, 2048, n_unit=64, n_spk=1)
+    with torch.no_grad():
+        comb, pf = m.fast_source_gen(f0f)
+    np.savez(os.path.join(HERE, "fastsrc.npz"), f0_frames=f0f.numpy(), combtooth=comb.numpy(),
+             phase_frames=pf.numpy()[..., 0])
+    np.savez(os.path.join(HERE, "csfast_a.npz"), **run_fast("fast", 2, 20, 41))
+    np.savez(os.path.join(HERE, "csfast_train.npz"), **run_fast("fast", 1, 9, 42, infer=False))
+    np.savez(os.path.join(HERE, "cssuper_a.npz"), **run_fast("super", 2, 20, 43))
+    np.savez(os.path.join(HERE, "cssuper_short.npz"), **run_fast("super", 1, 2, 44))     # T <= win/2: zero padding
+    np.savez(os.path.join(HERE, "cssuper_f3.npz"), **run_fast("super", 1, 3, 45))        # shortest reflect case
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

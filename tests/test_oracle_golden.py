@@ -85,3 +85,34 @@ def test_combsub_tail(golden_dir, name, infer):
                       g["ctrl_noise_magnitude"], g["noise"], infer=infer)
     for k, gk in (("signal", "signal"), ("harmonic", "harmonic"), ("noise", "noise_out")):
         assert rms(r[k] - g[gk]) <= 5e-6 * rms(g[gk]), (k, rms(r[k] - g[gk]), rms(g[gk]))
+
+
+# ---- CombSubFast / CombSubSuperFast -------------------------------------------
+def test_fast_source_gen(golden_dir):
+    g = _load(golden_dir, "fastsrc.npz")
+    comb, pf, _ = O.fast_source_gen(g["f0_frames"], 44100, 512)
+    assert np.array_equal(pf, g["phase_frames"])                 # the float32 recipe is reproduced bit for bit
+    assert np.abs(comb - g["combtooth"]).max() <= 2e-7           # float64 sine/divide vs torch's float32 sinc
+
+
+@pytest.mark.parametrize("name,infer", [("csfast_a.npz", True), ("csfast_train.npz", False)])
+def test_combsubfast_tail(golden_dir, name, infer):
+    g = _load(golden_dir, name)
+    r = O.combsubfast_dsp(g["f0_frames"], g["ctrl_harmonic_magnitude"], g["ctrl_harmonic_phase"],
+                          g["ctrl_noise_magnitude"], g["noise"], infer=infer)
+    assert np.array_equal(r["phase_frames"], g["phase_frames"])
+    assert rms(r["signal"] - g["signal"]) <= 2e-6 * rms(g["signal"])
+
+
+@pytest.mark.parametrize("name", ["cssuper_a.npz", "cssuper_short.npz", "cssuper_f3.npz"])
+def test_combsubsuperfast_tail(golden_dir, name):
+    g = _load(golden_dir, name)
+    r = O.combsubsuperfast_dsp(g["f0_frames"], g["ctrl_harmonic_magnitude"], g["ctrl_harmonic_phase"],
+                               g["ctrl_noise_magnitude"], g["ctrl_noise_phase"], g["noise"], window=g["window"])
+    assert np.array_equal(r["phase_frames"], g["phase_frames"])
+    assert np.abs(r["exciter"] - g["combtooth"]).max() <= 2e-7
+    assert rms(r["signal"] - g["signal"]) <= 2e-6 * rms(g["signal"])
+    # the default window of the oracle is the module's buffer
+    r2 = O.combsubsuperfast_dsp(g["f0_frames"], g["ctrl_harmonic_magnitude"], g["ctrl_harmonic_phase"],
+                                g["ctrl_noise_magnitude"], g["ctrl_noise_phase"], g["noise"])
+    assert rms(r2["signal"] - r["signal"]) <= 1e-6 * rms(g["signal"])
