@@ -28,13 +28,28 @@ import torch
 SR, HOP = 44100, 512
 
 
+FAST_MODELS = ("combsubfast", "combsubsuperfast")
+
+
+def model_sizes(kind, bins):
+    """control channels per split (ddsp/vocoder.py:549-554, :804-808, :728-732, :631-636)"""
+    if kind == "combsubfast":
+        return (HOP + 1,) * 3
+    if kind == "combsubsuperfast":
+        return (1025,) * 4
+    return (bins,) * 3
+
+
 def make_inputs(kind, B, F, sizes, device, seed):
     from oracle import ddsp_oracle as O            # only the synthetic-input generators
     f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=seed)).to(device)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     ctrl = torch.randn(B, F, sum(sizes), generator=g).to(device)      # one tensor, split into strided views
     ctrls = torch.split(ctrl, list(sizes), dim=-1)
-    noise = (torch.rand(B, F * HOP, generator=g) * 2 - 1).to(device)
+    if kind == "combsubsuperfast":
+        noise = torch.randn(B, F * HOP, generator=g).to(device)       # randn_like (vocoder.py:687)
+    else:
+        noise = (torch.rand(B, F * HOP, generator=g) * 2 - 1).to(device)
     return f0, ctrls, noise
 
 
@@ -55,6 +70,10 @@ def _cpu_worker(args):
     nz = O.synth_noise(1, F * HOP, seed=seed + 2)
     if kind == "combsub":
         r = O.combsub_dsp(f0, cs[0], cs[1], cs[2], nz, SR, HOP)
+    elif kind == "combsubfast":
+        r = O.combsubfast_dsp(f0, cs[0], cs[1], cs[2], nz, SR, HOP)
+    elif kind == "combsubsuperfast":
+        r = O.combsubsuperfast_dsp(f0, cs[0], cs[1], cs[2], cs[3], O.synth_gauss(1, F * HOP, seed=seed + 2), SR, HOP)
     else:
         r = O.sins_dsp(f0, cs[0], cs[1], cs[2], nz, SR, HOP)
     return float(_np.abs(r["signal"]).max())
@@ -100,12 +119,74 @@ def cpu_baseline(kind, F, sizes, budget_s=12.0):
                       % (done, F, F * HOP / SR, cores, wall)}
 
 
+def report_fast(a, rank, world, B, F, T, sizes, elapsed, gather_ms, f0, ctrls, noise, window, win):
+    """JSON line for CombSubFast / CombSubSuperFast: the dominant kernel is the fused
+    short-time spectral filter k_stft_filter, timed alone with events on the launch stream."""
+    from ddsp_svc_amd import synth
+    exc = torch.randn(B, T, device=f0.device)
+    super_ = a.model == "combsubsuperfast"
+
+    def once():
+        return synth.stft_filter(exc, noise, ctrls[0], ctrls[1], ctrls[2], ctrls[3] if super_ else None, window, HOP,
+                                 pad_reflect=super_, normalize=super_)
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    if rank != 0:
+        return
+    sigma_c = sum(sizes)
+    # the kernel reads exciter + noise + controls and writes the signal; the step regenerates the exciter from f0
+    k_bytes = (12.0 + 4.0 * sigma_c / HOP) * B * T
+    alg_bytes = (8.0 + 4.0 * (sigma_c + 1) / HOP) * B * T
+    kname = "k_stft_filter<%d>" % (4 if win == 2048 else 2)
+    traffic = hbm_traffic("k_stft_filter") if (B, F) == (32, 862) and super_ else None
+    pairs = (F + 2) // 2
+    fft_flops = B * pairs * (3 * 5.0 * win * np.log2(win) + win * 30.0)
+    total = B * world * T * a.steps
+    value = total / elapsed
+    ms = elapsed / a.steps * 1e3
+    res = {
+        "metric": "audio samples/sec, %s 44.1kHz win%d hop512" % ("CombSubSuperFast" if super_ else "CombSubFast", win),
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s B=%d/GPU x %.0f s utterances (F=%d, T=%d), %d x %d control bins, sr 44100, hop 512, "
+                               "DSP path (exciter phase + exciter + short-time spectral filter) from resident f0 / raw "
+                               "controls ~N(0,1) / noise" % (a.model, B, a.seconds, F, T, len(sizes), sizes[0]),
+                   "batch_per_gpu": B, "frames": F, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
+        "roofline": {"kernel": kname, "bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / 8000.0,
+                     "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+                     "algorithmic_bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_per_step": 1},
+        "roofline_compute": {"kernel": kname, "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
+                             "achieved": fft_flops / (k_ms * 1e-3) / 1e12, "frac": fft_flops / (k_ms * 1e-3) / 1e12 / 157.3,
+                             "executed_flops_per_launch": fft_flops},
+        "roofline_step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes,
+                              "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},
+    }
+    if gather_ms is not None:
+        res["gather_ms"] = gather_ms
+    if world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.model, F, sizes)
+        res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="combsub", choices=["combsub", "sins"])
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -132,11 +213,20 @@ def main():
     F = int(a.seconds * SR) // HOP + 1              # the reference's frame-count rule (vocoder.py:222)
     T = F * HOP
     n = a.bins
-    sizes = (n, n, n)
+    sizes = model_sizes(a.model, n)
     f0, ctrls, noise = make_inputs(a.model, B, F, sizes, device, seed=1234 + rank)
+    win = 2048 if a.model == "combsubsuperfast" else 2 * HOP
+    window = torch.hann_window(win, device=device)
+    if a.model == "combsubfast":
+        window = torch.sqrt(window)
 
     def step():
+        if a.model == "combsubsuperfast":
+            fs = synth.fast_source(f0, SR, HOP)
+            return synth.combsubsuperfast_synth(f0, fs, ctrls[0], ctrls[1], ctrls[2], ctrls[3], noise, window, SR, HOP)
         st = synth.phase(f0, SR, HOP)
+        if a.model == "combsubfast":
+            return synth.combsubfast_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, window, SR, HOP)
         if a.model == "combsub":
             return synth.combsub_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
                                        want_components=False, fir_impl=a.fir_impl)[0]
@@ -170,6 +260,13 @@ def main():
         fence()
         gather_ms = (time.perf_counter() - t1) * 1e3
         del full
+
+    if a.model in FAST_MODELS:
+        report_fast(a, rank, world, B, F, T, sizes, elapsed, gather_ms, f0, ctrls, noise, window, win)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- dominant kernel alone: the time-varying FIR (N = 2(n-1) taps), events on the launch stream.  Two forms ship:
     # the FFT-domain block convolution (k_fir_fft, what the step uses for hop 512 / N <= 512) and the direct form on

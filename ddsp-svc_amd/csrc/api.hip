@@ -238,4 +238,82 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   return finish();
 }
 
+size_t ddsp_hip_stft_workspace_bytes(int B, int F, int hop) {
+  if (B <= 0 || F <= 0 || hop <= 0) return 0;
+  return align_up((size_t)B * F * hop * sizeof(float), 256);
+}
+
+int ddsp_hip_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc, float* phase_frames,
+                         float* combtooth, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !rad_acc) return DDSP_HIP_EINVAL;
+  if (launch_fast_source(f0_frames, B, F, hop, sr, rad_acc, phase_frames, combtooth, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_stft_filter(const float* exciter, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hmag,
+                         const float* c_hphase, long ld_hphase, const float* c_nmag, long ld_nmag,
+                         const float* c_nphase, long ld_nphase, float noise_scale, const float* window, int win,
+                         int pad_reflect, int normalize, int B, int F, int hop, float* signal, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || win < 2 || (win & 1)) return DDSP_HIP_EINVAL;
+  const int n = win / 2 + 1;
+  if (ld_hmag < n || ld_hphase < n || ld_nmag < n || (c_nphase && ld_nphase < n)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!exciter || !noise || !c_hmag || !c_hphase || !c_nmag || !window || !signal) return DDSP_HIP_EINVAL;
+  if (pad_reflect && (long)F * hop <= win / 2) return DDSP_HIP_EINVAL;       // reflect padding needs T > win/2
+  if (launch_stft_filter(exciter, noise, noise_is_u01, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, c_nphase,
+                         ld_nphase, noise_scale, window, win, pad_reflect, normalize, B, F, hop, signal, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_combsubfast_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
+                               const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
+                               const float* c_nmag, long ld_nmag, const float* noise, int noise_is_u01,
+                               const float* window, int B, int F, int hop, double sr, int infer, float* signal, void* ws,
+                               size_t ws_bytes, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  const int n = hop + 1;
+  if (ld_hmag < n || ld_hphase < n || ld_nmag < n) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !c_hmag || !c_hphase || !c_nmag || !noise || !window || !signal) return DDSP_HIP_EINVAL;
+  if (!ws || ws_bytes < ddsp_hip_stft_workspace_bytes(B, F, hop)) return DDSP_HIP_EWS;
+  float* comb = static_cast<float*>(ws);
+  hipStream_t st = S(stream);
+  // exciter: the same combtooth as CombSub (vocoder.py:764-765 == :839-840)
+  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, comb, st) != 0) return DDSP_HIP_EHOP;
+  // frames of 2*hop, zero padding, no envelope division (vocoder.py:766-784)
+  if (launch_stft_filter(comb, noise, noise_is_u01, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, nullptr, 0,
+                         1.0f / 128.0f, window, 2 * hop, 0, 0, B, F, hop, signal, st) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_combsubsuperfast_synth(const float* f0_frames, const float* rad_acc, const float* c_hmag, long ld_hmag,
+                                    const float* c_hphase, long ld_hphase, const float* c_nmag, long ld_nmag,
+                                    const float* c_nphase, long ld_nphase, const float* noise, const float* window,
+                                    int win, int B, int F, int hop, double sr, float* signal, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || win < 2 || (win & 1) || !(sr > 0)) return DDSP_HIP_EINVAL;
+  const int n = win / 2 + 1;
+  if (ld_hmag < n || ld_hphase < n || ld_nmag < n || ld_nphase < n) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !rad_acc || !c_hmag || !c_hphase || !c_nmag || !c_nphase || !noise || !window || !signal)
+    return DDSP_HIP_EINVAL;
+  if (!ws || ws_bytes < ddsp_hip_stft_workspace_bytes(B, F, hop)) return DDSP_HIP_EWS;
+  float* comb = static_cast<float*>(ws);
+  hipStream_t st = S(stream);
+  // exciter from the closed-form phase (vocoder.py:643-649); rad_acc was produced before Unit2Control ran
+  // (only the per-sample part: the frame-rate scan is the caller's ddsp_hip_fast_source call)
+  if (launch_fast_combtooth(f0_frames, rad_acc, B, F, hop, sr, comb, st) != 0) return DDSP_HIP_ESHAPE;
+  // torch.stft / istft: reflect padding unless the signal is not longer than win/2 (vocoder.py:667-670)
+  const int reflect = (long)F * hop > win / 2 ? 1 : 0;
+  if (launch_stft_filter(comb, noise, 0, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, c_nphase, ld_nphase,
+                         1.0f / 128.0f, window, win, reflect, 1, B, F, hop, signal, st) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 }  // extern "C"

@@ -1,0 +1,105 @@
+// Complex FFT of N = 512 R points (R = 2: 1024, R = 4: 2048) for one workgroup of P = 64 R threads, 8 points per
+// thread in registers, three LDS exchanges through two ping-pong buffers -- the generalisation of fft2048.h
+// (whose complex helpers and radix-4/8 butterflies it re-uses) that the short-time spectral filters of
+// CombSubFast (window 1024) and CombSubSuperFast (window 2048) are built on.
+//
+// Decimation in frequency with N = 8 * 8 * 8 * R:
+//      n = P n1 + 8R n2 + R n3 + n4,          k = k1 + 8 k2 + 64 k3 + 512 k4
+//   pass 1  thread p = tid holds z[P n1 + p]:                DFT8 over n1, times W_N^(p k1)      -> A[k1][p]
+//   pass 2  thread (k1 = tid / 8R, c = tid % 8R = R n3 + n4): DFT8 over n2, times W_P^(c k2)      -> B[n3][k2][k1^n3][n4]
+//   pass 3  thread tid = n4 + R k1 + 8R k2:                   DFT8 over n3, times W_8R^(n4 k3)    -> A[k3][k2][k1][n4]
+//   pass 4  thread r = k1 + 8 k2 + 64 (k3 % R), s = k3 / R:   8/R DFT_R over n4
+// so thread r ends with Z[r + P s + 512 k4] = Z[P m + r], m = s + (8/R) k4: the "slot m, lane r" layout the
+// input had; the inverse transform (conjugate, forward, conjugate) chains without reordering.
+#pragma once
+#include "fft2048.h"
+
+namespace ddsp {
+namespace fft {
+
+template <int R>
+struct Plan {
+  static_assert(R == 2 || R == 4, "N = 1024 or 2048");
+  static constexpr int N = 512 * R;
+  static constexpr int P = 64 * R;          // threads
+  static constexpr int SLOTS = 8;           // complex points per thread: k = P m + tid
+  static constexpr int C = 8 * R;           // extent of the (n3, n4) index
+
+  struct Tw {
+    f32x2 w1[8];       // W_N^(tid k)
+    f32x2 w2[8];       // W_P^(c k),   c = tid % 8R
+    f32x2 w3[8];       // W_8R^(n4 k), n4 = tid % R
+    __device__ __forceinline__ void init(int tid) {
+      const int c = tid & (C - 1), n4 = tid & (R - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float s, co;
+        sincospif(-(float)((tid * k) & (N - 1)) / (float)(N / 2), &s, &co);
+        w1[k] = f32x2{co, s};
+        sincospif(-(float)((c * k) & (P - 1)) / (float)(P / 2), &s, &co);
+        w2[k] = f32x2{co, s};
+        sincospif(-(float)((n4 * k) & (C - 1)) / (float)(C / 2), &s, &co);
+        w3[k] = f32x2{co, s};
+      }
+    }
+  };
+
+  // v[n1] = z[P n1 + tid]  ->  v[m] = Z[P m + tid].  A and B hold N complex words each.
+  // A must be free of readers on entry; on return A may still be read by slower waves (pass 4), B is free.
+  static __device__ __forceinline__ void forward(f32x2 (&v)[8], const Tw& tw, f32x2* A, f32x2* B, int tid) {
+    dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) A[k * P + tid] = v[k];                              // [k1][p]
+    __syncthreads();
+    {
+      const int k1 = tid / C, c = tid & (C - 1);
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + n2 * C + c];
+      dft8(v);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      const int n3 = c / R, n4 = c & (R - 1);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) B[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];   // [n3][k2][k1 ^ n3][n4]
+    }
+    __syncthreads();
+    {
+#pragma unroll
+      for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];          // tid = n4 + R k1 + 8R k2
+      dft8(v);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
+#pragma unroll
+      for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + tid] = v[k3];                       // [k3][k2][k1][n4]
+    }
+    __syncthreads();
+    {
+      const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
+      const f32x2* src = A + k2 * C + k1 * R;
+      f32x2 t[8];
+      if constexpr (R == 4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          f32x2 a0 = src[(k3lo + 4 * s) * P + 0], a1 = src[(k3lo + 4 * s) * P + 1];
+          f32x2 a2 = src[(k3lo + 4 * s) * P + 2], a3 = src[(k3lo + 4 * s) * P + 3];
+          dft4(a0, a1, a2, a3);                                                     // k4 = 0..3 -> slot m = s + 2 k4
+          t[s] = a0; t[s + 2] = a1; t[s + 4] = a2; t[s + 6] = a3;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f32x2 a0 = src[(k3lo + 2 * s) * P + 0], a1 = src[(k3lo + 2 * s) * P + 1];
+          t[s] = a0 + a1;                                                           // k4 = 0, 1 -> slot m = s + 4 k4
+          t[s + 4] = a0 - a1;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = t[m];
+    }
+  }
+};
+
+}  // namespace fft
+}  // namespace ddsp

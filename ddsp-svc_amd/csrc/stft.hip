@@ -1,0 +1,366 @@
+// Short-time spectral filtering: the DSP tails of CombSubFast (ddsp/vocoder.py:758-784) and CombSubSuperFast
+// (:661-708), plus the closed-form exciter of the latter (fast_source_gen, :639-651).
+//
+// Both models frame the exciter and a noise draw with 50 % / 75 % overlap (frames of `win` samples every hop = 512,
+// win/2 samples of zero or reflect padding), window them, multiply the one-sided spectra by per-frame complex
+// filters exp(mag + i pi phase) predicted by Unit2Control, inverse-transform, window again and overlap-add
+// (CombSubSuperFast then divides by the summed squared window, as torch.istft does).  The reference materialises
+// [B,F+1,win/2+1] complex spectra four times; here one workgroup walks a run of consecutive frame PAIRS of one
+// utterance and nothing but the controls, the two input signals and the output touches HBM:
+//   Z_j     = FFT(w e_j + i w u_j)                 exciter and noise frames packed in one complex transform
+//   E = (Z[k] + conj Z[-k]) / 2,  U = (Z[k] - conj Z[-k]) / 2i
+//   S_j[k]  = E Hs_j[k] + U Hn_j[k]                for k <= win/2, Hermitian-extended above (irfft semantics:
+//                                                  the imaginary parts of the DC and Nyquist bins are dropped)
+//   y_j + i y_j+1 = IFFT(S_j + i S_j+1)            two real frames per inverse transform
+// i.e. 1.5 complex FFTs per frame (fft_r.h).  Overlap-add happens in an LDS ring of `win` samples; because every
+// frame starts at a multiple of the thread count, each thread only ever touches ring slots congruent to its id,
+// so the ring needs no barriers.  A run starts `WARM` pairs early (discarded) so the ring holds the tails of the
+// frames before its first own pair: no atomics, bit-reproducible.
+#include "fft_r.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace ddsp {
+
+using fft::cmul;
+
+constexpr int ST_HOP = 512;
+
+// ------------------------------------------------------------------------------------------------
+// fast_source_gen, frame-rate part (vocoder.py:641-647,650): rad_acc[f] = fmod(cumsum_f' rad2[f'], 1) with
+// rad2 = fmod(rad_last + 0.5, 1) - 0.5, and phase_frames = 2 pi rad[:, :, 0].  All float32 in the reference's
+// operation order; the cumulative sum is ATen's (float64 running sum, float32 outputs) -- the terms are
+// multiples of 2^-24 below 1, so the float64 sums are exact in any order and a parallel scan is bit-identical.
+// One 256-thread workgroup per utterance.
+// ------------------------------------------------------------------------------------------------
+struct FastSrc {
+  float sr;
+  int F, hop;
+  // s0 and ds0 of frame f (vocoder.py:641-642)
+  __device__ __forceinline__ void frame(const float* __restrict__ f0_row, int f, float& s0, float& ds0) const {
+    s0 = f0_row[f] / sr;
+    ds0 = 0.f;
+    if (f < F - 1) ds0 = f0_row[f + 1] / sr - s0;
+  }
+  // rad before the accumulated offset, at in-frame position n (vocoder.py:643)
+  __device__ __forceinline__ float rad_local(float s0, float ds0, int n) const {
+    const float nf = (float)n, n1 = (float)(n + 1);
+    const float a = s0 * n1;
+    const float b = (((0.5f * ds0) * nf) * n1) / (float)hop;
+    return a + b;
+  }
+};
+
+__global__ void __launch_bounds__(256) k_fast_source_scan(const float* __restrict__ f0_frames, FastSrc cfg,
+                                                          float* __restrict__ rad_acc,
+                                                          float* __restrict__ phase_frames) {
+  __shared__ double wsum[4];
+  __shared__ double carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long b = blockIdx.x;
+  const float* f0_row = f0_frames + b * cfg.F;
+  if (tid == 0) carry_s = 0.0;
+  __syncthreads();
+  for (int base = 0; base < cfg.F; base += 256) {
+    const int f = base + tid;
+    float s0 = 0.f, ds0 = 0.f, rad2 = 0.f;
+    if (f < cfg.F) {
+      cfg.frame(f0_row, f, s0, ds0);
+      const float last = cfg.rad_local(s0, ds0, cfg.hop - 1);
+      rad2 = fmodf(last + 0.5f, 1.0f) - 0.5f;                                      // :645
+    }
+    const double v = (double)rad2;
+    const double excl = wave_excl_scan(v, lane);
+    if (lane == 63) wsum[wave] = excl + v;
+    __syncthreads();
+    double pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const double incl = pre + excl + v;                                           // running sum including frame f
+    const double before = pre + excl;                                             // ... up to frame f - 1
+    if (f < cfg.F) {
+      rad_acc[b * cfg.F + f] = fmodf((float)incl, 1.0f);                            // :646
+      const float shifted = f > 0 ? fmodf((float)before, 1.0f) : 0.0f;             // F.pad(rad_acc[:, :-1]), :647
+      float rad = cfg.rad_local(s0, ds0, 0) + shifted;
+      rad = rad - rintf(rad);                                                      // :648
+      if (phase_frames) phase_frames[b * cfg.F + f] = kTwoPiF * rad;               // :650
+    }
+    __syncthreads();
+    if (tid == 255) carry_s = incl;
+    __syncthreads();
+  }
+}
+
+// combtooth = sinc(rad / (s0 + 1e-5)) (vocoder.py:643-649); 4 consecutive samples per thread
+__global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict__ f0_frames,
+                                                        const float* __restrict__ rad_acc, FastSrc cfg, long total,
+                                                        float* __restrict__ out) {
+  const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= total) return;
+  const long T = (long)cfg.F * cfg.hop;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long i = i0 + r;
+    v[r] = 0.f;
+    if (i < total) {
+      const long b = i / T;
+      const int t = (int)(i - b * T);
+      const int f = t / cfg.hop, n = t - f * cfg.hop;
+      float s0, ds0;
+      cfg.frame(f0_frames + b * cfg.F, f, s0, ds0);
+      float rad = cfg.rad_local(s0, ds0, n);
+      const float s0n = s0 + (ds0 * (float)n) / (float)cfg.hop;                    // :644
+      rad = rad + (f > 0 ? rad_acc[b * cfg.F + f - 1] : 0.0f);                     // :647
+      rad = rad - rintf(rad);                                                      // :648
+      v[r] = sinc_f32(rad / (s0n + 1e-5f));                                        // :649
+    }
+  }
+  if (i0 + 3 < total && (reinterpret_cast<uintptr_t>(out + i0) & 15) == 0) {
+    *reinterpret_cast<float4*>(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int r = 0; r < 4 && i0 + r < total; ++r) out[i0 + r] = v[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the spectral filter itself
+// ------------------------------------------------------------------------------------------------
+struct StftGeom {
+  int F, T;               // control frames, samples per utterance (F * hop)
+  int pairs;              // frame pairs per utterance: ceil((F + 1) / 2)   (frames 0..F)
+  int run, runs_per_utt;  // own pairs per workgroup
+  int reflect;            // padding: reflect (torch.stft, vocoder.py:667-670) or zeros (:766)
+  int normalize;          // divide by the overlap-added squared window (torch.istft)
+  int noise_u01;          // noise holds a U[0,1) draw: apply 2u - 1 on load (vocoder.py:771)
+  float noise_scale;      // 1/128 (vocoder.py:663,760)
+  long ld_hm, ld_hp, ld_nm, ld_np;
+};
+
+template <int R>
+__global__ void __launch_bounds__(64 * R, R == 4 ? 4 : 8)
+k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, const float* __restrict__ c_hmag,
+              const float* __restrict__ c_hphase, const float* __restrict__ c_nmag,
+              const float* __restrict__ c_nphase, const float* __restrict__ window, float* __restrict__ out,
+              StftGeom g) {
+  using PL = fft::Plan<R>;
+  constexpr int N = PL::N, P = PL::P, S = 8;
+  constexpr int PAD = N / 2;
+  constexpr int EMIT = ST_HOP / P;                             // ring slots per thread that complete per frame
+  constexpr int OVL = N / ST_HOP;                              // frames overlapping one sample
+  constexpr int WARM = (OVL - 1 + 1) / 2;                      // warm-up pairs: OVL - 1 earlier frames reach in
+  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];       // ping-pong exchange buffers; roles swap per transform
+  __shared__ float ring[N];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.runs_per_utt;
+  const int run_no = blockIdx.x - b * g.runs_per_utt;
+  const int p_first = run_no * g.run;
+  int p_last = p_first + g.run;
+  if (p_last > g.pairs) p_last = g.pairs;
+  const long ob = (long)b * g.T;
+  const float* eb = exc + ob;
+  const float* nb = noise + ob;
+
+  typename PL::Tw tw;
+  tw.init(tid);
+  float w[S];
+#pragma unroll
+  for (int m = 0; m < S; ++m) {
+    w[m] = window[P * m + tid];
+    ring[P * m + tid] = 0.f;
+  }
+  const float cs = 0.5f / (float)N;                            // E = (..)/2, U = (..)/2i and the 1/N of the inverse
+  const float cn = cs * g.noise_scale;
+  int cur = 0;                                                 // ex[cur] plays "A" of the next transform
+
+  const int pr0 = p_first > WARM ? p_first - WARM : 0;
+  for (int pr = pr0; pr < p_last; ++pr) {
+    f32x2 V[S];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * pr + h;                                // frame index, 0..F (F + 1 only pads an odd count)
+      const bool live = j <= g.F;
+      const int row = j < g.F ? j : g.F - 1;                   // last filter frame repeated (vocoder.py:662,664)
+      const long rb = (long)b * g.F + row;
+      // raw controls of the bins this thread evaluates: k = P m + tid for m < 4, plus the Nyquist bin on thread 0
+      // (the upper half of the spectrum is the conjugate mirror, handed over through LDS below)
+      constexpr int NB = S / 2 + 1;
+      float hm[NB], hp[NB], nm[NB], np_[NB];
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        hm[m] = hp[m] = nm[m] = np_[m] = 0.f;
+        if (live && (m < NB - 1 || tid == 0)) {
+          const int k = P * m + tid;
+          hm[m] = c_hmag[rb * g.ld_hm + k];
+          hp[m] = c_hphase[rb * g.ld_hp + k];
+          nm[m] = c_nmag[rb * g.ld_nm + k];
+          if (c_nphase) np_[m] = c_nphase[rb * g.ld_np + k];
+        }
+      }
+      // windowed input frame: exciter in the real, noise in the imaginary part
+      f32x2 z[S];
+      const int s0 = j * ST_HOP - PAD;
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        int i = s0 + P * m + tid;
+        if (g.reflect) {
+          if (i < 0) i = -i;
+          if (i >= g.T) i = 2 * (g.T - 1) - i;
+        }
+        float e = 0.f, u = 0.f;
+        if (live && i >= 0 && i < g.T) {
+          e = eb[i];
+          u = nb[i];
+          if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+        }
+        z[m] = f32x2{w[m] * e, w[m] * u};
+      }
+      f32x2* A = ex[cur];
+      f32x2* Bx = ex[cur ^ 1];
+      cur ^= 1;
+      PL::forward(z, tw, A, Bx, tid);
+#pragma unroll
+      for (int m = 0; m < S; ++m) Bx[P * m + tid] = z[m];       // natural order, buffer B is free
+      __syncthreads();                                          // ... and now A is free too (everyone left pass 4)
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        const int k = P * m + tid;
+        const f32x2 zneg = Bx[(N - k) & (N - 1)];
+        const f32x2 e2 = fft::add_conj(z[m], zneg);             // 2 E[k]
+        const f32x2 u2 = fft::sub_conj(z[m], zneg);             // 2i U[k]
+        // filters exp(mag) (cos(pi ph) + i sin(pi ph)); the noise one carries U's factor -i
+        float th = 0.5f * hp[m];
+        th = th - rintf(th);
+        const float ah = cs * expf(hm[m]);
+        const f32x2 Hs = {ah * __builtin_amdgcn_cosf(th), ah * __builtin_amdgcn_sinf(th)};
+        float tn = 0.5f * np_[m];
+        tn = tn - rintf(tn);
+        const float an = cn * expf(nm[m]);
+        const f32x2 Hn = {an * __builtin_amdgcn_sinf(tn), -an * __builtin_amdgcn_cosf(tn)};
+        f32x2 s = cmul(e2, Hs) + cmul(u2, Hn);
+        if (!live) s = f32x2{0.f, 0.f};
+        if (m < NB - 1) {
+          if (m == 0 && tid == 0) s.y = 0.f;                    // irfft ignores Im(DC)
+          A[(N - k) & (N - 1)] = fft::cconj(s);                 // S[N - k] = conj S[k] for its owner (slot 7 - m)
+          if (h == 0) V[m] = s;
+          else V[m] = fft::conj_minus_i_conj(V[m], s);          // V = S_j + i S_j+1, conjugated for the inverse
+        } else if (tid == 0) {
+          s.y = 0.f;                                            // ... and Im(Nyquist)
+          if (h == 0) V[m] = s;
+          else V[m] = fft::conj_minus_i_conj(V[m], s);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = NB - 1; m < S; ++m) {
+        if (m == NB - 1 && tid == 0) continue;                  // the Nyquist bin was evaluated above
+        const f32x2 s = A[P * m + tid];
+        if (h == 0) V[m] = s;
+        else V[m] = fft::conj_minus_i_conj(V[m], s);
+      }
+      // no barrier: the next transform writes Bx in its first pass (its readers are behind the barrier above) and
+      // A only after its own first barrier
+    }
+    {
+      f32x2* A = ex[cur];
+      f32x2* Bx = ex[cur ^ 1];
+      cur ^= 1;
+      PL::forward(V, tw, A, Bx, tid);
+    }
+    // ifft(V) = conj(FFT(conj V)): y_j = Re, y_j+1 = -Im (1/N folded into the filters)
+    const int a0 = 2 * pr * ST_HOP - PAD;                      // output position of frame 2 pr's first sample
+    const bool own = pr >= p_first;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * pr + h;
+      const int aj = a0 + h * ST_HOP;
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        const float y = h == 0 ? V[m].x : -V[m].y;
+        ring[(aj + P * m + tid) & (N - 1)] += y * w[m];
+      }
+      // samples [aj, aj + hop) have now seen every frame that reaches them; the last pair flushes the rest
+      const int n_emit = (pr == g.pairs - 1 && h == 1) ? S : EMIT;
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        if (m < n_emit) {
+          const int t = aj + P * m + tid;
+          const int ri = t & (N - 1);
+          float v = ring[ri];
+          ring[ri] = 0.f;
+          if (own && t >= 0 && t < g.T) {
+            if (g.normalize) {
+              // summed squared window over the frames jf = j + (m / EMIT) - q that exist (0..F) and cover t
+              float env = 0.f;
+#pragma unroll
+              for (int q = 0; q < OVL; ++q) {
+                const int jf = j + m / EMIT - q;
+                const float wq = w[(m % EMIT) + q * EMIT];
+                if (jf >= 0 && jf <= g.F) env = fmaf(wq, wq, env);
+              }
+              v = v / env;
+            }
+            out[ob + t] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+int launch_fast_combtooth(const float* f0_frames, const float* rad_acc, int B, int F, int hop, double sr, float* out,
+                          hipStream_t st) {
+  if ((long)F * hop >= (1L << 30)) return -1;
+  FastSrc cfg;
+  cfg.sr = (float)sr; cfg.F = F; cfg.hop = hop;
+  const long total = (long)B * F * hop;
+  const long blocks = (total + 1023) / 1024;
+  if (blocks > 0x7fffffffL) return -1;
+  hipLaunchKernelGGL(k_fast_combtooth, dim3((unsigned)blocks), dim3(256), 0, st, f0_frames, rad_acc, cfg, total, out);
+  return 0;
+}
+
+int launch_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc, float* phase_frames,
+                       float* combtooth, hipStream_t st) {
+  if ((long)F * hop >= (1L << 30)) return -1;
+  FastSrc cfg;
+  cfg.sr = (float)sr; cfg.F = F; cfg.hop = hop;
+  hipLaunchKernelGGL(k_fast_source_scan, dim3((unsigned)B), dim3(256), 0, st, f0_frames, cfg, rad_acc, phase_frames);
+  if (combtooth) return launch_fast_combtooth(f0_frames, rad_acc, B, F, hop, sr, combtooth, st);
+  return 0;
+}
+
+int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
+                       const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
+                       long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize, int B,
+                       int F, int hop, float* out, hipStream_t st) {
+  if (hop != ST_HOP || (win != 1024 && win != 2048) || (long)F * hop >= (1L << 30)) return -1;
+  StftGeom g;
+  g.F = F; g.T = F * hop;
+  g.pairs = (F + 2) / 2;
+  g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
+  g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
+  // run length: as many workgroups as the chip holds at once so all run in one round; every run pays its warm-up
+  const int wg_per_cu = win == 2048 ? 4 : 8;
+  const int warm = win == 2048 ? 2 : 1;
+  const long slots = (long)wg_per_cu * 256;
+  long per_utt = slots / (B > 0 ? B : 1);
+  if (per_utt < 1) per_utt = 1;
+  int run = (int)((g.pairs + per_utt - 1) / per_utt);
+  if (run < 4 * warm) run = 4 * warm;
+  if (const char* e = getenv("DDSP_HIP_STFT_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (run > g.pairs) run = g.pairs;
+  g.run = run;
+  g.runs_per_utt = (g.pairs + run - 1) / run;
+  const long wgs = (long)B * g.runs_per_utt;
+  if (wgs > 0x7fffffffL) return -1;
+  if (win == 2048)
+    hipLaunchKernelGGL(k_stft_filter<4>, dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase, c_nmag,
+                       c_nphase, window, out, g);
+  else
+    hipLaunchKernelGGL(k_stft_filter<2>, dim3((unsigned)wgs), dim3(128), 0, st, exc, noise, c_hmag, c_hphase, c_nmag,
+                       c_nphase, window, out, g);
+  return 0;
+}
+
+}  // namespace ddsp

@@ -155,3 +155,111 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
         ptr(ir_table(n_ap, dev)), ptr(ir_table(n_h, dev)), ptr(ir_table(n_nz, dev)),
         ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0)))
     return signal, harm, nzo
+
+
+# ---- CombSubFast / CombSubSuperFast (vocoder.py:613-786) ------------------------------------------
+@dataclass
+class FastSourceState:
+    """Output of ``fast_source``: ``phase_frames [B,F,1]`` for Unit2Control and ``rad_acc [B,F]``, the
+    float32 frame-rate phase accumulator the exciter restarts from (vocoder.py:646)."""
+    rad_acc: torch.Tensor
+    phase_frames: torch.Tensor
+    combtooth: Optional[torch.Tensor] = None
+
+
+def fast_source(f0_frames, sampling_rate, block_size, want_combtooth=False) -> FastSourceState:
+    """``CombSubSuperFast.fast_source_gen`` (vocoder.py:639-651)."""
+    _ffi.check_device(f0_frames)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    dev = f0.device
+    rad_acc = torch.empty(B, F, dtype=torch.float32, device=dev)
+    pf = torch.empty(B, F, 1, dtype=torch.float32, device=dev)
+    comb = torch.empty(B, F * hop, dtype=torch.float32, device=dev) if want_combtooth else None
+    _ffi.check(_ffi.lib().ddsp_hip_fast_source(ptr(f0), B, F, hop, float(sampling_rate), ptr(rad_acc), ptr(pf),
+                                               ptr(comb), _ffi.stream_of(f0)))
+    return FastSourceState(rad_acc, pf, comb)
+
+
+def _stft_ws(B, F, hop, device):
+    need = _ffi.lib().ddsp_hip_stft_workspace_bytes(B, F, hop)
+    key = "stft:" + str(device)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws, need
+
+
+def stft_filter(exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase, window,
+                block_size, noise_scale=1.0 / 128.0, pad_reflect=True, normalize=True, noise_is_u01=False):
+    """The shared spectral-filtering tail (vocoder.py:661-708 / :758-784) on explicit exciter and noise
+    signals ``[B,T]``; ``noise_phase`` may be None (zero-phase noise filter)."""
+    _ffi.check_device(exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnitude, window)
+    B, T = exciter.shape
+    hop = int(block_size)
+    F = T // hop
+    win = window.numel()
+    n = win // 2 + 1
+    hm, ldhm = _rows(harmonic_magnitude, n)
+    hp, ldhp = _rows(harmonic_phase, n)
+    nm, ldnm = _rows(noise_magnitude, n)
+    npz, ldnp = (None, 0) if noise_phase is None else _rows(noise_phase, n)
+    out = torch.empty(B, T, dtype=torch.float32, device=exciter.device)
+    _ffi.check(_ffi.lib().ddsp_hip_stft_filter(
+        ptr(_f32c(exciter)), ptr(_f32c(noise)), int(noise_is_u01), ptr(hm), ldhm, ptr(hp), ldhp, ptr(nm), ldnm,
+        ptr(npz), ldnp, float(noise_scale), ptr(_f32c(window)), win, int(pad_reflect), int(normalize), B, F, hop,
+        ptr(out), _ffi.stream_of(exciter)))
+    return out
+
+
+def combsubfast_synth(f0_frames, state: PhaseState, harmonic_magnitude, harmonic_phase, noise_magnitude, noise,
+                      window, sampling_rate, block_size, noise_is_u01=False):
+    """DSP tail of ``CombSubFast.forward`` (vocoder.py:758-784) from raw controls -> ``signal [B,T]``."""
+    _ffi.check_device(f0_frames, harmonic_magnitude, harmonic_phase, noise_magnitude, noise, window, state.phase0)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    T = F * hop
+    n = hop + 1
+    if window.numel() != 2 * hop:
+        raise ValueError("CombSubFast window must hold 2 * block_size samples")
+    hm, ldhm = _rows(harmonic_magnitude, n)
+    hp, ldhp = _rows(harmonic_phase, n)
+    nm, ldnm = _rows(noise_magnitude, n)
+    nz = _f32c(noise.reshape(B, T))
+    dev = f0.device
+    ws, need = _stft_ws(B, F, hop, dev)
+    signal = torch.empty(B, T, dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().ddsp_hip_combsubfast_synth(
+        ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(hm), ldhm, ptr(hp), ldhp, ptr(nm), ldnm,
+        ptr(nz), int(noise_is_u01), ptr(_f32c(window)), B, F, hop, float(sampling_rate), int(state.infer),
+        ptr(signal), ptr(ws), need, _ffi.stream_of(f0)))
+    return signal
+
+
+def combsubsuperfast_synth(f0_frames, state: FastSourceState, harmonic_magnitude, harmonic_phase, noise_magnitude,
+                           noise_phase, noise, window, sampling_rate, block_size):
+    """DSP tail of ``CombSubSuperFast.forward`` (vocoder.py:661-708) from raw controls; ``noise [B,T]`` is the
+    standard-normal draw (:687) -> ``signal [B,T]``."""
+    _ffi.check_device(f0_frames, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase, noise, window,
+                      state.rad_acc)
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    hop = int(block_size)
+    T = F * hop
+    win = window.numel()
+    n = win // 2 + 1
+    hm, ldhm = _rows(harmonic_magnitude, n)
+    hp, ldhp = _rows(harmonic_phase, n)
+    nm, ldnm = _rows(noise_magnitude, n)
+    npz, ldnp = _rows(noise_phase, n)
+    nz = _f32c(noise.reshape(B, T))
+    dev = f0.device
+    ws, need = _stft_ws(B, F, hop, dev)
+    signal = torch.empty(B, T, dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().ddsp_hip_combsubsuperfast_synth(
+        ptr(f0), ptr(state.rad_acc), ptr(hm), ldhm, ptr(hp), ldhp, ptr(nm), ldnm, ptr(npz), ldnp, ptr(nz),
+        ptr(_f32c(window)), win, B, F, hop, float(sampling_rate), ptr(signal), ptr(ws), need, _ffi.stream_of(f0)))
+    return signal

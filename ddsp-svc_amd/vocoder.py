@@ -1,4 +1,5 @@
-"""Drop-in ``Sins`` / ``CombSub`` modules (reference: ddsp/vocoder.py:532-611 and :788-862).
+"""Drop-in ``Sins`` / ``CombSub`` / ``CombSubFast`` / ``CombSubSuperFast`` modules (reference:
+ddsp/vocoder.py:532-611, :788-862, :712-786, :613-710).
 
 Same constructor arguments, buffers (``sampling_rate``, ``block_size``), child module name
 (``unit2ctrl``) and ``forward`` signature/return value as the reference, so checkpoints load
@@ -22,7 +23,8 @@ def _reference_unit2control():
 
 
 class _SynthBase(torch.nn.Module):
-    def __init__(self, sampling_rate, block_size, split_map, n_unit, n_spk, unit2ctrl_factory=None):
+    def __init__(self, sampling_rate, block_size, split_map, n_unit, n_spk, unit2ctrl_factory=None,
+                 **unit2ctrl_kwargs):
         super().__init__()
         # 0-dim buffers exactly as the reference registers them (state_dict compatibility); cached
         # Python numbers avoid the .item() device syncs the reference pays on every forward
@@ -31,7 +33,7 @@ class _SynthBase(torch.nn.Module):
         self._sr = float(sampling_rate)
         self._hop = int(block_size)
         factory = unit2ctrl_factory or _reference_unit2control()
-        self.unit2ctrl = factory(n_unit, n_spk, split_map)
+        self.unit2ctrl = factory(n_unit, n_spk, split_map, **unit2ctrl_kwargs)
         self.return_components = True       # the (harmonic, noise) tuple is API; set False to skip materialising it
         self.fir_impl = 0
 
@@ -93,16 +95,91 @@ class CombSub(_SynthBase):
         return signal, hidden, (harmonic, noise)
 
 
+class CombSubFast(_SynthBase):
+    """Combtooth subtractive synthesiser, ddsp/vocoder.py:712-786: sqrt-Hann frames of ``2*block_size``,
+    per-frame complex source filter and zero-phase noise filter in the rfft domain, overlap-add."""
+
+    def __init__(self, sampling_rate, block_size, n_unit=256, n_spk=1, use_pitch_aug=False, pcmer_norm=False,
+                 unit2ctrl_factory=None):
+        split_map = {"harmonic_magnitude": block_size + 1, "harmonic_phase": block_size + 1,
+                     "noise_magnitude": block_size + 1}                                          # :728-732
+        super().__init__(sampling_rate, block_size, split_map, n_unit, n_spk, unit2ctrl_factory,
+                         use_pitch_aug=use_pitch_aug, pcmer_norm=pcmer_norm)                     # :733
+        self.register_buffer("window", torch.sqrt(torch.hann_window(2 * block_size)))           # :726
+
+    def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, aug_shift=None,
+                initial_phase=None, infer=True, **kwargs):
+        st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :743-753
+        ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
+                                       spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :756
+        self._check_inference_only(*ctrls.values())
+        B, F = f0_frames.shape[0], f0_frames.shape[1]
+        u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :771
+        signal = synth.combsubfast_synth(f0_frames, st, ctrls["harmonic_magnitude"], ctrls["harmonic_phase"],
+                                         ctrls["noise_magnitude"], u01, self.window, self._sr, self._hop,
+                                         noise_is_u01=True)
+        return signal, hidden, (signal, signal)                                                 # :786
+
+
+class CombSubSuperFast(_SynthBase):
+    """Combtooth subtractive synthesiser, ddsp/vocoder.py:613-710 (the model ``configs/combsub.yaml`` ships and
+    the DDSP stage of the diffusion / reflow cascades): closed-form exciter phase, ``torch.stft`` /
+    ``torch.istft`` framing with a Hann window of ``win_length``, complex source and noise filters."""
+
+    def __init__(self, sampling_rate, block_size, win_length, n_unit=256, n_spk=1, use_pitch_aug=False,
+                 pcmer_norm=False, unit2ctrl_factory=None):
+        n = win_length // 2 + 1
+        split_map = {"harmonic_magnitude": n, "harmonic_phase": n, "noise_magnitude": n, "noise_phase": n}   # :631-636
+        super().__init__(sampling_rate, block_size, split_map, n_unit, n_spk, unit2ctrl_factory,
+                         use_pitch_aug=use_pitch_aug, use_naive_v2=True, use_conv_stack=True)    # :637
+        self.register_buffer("win_length", torch.tensor(win_length))                            # :628
+        self.register_buffer("window", torch.hann_window(win_length))                           # :629
+
+    def fast_source_gen(self, f0_frames):
+        """vocoder.py:639-651 -> ``(combtooth [B,T], phase_frames [B,F,1])``."""
+        st = synth.fast_source(f0_frames, self._sr, self._hop, want_combtooth=True)
+        return st.combtooth, st.phase_frames
+
+    def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, aug_shift=None,
+                initial_phase=None, infer=True, **kwargs):
+        st = synth.fast_source(f0_frames, self._sr, self._hop)                                  # :653
+        ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
+                                       spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :656
+        self._check_inference_only(*ctrls.values())
+        B, F = f0_frames.shape[0], f0_frames.shape[1]
+        gauss = torch.randn(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)     # randn_like, :687
+        signal = synth.combsubsuperfast_synth(f0_frames, st, ctrls["harmonic_magnitude"], ctrls["harmonic_phase"],
+                                              ctrls["noise_magnitude"], ctrls["noise_phase"], gauss, self.window,
+                                              self._sr, self._hop)
+        return signal, hidden, (signal, signal)                                                 # :710
+
+
 def patch_reference():
     """Swap these classes (and the ddsp.core functions on the path) into an already-importable
     reference checkout so ``ddsp.vocoder.load_model``, ``main.py``, ``main_diff.py`` ... pick them up
-    without edits.  Call before the reference scripts bind the names."""
+    without edits.  The cascades bind ``CombSubFast`` / ``CombSubSuperFast`` by name when they are imported
+    (diffusion/vocoder.py:13, reflow/vocoder.py:12), so either call this first or rely on the rebinding of
+    the already-imported modules done here."""
+    import sys
+
     import ddsp.core as rcore
     import ddsp.vocoder as rvoc
     from . import core as hcore
-    rvoc.Sins, rvoc.CombSub = Sins, CombSub
+    mine = {"Sins": Sins, "CombSub": CombSub, "CombSubFast": CombSubFast, "CombSubSuperFast": CombSubSuperFast}
+    for name, cls in mine.items():
+        if not hasattr(rvoc, "_reference_" + name):
+            setattr(rvoc, "_reference_" + name, getattr(rvoc, name))
+        setattr(rvoc, name, cls)
+    for modname in ("diffusion.vocoder", "reflow.vocoder", "train"):
+        mod = sys.modules.get(modname)
+        if mod is not None:
+            for name, cls in mine.items():
+                if hasattr(mod, name):
+                    setattr(mod, name, cls)
     for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve",
                  "frequency_impulse_response"):
+        if hasattr(rcore, "_reference_" + name):
+            continue                                     # already patched
         setattr(rcore, "_reference_" + name, getattr(rcore, name))
 
         def dispatch(*a, __h=getattr(hcore, name), __r=getattr(rcore, name), **k):

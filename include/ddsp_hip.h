@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 100          /* 0.1.0 */
+#define DDSP_HIP_VERSION 110          /* 0.1.1: + CombSubFast / CombSubSuperFast */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -118,6 +118,51 @@ int ddsp_hip_combtooth(const float* f0_frames, const float* initial_phase, const
 int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, const double* phase0,
                            const float* c_amp, long ld_amp, int B, int F, int hop, int H, double sr, int infer,
                            float* out, void* stream);
+
+/* ---- CombSubFast / CombSubSuperFast (ddsp/vocoder.py:613-786): short-time spectral filtering ---- */
+
+/* ddsp/vocoder.py:639-651  CombSubSuperFast.fast_source_gen(f0_frames[B,F]): closed-form per-frame
+ * phase with a float32 frame-rate accumulator.
+ *   rad_acc[B,F]: fmod(cumsum(rad2), 1) (:646), the state the exciter restarts from;
+ *   phase_frames[B,F] or NULL = 2*pi*rad[:, :, 0] (:650, what Unit2Control receives);
+ *   combtooth[B,T] or NULL = sinc(rad / (s0 + 1e-5)) (:649). */
+int ddsp_hip_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc,
+                         float* phase_frames, float* combtooth, void* stream);
+
+/* The shared tail of both models: frames of `win` samples every `hop` (win/2 padding each side:
+ * reflect as torch.stft does (:667-684) or zeros (:766)), times window[win], rfft, times the
+ * per-frame filters exp(c_hmag + i*pi*c_hphase) (exciter) and noise_scale*exp(c_nmag +
+ * i*pi*c_nphase) (noise; c_nphase NULL = zero phase, :760), last filter frame repeated (:662,:759),
+ * irfft, times window, overlap-add, crop win/2 (:783-784); normalize != 0 divides by the
+ * overlap-added squared window as torch.istft does (:702-708).
+ *   exciter, noise, signal [B,T]; controls [B,F,win/2+1] with row strides ld_*; window[win].
+ * Supported: hop 512 with win 1024 (CombSubFast) or 2048 (CombSubSuperFast). */
+int ddsp_hip_stft_filter(const float* exciter, const float* noise, int noise_is_u01,
+                         const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
+                         const float* c_nmag, long ld_nmag, const float* c_nphase, long ld_nphase,
+                         float noise_scale, const float* window, int win, int pad_reflect, int normalize,
+                         int B, int F, int hop, float* signal, void* stream);
+
+/* DSP tail of CombSubFast.forward (ddsp/vocoder.py:758-784) from raw controls and the phase state of
+ * ddsp_hip_phase: combtooth (:764) -> sqrt-Hann frames of 2*hop -> filters -> overlap-add.
+ * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1, :771); window[2*hop] is the
+ * module's buffer (:726); ws: B*T floats (ddsp_hip_stft_workspace_bytes). */
+int ddsp_hip_combsubfast_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
+                               const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
+                               const float* c_nmag, long ld_nmag, const float* noise, int noise_is_u01,
+                               const float* window, int B, int F, int hop, double sr, int infer,
+                               float* signal, void* ws, size_t ws_bytes, void* stream);
+
+/* DSP tail of CombSubSuperFast.forward (ddsp/vocoder.py:661-708) from raw controls and rad_acc of
+ * ddsp_hip_fast_source.  noise[B,T] is the standard-normal draw (:687); window[win] the module's
+ * Hann buffer (:629). */
+int ddsp_hip_combsubsuperfast_synth(const float* f0_frames, const float* rad_acc,
+                                    const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
+                                    const float* c_nmag, long ld_nmag, const float* c_nphase, long ld_nphase,
+                                    const float* noise, const float* window, int win, int B, int F, int hop,
+                                    double sr, float* signal, void* ws, size_t ws_bytes, void* stream);
+
+size_t ddsp_hip_stft_workspace_bytes(int B, int F, int hop);
 
 #ifdef __cplusplus
 }

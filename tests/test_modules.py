@@ -31,8 +31,9 @@ class TinyUnit2Control(torch.nn.Module):
     """Stand-in with Unit2Control's interface (ddsp/unit2control.py:26-109): forward(units, f0, phase,
     volume, spk_id, spk_mix_dict) -> (dict of [B,F,n] views of one tensor, hidden [B,F,256])."""
 
-    def __init__(self, n_unit, n_spk, output_splits):
+    def __init__(self, n_unit, n_spk, output_splits, **kwargs):
         super().__init__()
+        self.kwargs = kwargs
         self.output_splits = output_splits
         self.proj = torch.nn.Linear(n_unit + 3, 256)
         self.dense_out = torch.nn.Linear(256, sum(output_splits.values()))
@@ -102,6 +103,61 @@ def test_dropin_module_structure_and_dsp(dev, kind, monkeypatch):
         m(units, f0, vol)
 
 
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("kind", ["fast", "superfast"])
+def test_dropin_fast_modules(dev, kind, monkeypatch):
+    """CombSubFast / CombSubSuperFast: constructor, buffers, Unit2Control arguments, forward contract and the DSP
+    result against the oracle on the controls the stand-in produced (vocoder.py:613-786)."""
+    from ddsp_svc_amd import vocoder as V
+    torch.manual_seed(0)
+    B, F, n_unit = 2, 7, 12
+    if kind == "fast":
+        m = V.CombSubFast(SR, HOP, n_unit=n_unit, n_spk=1, pcmer_norm=True, unit2ctrl_factory=TinyUnit2Control)
+        keys = {"harmonic_magnitude": 513, "harmonic_phase": 513, "noise_magnitude": 513}
+        assert m.unit2ctrl.kwargs == {"use_pitch_aug": False, "pcmer_norm": True}                 # vocoder.py:733
+    else:
+        m = V.CombSubSuperFast(SR, HOP, 2048, n_unit=n_unit, n_spk=1, unit2ctrl_factory=TinyUnit2Control)
+        keys = {"harmonic_magnitude": 1025, "harmonic_phase": 1025, "noise_magnitude": 1025, "noise_phase": 1025}
+        assert m.unit2ctrl.kwargs == {"use_pitch_aug": False, "use_naive_v2": True, "use_conv_stack": True}   # :637
+    m = m.to(dev).eval()
+    sd = m.state_dict()
+    assert sd["sampling_rate"].dim() == 0 and sd["block_size"].dim() == 0
+    if kind == "fast":
+        assert torch.equal(sd["window"].cpu(), torch.sqrt(torch.hann_window(1024)))                # :726
+    else:
+        assert int(sd["win_length"]) == 2048 and torch.equal(sd["window"].cpu(), torch.hann_window(2048))   # :628-629
+    assert dict(m.unit2ctrl.output_splits) == keys
+    units, f0, vol, u = _inputs(B, F, n_unit, dev)
+    gz = torch.randn(B, F * HOP, generator=torch.Generator().manual_seed(5)).to(dev)
+    captured = {}
+    m.unit2ctrl.register_forward_hook(lambda mod, i, o: captured.update(ctrls=o[0], phase=i[2]))
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: u)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: gz)
+    with torch.no_grad():
+        signal, hidden, (h2, n2) = m(units, f0, vol, spk_id=None, spk_mix_dict=None, aug_shift=None,
+                                     initial_phase=None, infer=True)
+    assert signal.shape == (B, F * HOP) and hidden.shape == (B, F, 256)
+    assert h2 is signal and n2 is signal                                                         # :710, :786
+    f0n = f0.cpu().numpy()
+    c = {k: v.detach().cpu().numpy() for k, v in captured["ctrls"].items()}
+    if kind == "fast":
+        nz = (u.cpu().numpy() * np.float32(2) - np.float32(1)).astype(np.float32)
+        ref = O.combsubfast_dsp(f0n, c["harmonic_magnitude"], c["harmonic_phase"], c["noise_magnitude"], nz, SR, HOP)
+        d = captured["phase"].cpu().numpy()[..., 0] - ref["phase_frames"]
+        assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi))).max() <= 5e-7
+    else:
+        ref = O.combsubsuperfast_dsp(f0n, c["harmonic_magnitude"], c["harmonic_phase"], c["noise_magnitude"],
+                                     c["noise_phase"], gz.cpu().numpy(), SR, HOP, 2048)
+        assert np.array_equal(captured["phase"].cpu().numpy()[..., 0], ref["phase_frames"])
+        comb, pf = m.fast_source_gen(f0)                                                         # :639-651
+        assert comb.shape == (B, F * HOP) and pf.shape == (B, F, 1)
+        assert np.abs(comb.cpu().numpy() - ref["exciter"]).max() <= 3e-7
+    e = rms(signal.cpu().numpy() - ref["signal"])
+    assert e <= 1e-5 * rms(ref["signal"]), (e, rms(ref["signal"]))
+    with pytest.raises(NotImplementedError):
+        m(units, f0, vol)
+
+
 def _import_reference():
     if not os.path.isdir(os.path.join(REF, "ddsp")):
         pytest.skip("reference checkout not present (only in the build container)")
@@ -142,6 +198,35 @@ def test_against_reference_module(dev, kind):
         assert e <= 2e-5 * rms(want.numpy()) and e <= 1e-4, (name, e, rms(want.numpy()))
 
 
+@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("kind", ["fast", "superfast"])
+def test_fast_against_reference_module(dev, kind):
+    """CombSubFast / CombSubSuperFast with the reference's own Unit2Control: same weights (strict state_dict load,
+    window buffers included), inputs and noise -> the reference's waveform."""
+    rcore, rvoc = _import_reference()
+    from ddsp_svc_amd import vocoder as V
+    name = {"fast": "CombSubFast", "superfast": "CombSubSuperFast"}[kind]
+    ref_cls = getattr(rvoc, "_reference_" + name, getattr(rvoc, name))
+    torch.manual_seed(2)
+    B, F, n_unit = 2, 9, 16
+    args = (SR, HOP) if kind == "fast" else (SR, HOP, 2048)
+    ref = ref_cls(*args, n_unit=n_unit, n_spk=1).eval()
+    ours = getattr(V, name)(*args, n_unit=n_unit, n_spk=1).eval()
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    units, f0, vol, u = _inputs(B, F, n_unit, torch.device("cpu"), seed=6)
+    gz = torch.randn(B, F * HOP, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)), \
+                mock.patch("torch.randn_like", side_effect=lambda t: gz.reshape(t.shape)):
+            r_sig, r_hid, _ = ref(units, f0, vol, infer=True)
+        with mock.patch("torch.rand", side_effect=lambda *a, **k: u), \
+                mock.patch("torch.randn", side_effect=lambda *a, **k: gz):
+            o_sig, o_hid, _ = ours(units, f0, vol, infer=True)
+    assert rms((o_hid - r_hid).numpy()) <= 1e-6 * max(rms(r_hid.numpy()), 1e-12) + 1e-7
+    e = rms((o_sig - r_sig).numpy())
+    assert e <= 2e-5 * rms(r_sig.numpy()) and e <= 1e-4, (e, rms(r_sig.numpy()))
+
+
 def test_patch_reference_swaps_classes_and_keeps_cpu_core():
     rcore, rvoc = _import_reference()
     from ddsp_svc_amd import vocoder as V
@@ -150,13 +235,16 @@ def test_patch_reference_swaps_classes_and_keeps_cpu_core():
     try:
         V.patch_reference()
         assert rvoc.Sins is V.Sins and rvoc.CombSub is V.CombSub
+        assert rvoc.CombSubFast is V.CombSubFast and rvoc.CombSubSuperFast is V.CombSubSuperFast
         sig = torch.rand(1, 4, 2)
         out = rcore.upsample(sig, 8)                         # CPU tensors keep the reference implementation
         assert out.shape == (1, 32, 2)
         np.testing.assert_array_equal(out.numpy(), O.upsample(sig.numpy(), 8))
     finally:
         rvoc.Sins, rvoc.CombSub = rvoc._reference_Sins, rvoc._reference_CombSub
+        rvoc.CombSubFast, rvoc.CombSubSuperFast = rvoc._reference_CombSubFast, rvoc._reference_CombSubSuperFast
         for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response"):
             if hasattr(rcore, "_reference_" + name):
                 setattr(rcore, name, getattr(rcore, "_reference_" + name))
+                delattr(rcore, "_reference_" + name)
         rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter
