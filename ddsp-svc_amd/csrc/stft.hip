@@ -125,6 +125,23 @@ __global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // the spectral filter itself
 // ------------------------------------------------------------------------------------------------
+// exp(x) on the hardware base-2 exponential: x log2(e) is split into its float32 rounding t and the residual r
+// (two-constant log2(e)), exp2(t) (1 + r ln 2).  Relative error ~1e-7 for |x| <= 80 (a bare exp2(x * log2e) is
+// off by |x| * 6e-8).  3 fma/mul + v_exp_f32 + 2 fma.
+__device__ __forceinline__ float exp_hw(float x) {
+  const float l2e_hi = 1.44269502f;                  // fl32(log2 e)
+  const float l2e_lo = 1.92596303e-8f;               // log2 e - l2e_hi
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147182f, e);
+}
+// (cos, sin) of pi * p on v_cos_f32 / v_sin_f32, which take revolutions; fract keeps the argument in their range
+__device__ __forceinline__ f32x2 cis_pi(float p) {
+  const float rev = __builtin_amdgcn_fractf(0.5f * p);
+  return f32x2{__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+}
 struct StftGeom {
   int F, T;               // control frames, samples per utterance (F * hop)
   int pairs;              // frame pairs per utterance: ceil((F + 1) / 2)   (frames 0..F)
@@ -136,8 +153,9 @@ struct StftGeom {
   long ld_hm, ld_hp, ld_nm, ld_np;
 };
 
-template <int R>
-__global__ void __launch_bounds__(64 * R, R == 4 ? 4 : 8)
+// WPS = waves per SIMD the kernel is compiled for (HIP's second __launch_bounds__ argument): register budget 512 / WPS
+template <int R, int WPS>
+__global__ void __launch_bounds__(64 * R, WPS)
 k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, const float* __restrict__ c_hmag,
               const float* __restrict__ c_hphase, const float* __restrict__ c_nmag,
               const float* __restrict__ c_nphase, const float* __restrict__ window, float* __restrict__ out,
@@ -199,20 +217,32 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
       // windowed input frame: exciter in the real, noise in the imaginary part
       f32x2 z[S];
       const int s0 = j * ST_HOP - PAD;
+      if (s0 >= 0 && s0 + N <= g.T) {                            // interior frame (wave-uniform): no edge handling
+        const float* ef = eb + s0 + tid;
+        const float* nf = nb + s0 + tid;
 #pragma unroll
-      for (int m = 0; m < S; ++m) {
-        int i = s0 + P * m + tid;
-        if (g.reflect) {
-          if (i < 0) i = -i;
-          if (i >= g.T) i = 2 * (g.T - 1) - i;
-        }
-        float e = 0.f, u = 0.f;
-        if (live && i >= 0 && i < g.T) {
-          e = eb[i];
-          u = nb[i];
+        for (int m = 0; m < S; ++m) {
+          const float e = ef[P * m];
+          float u = nf[P * m];
           if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+          z[m] = f32x2{w[m] * e, w[m] * u};
         }
-        z[m] = f32x2{w[m] * e, w[m] * u};
+      } else {
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+          int i = s0 + P * m + tid;
+          if (g.reflect) {
+            if (i < 0) i = -i;
+            if (i >= g.T) i = 2 * (g.T - 1) - i;
+          }
+          float e = 0.f, u = 0.f;
+          if (live && i >= 0 && i < g.T) {
+            e = eb[i];
+            u = nb[i];
+            if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+          }
+          z[m] = f32x2{w[m] * e, w[m] * u};
+        }
       }
       f32x2* A = ex[cur];
       f32x2* Bx = ex[cur ^ 1];
@@ -228,14 +258,11 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
         const f32x2 e2 = fft::add_conj(z[m], zneg);             // 2 E[k]
         const f32x2 u2 = fft::sub_conj(z[m], zneg);             // 2i U[k]
         // filters exp(mag) (cos(pi ph) + i sin(pi ph)); the noise one carries U's factor -i
-        float th = 0.5f * hp[m];
-        th = th - rintf(th);
-        const float ah = cs * expf(hm[m]);
-        const f32x2 Hs = {ah * __builtin_amdgcn_cosf(th), ah * __builtin_amdgcn_sinf(th)};
-        float tn = 0.5f * np_[m];
-        tn = tn - rintf(tn);
-        const float an = cn * expf(nm[m]);
-        const f32x2 Hn = {an * __builtin_amdgcn_sinf(tn), -an * __builtin_amdgcn_cosf(tn)};
+        const f32x2 ch = cis_pi(hp[m]), cz = cis_pi(np_[m]);
+        const float ah = cs * exp_hw(hm[m]);
+        const float an = cn * exp_hw(nm[m]);
+        const f32x2 Hs = {ah * ch.x, ah * ch.y};
+        const f32x2 Hn = {an * cz.y, -an * cz.x};
         f32x2 s = cmul(e2, Hs) + cmul(u2, Hn);
         if (!live) s = f32x2{0.f, 0.f};
         if (m < NB - 1) {
@@ -340,26 +367,38 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
   g.pairs = (F + 2) / 2;
   g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
   g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
-  // run length: as many workgroups as the chip holds at once so all run in one round; every run pays its warm-up
-  const int wg_per_cu = win == 2048 ? 4 : 8;
+  // waves per SIMD the kernel variant is compiled for (register budget = 512 / wps): the natural register demand
+  // (~190) spills heavily at 128, so 3 (168 VGPRs, three 256-thread workgroups per CU) for win 2048 and 2 (four
+  // 128-thread workgroups per CU) for win 1024 -- measured in profiles/r01_v5_stft_variants.json
+  int wps = win == 2048 ? 3 : 2;
+  if (const char* e = getenv("DDSP_HIP_STFT_WPS")) { int v = atoi(e); if (v >= 1) wps = v; }
+  const int wg_per_cu = wps * 4 / (win == 2048 ? 4 : 2);
   const int warm = win == 2048 ? 2 : 1;
+  // run length: as many workgroups as the chip holds at once, so all of them run in one round with equal work (a
+  // partial second round costs more than the longer runs; every run pays its warm-up)
   const long slots = (long)wg_per_cu * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
-  if (run < 4 * warm) run = 4 * warm;
+  if (run < 3 * warm) run = 3 * warm;
   if (const char* e = getenv("DDSP_HIP_STFT_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
-  if (win == 2048)
-    hipLaunchKernelGGL(k_stft_filter<4>, dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase, c_nmag,
-                       c_nphase, window, out, g);
-  else
-    hipLaunchKernelGGL(k_stft_filter<2>, dim3((unsigned)wgs), dim3(128), 0, st, exc, noise, c_hmag, c_hphase, c_nmag,
-                       c_nphase, window, out, g);
+#define DDSP_STFT_LAUNCH(R_, WPS_)                                                                                  \
+  hipLaunchKernelGGL((k_stft_filter<R_, WPS_>), dim3((unsigned)wgs), dim3(64 * R_), 0, st, exc, noise, c_hmag, c_hphase, \
+                     c_nmag, c_nphase, window, out, g)
+  if (win == 2048) {
+    if (wps == 4) DDSP_STFT_LAUNCH(4, 4);
+    else if (wps == 2) DDSP_STFT_LAUNCH(4, 2);
+    else DDSP_STFT_LAUNCH(4, 3);
+  } else {
+    if (wps == 3) DDSP_STFT_LAUNCH(2, 3);
+    else DDSP_STFT_LAUNCH(2, 2);
+  }
+#undef DDSP_STFT_LAUNCH
   return 0;
 }
 

@@ -248,3 +248,58 @@ def test_patch_reference_swaps_classes_and_keeps_cpu_core():
                 setattr(rcore, name, getattr(rcore, "_reference_" + name))
                 delattr(rcore, "_reference_" + name)
         rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter
+
+
+@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+def test_patch_reference_reaches_the_cascades(dev):
+    """The diffusion / reflow cascades bind CombSubFast / CombSubSuperFast by name when they are imported
+    (diffusion/vocoder.py:13, reflow/vocoder.py:12) and build them inside Unit2Wav / Unit2WavFast
+    (diffusion/vocoder.py:234,282; reflow/vocoder.py:164).  After patch_reference() those constructors must yield
+    the HIP-backed classes, take the reference's checkpoints unchanged (strict) and produce the reference's DDSP
+    waveform -- BASELINE.json cfg 5's integration seam, on the emulated device here."""
+    rcore, rvoc = _import_reference()
+    import importlib
+    dvoc = importlib.import_module("diffusion.vocoder")
+    fvoc = importlib.import_module("reflow.vocoder")
+    from ddsp_svc_amd import vocoder as V
+    saved = {m: {n: getattr(m, n) for n in ("CombSubFast", "CombSubSuperFast") if hasattr(m, n)} for m in (dvoc, fvoc)}
+    ref_names = {n: getattr(rvoc, "_reference_" + n, getattr(rvoc, n)) for n in ("Sins", "CombSub", "CombSubFast",
+                                                                                 "CombSubSuperFast")}
+    n_unit = 16
+    torch.manual_seed(4)
+    ref_fast = dvoc.Unit2WavFast(SR, HOP, 2048, n_unit, 1, n_layers=1, n_chans=32).eval()
+    ref_slow = dvoc.Unit2Wav(SR, HOP, n_unit, 1, n_layers=1, n_chans=32).eval()
+    ref_flow = fvoc.Unit2Wav(SR, HOP, 2048, n_unit, 1, n_layers=1, n_chans=32).eval()
+    try:
+        V.patch_reference()
+        assert dvoc.CombSubFast is V.CombSubFast and dvoc.CombSubSuperFast is V.CombSubSuperFast
+        assert fvoc.CombSubSuperFast is V.CombSubSuperFast
+        ours_fast = dvoc.Unit2WavFast(SR, HOP, 2048, n_unit, 1, n_layers=1, n_chans=32).eval()
+        ours_slow = dvoc.Unit2Wav(SR, HOP, n_unit, 1, n_layers=1, n_chans=32).eval()
+        ours_flow = fvoc.Unit2Wav(SR, HOP, 2048, n_unit, 1, n_layers=1, n_chans=32).eval()
+        assert type(ours_fast.ddsp_model) is V.CombSubSuperFast and type(ours_slow.ddsp_model) is V.CombSubFast
+        assert type(ours_flow.ddsp_model) is V.CombSubSuperFast
+        units, f0, vol, u = _inputs(1, 6, n_unit, torch.device("cpu"), seed=8)
+        gz = torch.randn(1, 6 * HOP, generator=torch.Generator().manual_seed(9))
+        for ours, ref in ((ours_fast, ref_fast), (ours_slow, ref_slow), (ours_flow, ref_flow)):
+            ours.load_state_dict(ref.state_dict(), strict=True)
+            with torch.no_grad():
+                with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)), \
+                        mock.patch("torch.randn_like", side_effect=lambda t: gz.reshape(t.shape)):
+                    r_wav, r_hid, _ = ref.ddsp_model(units, f0, vol, infer=True)
+                with mock.patch("torch.rand", side_effect=lambda *a, **k: u), \
+                        mock.patch("torch.randn", side_effect=lambda *a, **k: gz):
+                    o_wav, o_hid, _ = ours.ddsp_model(units, f0, vol, infer=True)
+            e = rms((o_wav - r_wav).numpy())
+            assert e <= 2e-5 * rms(r_wav.numpy()) and e <= 1e-4, (type(ref).__name__, e, rms(r_wav.numpy()))
+    finally:
+        for m, names in saved.items():
+            for n, c in names.items():
+                setattr(m, n, c)
+        for n, c in ref_names.items():
+            setattr(rvoc, n, c)
+        for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response"):
+            if hasattr(rcore, "_reference_" + name):
+                setattr(rcore, name, getattr(rcore, "_reference_" + name))
+                delattr(rcore, "_reference_" + name)
+        rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter
