@@ -9,7 +9,7 @@ caller discards is not materialised).  Multi-GPU: one process per GPU, utterance
 data-path collective ("weak" scaling: B per GPU fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      the dominant kernel (k_fir_mfma) timed alone with events on the launch stream
+  roofline      the dominant kernel (the time-varying FIR, k_fir_blk) timed alone with events on the launch stream
   cpu_baseline  the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
                 on this host's cores over a bounded sample of the same workload (N=1 only)
 """
@@ -294,17 +294,20 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    used_impl = a.fir_impl if a.fir_impl else (4 if N <= 512 else 3)
+    used_impl = a.fir_impl if a.fir_impl else (5 if N <= 512 else 3)
     fir_ms = time_fir(used_impl)
     mfma_ms = time_fir(3) if used_impl != 3 else fir_ms
     fir_flops = 4.0 * N * B * T                      # direct form: 2N multiply-adds per output sample
     fir_launches = 3 if a.model == "combsub" else 2
     fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
-    kname = "k_fir_fft" if used_impl == 4 else "k_fir_mfma"
+    kname = {4: "k_fir_fft", 5: "k_fir_blk"}.get(used_impl, "k_fir_mfma")
     traffic = hbm_traffic(kname) if (B, F, n) == (32, 862, 256) else None
-    # arithmetic the FFT form actually executes: per frame pair three 2048-point complex FFTs (5 N log2 N) + products
-    pairs = (F + 2) // 2
-    fft_flops = B * pairs * (3 * 5.0 * 2048 * 11 + 2048 * 2 * 10.0)
+    # arithmetic the FFT forms actually execute (5 N log2 N per complex transform + spectral products): per frame pair
+    # three 2048-point transforms (k_fir_fft) or per hop-block pair four 1024-point ones (k_fir_blk)
+    if used_impl == 5:
+        fft_flops = B * ((F + 1) // 2) * (4 * 5.0 * 1024 * 10 + 1024 * 3 * 14.0)
+    else:
+        fft_flops = B * ((F + 2) // 2) * (3 * 5.0 * 2048 * 11 + 2048 * 2 * 10.0)
 
     if rank == 0:
         total = B * world * T * a.steps
@@ -329,12 +332,12 @@ def main():
                          "note": "north-star roofline (algorithmic HBM bytes / time).  The kernel is NOT HBM-bound: see "
                                  "roofline_compute for the roof that binds it (DESIGN.md section 5)"},
             "roofline_compute": (
-                {"kernel": "k_fir_fft", "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
+                {"kernel": kname, "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
                  "achieved": fft_flops / (fir_ms * 1e-3) / 1e12, "frac": fft_flops / (fir_ms * 1e-3) / 1e12 / 157.3,
                  "executed_flops_per_launch": fft_flops,
                  "direct_form_equivalent_TFLOPs": fir_flops / (fir_ms * 1e-3) / 1e12,
                  "note": "vector f32 peak counts packed FMA; FFT butterflies are add/sub/mul (no FMA) so the attainable "
-                         "issue rate is at most half of it"} if used_impl == 4 else
+                         "issue rate is at most half of it"} if used_impl in (4, 5) else
                 {"kernel": "k_fir_mfma", "bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
                  "achieved": fir_flops / (fir_ms * 1e-3) / 1e12, "frac": fir_flops / (fir_ms * 1e-3) / 1e12 / 157.3,
                  "algorithmic_flops_per_launch": fir_flops}),

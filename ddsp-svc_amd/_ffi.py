@@ -48,7 +48,7 @@ SIGNATURES = {
 
 MODE_ROLL, MODE_HANN, MODE_DYNAMIC = 0, 1, 2
 ACT_NONE, ACT_EXP = 0, 1
-FIR_AUTO, FIR_SIMPLE, FIR_MFMA, FIR_MFMA8, FIR_FFT = 0, 1, 2, 3, 4
+FIR_AUTO, FIR_SIMPLE, FIR_MFMA, FIR_MFMA8, FIR_FFT, FIR_BLK = 0, 1, 2, 3, 4, 5
 
 _LIB = None
 _LOCK = threading.Lock()

@@ -43,7 +43,8 @@ extern "C" {
 #define DDSP_HIP_FIR_SIMPLE 1
 #define DDSP_HIP_FIR_MFMA   2       /* 4 waves = 1024 outputs per workgroup */
 #define DDSP_HIP_FIR_MFMA8  3       /* 8 waves = 2048 outputs per workgroup */
-#define DDSP_HIP_FIR_FFT    4       /* frequency-domain block convolution, hop 512, N <= 512 */
+#define DDSP_HIP_FIR_FFT    4       /* frequency-domain block convolution per frame (2048-point), hop 512, N <= 512 */
+#define DDSP_HIP_FIR_BLK    5       /* frequency-domain convolution per hop block (1024-point), hop 512, N <= 512 */
 
 int ddsp_hip_version(void);
 const char* ddsp_hip_error_string(int code);

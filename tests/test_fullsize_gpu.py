@@ -37,7 +37,7 @@ def batch(cuda):
     return f0, torch.split(ctrl, [NB, NB, NB], dim=-1), noise
 
 
-@pytest.mark.parametrize("impl", [3, 4])
+@pytest.mark.parametrize("impl", [3, 4, 5])
 def test_fir_identity_and_delay(cuda, batch, impl):
     """taps = unit impulse at N/2 (the delay the crop compensates, core.py:115) -> output == input; an impulse
     d taps later delays by d with zero fill at the start"""
@@ -55,7 +55,7 @@ def test_fir_identity_and_delay(cuda, batch, impl):
     assert float(y[:, :d].abs().max()) <= 1e-6
 
 
-@pytest.mark.parametrize("impl", [3, 4])
+@pytest.mark.parametrize("impl", [3, 4, 5])
 def test_fir_linearity_and_frame_locality(cuda, batch, impl):
     from ddsp_svc_amd import core
     _, _, x = batch

@@ -182,13 +182,13 @@ def test_allpass_response(dev):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("impl", [1, 2, 3, 4])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n_mag", [65, 129, 256])
 def test_fft_convolve_golden(dev, golden_dir, impl, n_mag):
     from ddsp_svc_amd import core
     g = np.load(os.path.join(golden_dir, f"filter_n{n_mag}.npz"))
     audio = T_(g["audio"], dev)
-    if impl == 4 and audio.shape[1] // g["ir_roll"].shape[1] != 512:
+    if impl in (4, 5) and audio.shape[1] // g["ir_roll"].shape[1] != 512:
         pytest.skip("the FFT form takes hop 512 only (this fixture uses another hop)")
     for key_ir, key_y in (("ir_roll", "y_roll"), ("ir_hann", "y_hann"), ("ir_dyn", "y_dyn")):
         y = N_(core.fft_convolve(audio, T_(g[key_ir], dev), impl=impl))
@@ -230,12 +230,16 @@ def test_fft_convolve_persistent_loop(dev, impl, monkeypatch):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("B,F,N,run", [(1, 1, 510, 12), (2, 2, 30, 12), (1, 3, 512, 12), (2, 7, 510, 2), (1, 8, 128, 1), (1, 13, 2, 3)])
-def test_fft_convolve_fft_form(dev, B, F, N, run, monkeypatch):
-    """impl 4 (frequency-domain block convolution): odd/even frame counts, single frames, the largest N it takes,
-    short workgroup runs (warm-up pair + hand-over between workgroups), and the fused input/output options"""
+@pytest.mark.parametrize("impl", [4, 5])
+@pytest.mark.parametrize("B,F,N,run", [(1, 1, 510, 12), (2, 2, 30, 12), (1, 3, 512, 12), (2, 7, 510, 2), (1, 8, 128, 1), (1, 13, 2, 3),
+                                       (1, 12, 254, 1)])
+def test_fft_convolve_fft_form(dev, B, F, N, run, impl, monkeypatch):
+    """impl 4 / 5 (frequency-domain convolution per frame / per hop block): odd/even frame counts, single frames,
+    the largest N they take, short workgroup runs (warm-up pair + hand-over between workgroups), and the fused
+    input/output options"""
     from ddsp_svc_amd import _ffi
     monkeypatch.setenv("DDSP_HIP_FFT_RUN", str(run))
+    monkeypatch.setenv("DDSP_HIP_BLK_RUN", str(run))
     rng = np.random.default_rng(B * 100 + F * 10 + N)
     T = F * HOP
     u = rng.uniform(0, 1, size=(B, T)).astype(np.float32)
@@ -247,11 +251,11 @@ def test_fft_convolve_fft_form(dev, B, F, N, run, monkeypatch):
     out, plain = torch.empty(B, T, device=dev), torch.empty(B, T, device=dev)
     st = _ffi.stream_of(ut)
     _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ut.data_ptr(), 1, irt.data_ptr(), addt.data_ptr(), out.data_ptr(),
-                                                plain.data_ptr(), B, F, HOP, N, 4, st))
+                                                plain.data_ptr(), B, F, HOP, N, impl, st))
     assert rms(N_(plain) - ref) <= 2e-6 * rms(ref)
     assert rms(N_(out) - (ref + add)) <= 2e-6 * rms(ref + add)
     # shapes outside the kernel are refused, not mangled
-    assert _ffi.lib().ddsp_hip_fft_convolve(ut.data_ptr(), 0, irt.data_ptr(), None, out.data_ptr(), None, B, F * 2, HOP // 2, N, 4, st) == -3
+    assert _ffi.lib().ddsp_hip_fft_convolve(ut.data_ptr(), 0, irt.data_ptr(), None, out.data_ptr(), None, B, F * 2, HOP // 2, N, impl, st) == -3
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
