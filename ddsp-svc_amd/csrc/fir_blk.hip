@@ -62,33 +62,35 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   for (int m = 0; m < S; ++m) ring[P * m + tid] = 0.f;
   int cur = 0;                                                 // ex[cur] plays "A"; swapped after every inverse transform
 
-  // one tap row, shifted: value at transform index n = 128 m + tid is taps[row][n - SH]; only m >= 2 can be live
+  // Global loads are issued unconditionally from clamped addresses and masked when they are USED: a load whose
+  // result feeds a select or the 2u-1 map right away would be waited for on the spot instead of staying in flight
+  // across the transforms (and a predicated load costs an exec-mask branch).
+  // One tap row, shifted: the value at transform index n = 128 m + tid is taps[row][n - SH]; only m >= 2 can be live.
   struct TapRow { float v[6]; };
   auto load_taps = [&](int j) -> TapRow {
     TapRow r;
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
-    const float* tr = tb + (long)row * g.N - SH + tid;
+    const float* tr = tb + (long)row * g.N;
 #pragma unroll
     for (int m = 2; m < S; ++m) {
-      const int i = P * m + tid - SH;
-      r.v[m - 2] = (i >= 0 && i < g.N) ? tr[P * m] : 0.f;
+      int i = P * m + tid - SH;
+      i = i < 0 ? 0 : (i >= g.N ? g.N - 1 : i);
+      r.v[m - 2] = tr[i];
     }
     return r;
   };
-  // one hop block of the input: 4 samples per thread (s = 128 m + tid), zero beyond the utterance
+  auto tap_at = [&](const TapRow& r, int m) -> float {          // m >= 2
+    const int i = P * m + tid - SH;
+    return (i >= 0 && i < g.N) ? r.v[m - 2] : 0.f;
+  };
+  // one hop block of the input: 4 samples per thread (s = 128 m + tid); blocks beyond the utterance read block F-1
+  // and are zeroed at use
   struct Blk { float v[4]; };
   auto load_blk = [&](int bi) -> Blk {
     Blk r;
-    const float* src = xb + (long)bi * FB_HOP + tid;
+    const float* src = xb + (long)(bi < g.F ? bi : g.F - 1) * FB_HOP + tid;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      float v = 0.f;
-      if (bi < g.F) {
-        v = src[P * m];
-        if (x_is_u01) v = fmaf(2.0f, v, -1.0f);                // noise = rand*2-1 (vocoder.py:603,854)
-      }
-      r.v[m] = v;
-    }
+    for (int m = 0; m < 4; ++m) r.v[m] = src[P * m];
     return r;
   };
   // FFT of two tap rows packed as real + i imaginary; returns with z in natural "slot m, lane tid" layout and
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     f32x2 z[S];
     z[0] = z[1] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int m = 2; m < S; ++m) z[m] = f32x2{ta.v[m - 2], tb2.v[m - 2]};
+    for (int m = 2; m < S; ++m) z[m] = f32x2{tap_at(ta, m), tap_at(tb2, m)};
     const f32x2* Zn = transform(z);
 #pragma unroll
     for (int m = 0; m < S; ++m) {
@@ -150,11 +152,15 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const Blk& cx = h == 0 ? cx0 : cx1;
+      const bool live = b0 + h < g.F;
       f32x2 z[S];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        float xv = cx.v[m];
+        if (x_is_u01) xv = fmaf(2.0f, xv, -1.0f);               // noise = rand*2-1 (vocoder.py:603,854)
+        if (!live) xv = 0.f;
         const float lam = (float)(P * m + tid) * inv_hop;
-        z[m] = f32x2{(1.0f - lam) * cx.v[m], lam * cx.v[m]};     // the two Bartlett halves (core.py:161)
+        z[m] = f32x2{(1.0f - lam) * xv, lam * xv};               // the two Bartlett halves (core.py:161)
       }
 #pragma unroll
       for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
@@ -173,6 +179,20 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
         else V[m] = fft::conj_minus_i_conj(V[m], y);
       }
     }
+    // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform
+    const bool own = q >= q_first;
+    const int e0 = (b0 - 1) * FB_HOP + 256 + tid;               // first emitted time of this thread
+    float add[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) add[i] = 0.f;
+    if (addend) {                                               // uniform; clamped addresses, masked by the store
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        int t = e0 + P * i;
+        t = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
+        add[i] = addend[ob + t];
+      }
+    }
     {
       f32x2* A = ex[cur];
       f32x2* Bx = ex[cur ^ 1];
@@ -182,7 +202,8 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
       cur ^= 1;
     }
     // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb-1) hop + n.
-    const bool own = q >= q_first;
+    const bool last = q == g.pairs - 1;
+    const bool interior = own && !last && (b0 - 1) * FB_HOP + 256 >= 0 && (b0 + 1) * FB_HOP + 256 <= g.T;   // uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int base = (b0 + h - 1) * FB_HOP;                   // time of transform index 0
@@ -190,17 +211,32 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
       for (int m = 0; m < S; ++m) ring[(base + P * m + tid) & (NF - 1)] += h == 0 ? V[m].x : -V[m].y;
       // times below (bb+1) hop - N/2 are final once block bb is in: emit [base + 256, base + 768); the last pair
       // also flushes what is left
-      const int n_emit = (q == g.pairs - 1 && h == 1) ? 8 : 4;
+      if (interior) {
 #pragma unroll
-      for (int m = 0; m < S; ++m) {
-        if (m < n_emit) {
+        for (int m = 0; m < 4; ++m) {
           const int t = base + 256 + P * m + tid;
           const int ri = t & (NF - 1);
           const float v = ring[ri];
           ring[ri] = 0.f;
-          if (own && t >= 0 && t < g.T) {
-            if (out_plain) out_plain[ob + t] = v;
-            out[ob + t] = addend ? v + addend[ob + t] : v;
+          if (out_plain) out_plain[ob + t] = v;
+          out[ob + t] = v + add[4 * h + m];
+        }
+      } else {
+        const int n_emit = (last && h == 1) ? 8 : 4;
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+          if (m < n_emit) {
+            const int t = base + 256 + P * m + tid;
+            const int ri = t & (NF - 1);
+            const float v = ring[ri];
+            ring[ri] = 0.f;
+            if (own && t >= 0 && t < g.T) {
+              if (out_plain) out_plain[ob + t] = v;
+              float a = 0.f;
+              if (m < 4) a = add[4 * h + m];                    // t == e0 + 128 (4 h + m)
+              else if (addend) a = addend[ob + t];              // the flush of the last pair
+              out[ob + t] = v + a;
+            }
           }
         }
       }
