@@ -124,10 +124,10 @@ __device__ __forceinline__ float cos_turns(float a) {
   return __builtin_amdgcn_cosf(r);
 }
 
-template <int ACT, bool HAS_IM>
+template <int ACT, bool HAS_IM, int MODE>
 __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_re, long ld_re,
                                                  const float* __restrict__ a_im, long ld_im, float scale,
-                                                 const float* __restrict__ table, int mode,
+                                                 const float* __restrict__ table,
                                                  const float* __restrict__ half_width, long rows, int n,
                                                  float* __restrict__ taps, int a_vec_ok) {
   __shared__ __attribute__((aligned(16))) float stage[2 * IR_STAGE];
@@ -238,39 +238,76 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
     __syncthreads();
   }
 
-  // epilogue: roll + mirror + window.  C/D layout: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+  // epilogue: roll + mirror + window.  C/D layout: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+  //   z[m] lands at taps[N/2 + m] (side 0, m < N/2) and z[N - m] at taps[N/2 - m] (side 1, m >= 1); z[N/2] only at taps[0]
+  // Everything a store needs besides the accumulator is fetched up front -- the window value of the lane's
+  // columns (periodic Hann) or the half width of the lane's rows (dynamic window) -- so the stores stream out
+  // back to back: a load between two stores would wait for every store before it (one counter tracks both).
   const int half = N / 2;
   const float* hann = table + 2 * plane;
+  // full tiles take a branch-free path: the two columns without a partner (m = 0 has no side 1, m = N/2 no side 0)
+  // store their one value twice instead of being masked
+  const bool full = row0 + GM <= rows && col0 + GN - 1 <= half;                  // workgroup-uniform
+  int jcol[2][2];                                     // [cb][side] output column; -1 = nothing to store (masked path)
+  bool flip[2][2];                                    // store the other side's value (full path duplicates)
+  float wcol[2][2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int m = col0 + wc * 64 + cb * 32 + li;
-    if (m > half) continue;                             // also covers m >= n
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int side = 0; side < 2; ++side) {
+      const bool ok = m <= half && (side == 0 ? m < half : m >= 1);
+      int j = side == 0 ? half + m : half - m;
+      flip[cb][side] = false;
+      if (!ok) {
+        if (full) { j = side == 0 ? half - m : half + m; flip[cb][side] = true; }   // m = N/2 -> taps[0]; m = 0 -> taps[N/2]
+        else j = -1;
+      }
+      jcol[cb][side] = j;
+      wcol[cb][side] = (MODE == IR_MODE_HANN && j >= 0) ? hann[j] : 1.f;
+    }
+  }
+  auto emit = [&](float* dst, float E, float O, float hw, int cb, int side) {
+    const int j = jcol[cb][side];
+    const bool minus = (side == 1) != flip[cb][side];
+    const float z = minus ? E - O : E + O;
+    float w = wcol[cb][side];
+    if (MODE == IR_MODE_DYNAMIC) {
+      float u = (float)(j - half) / hw;               // core.py:244
+      if (u > 1.0f) u = 0.0f;                         // core.py:245 -- only the upper side is clamped
+      w = (1.0f + cos_turns(kPiF * u)) / 2.0f;        // core.py:246
+    }
+    dst[j] = z * w;
+  };
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    float hwr[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long r = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      hwr[reg] = (MODE == IR_MODE_DYNAMIC && r < rows) ? half_width[r] : 1.f;
+    }
+    if (full) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float* dst = taps + (row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * (long)N;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int side = 0; side < 2; ++side)
+            emit(dst, accE[rb][cb][reg], HAS_IM ? accO[rb][cb][reg] : 0.f, hwr[reg], cb, side);
+      }
+    } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const long r = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if (r >= rows) continue;
-        const float E = accE[rb][cb][reg];
-        const float O = HAS_IM ? accO[rb][cb][reg] : 0.f;
-        const float hw = (mode == IR_MODE_DYNAMIC) ? half_width[r] : 1.f;
         float* dst = taps + r * (long)N;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          if (side == 0 && m >= half) continue;         // z[N/2] lands only at taps[0]
-          if (side == 1 && m == 0) continue;            // z[0] lands only at taps[N/2]
-          const int j = side == 0 ? half + m : half - m;
-          const float z = side == 0 ? E + O : E - O;
-          float w = 1.f;
-          if (mode == IR_MODE_HANN) {
-            w = hann[j];
-          } else if (mode == IR_MODE_DYNAMIC) {
-            float u = (float)(j - half) / hw;           // core.py:244
-            if (u > 1.0f) u = 0.0f;                     // core.py:245 -- only the upper side is clamped
-            w = (1.0f + cos_turns(kPiF * u)) / 2.0f;    // core.py:246
-          }
-          dst[j] = z * w;
-        }
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int side = 0; side < 2; ++side)
+            if (jcol[cb][side] >= 0) emit(dst, accE[rb][cb][reg], HAS_IM ? accO[rb][cb][reg] : 0.f, hwr[reg], cb, side);
       }
     }
   }
@@ -303,17 +340,24 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
   dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)(ir_np(n) / GN)), block(256);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int vec = (al16(a_re) && (ld_re & 3) == 0 && (!a_im || (al16(a_im) && (ld_im & 3) == 0))) ? 1 : 0;
+#define DDSP_IR_LAUNCH(ACT_, IM_, MODE_)                                                                          \
+  hipLaunchKernelGGL((k_ir_gemm<ACT_, IM_, MODE_>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, \
+                     half_width, rows, n, taps, vec)
+#define DDSP_IR_MODES(ACT_, IM_)                                              \
+  do {                                                                        \
+    if (mode == IR_MODE_HANN) DDSP_IR_LAUNCH(ACT_, IM_, IR_MODE_HANN);        \
+    else if (mode == IR_MODE_DYNAMIC) DDSP_IR_LAUNCH(ACT_, IM_, IR_MODE_DYNAMIC); \
+    else DDSP_IR_LAUNCH(ACT_, IM_, IR_MODE_ROLL);                             \
+  } while (0)
   if (a_im) {
-    if (act == IR_ACT_EXP)
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
-    else
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, true>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
+    if (act == IR_ACT_EXP) DDSP_IR_MODES(IR_ACT_EXP, true);
+    else DDSP_IR_MODES(IR_ACT_NONE, true);
   } else {
-    if (act == IR_ACT_EXP)
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_EXP, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
-    else
-      hipLaunchKernelGGL((k_ir_gemm<IR_ACT_NONE, false>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, mode, half_width, rows, n, taps, vec);
+    if (act == IR_ACT_EXP) DDSP_IR_MODES(IR_ACT_EXP, false);
+    else DDSP_IR_MODES(IR_ACT_NONE, false);
   }
+#undef DDSP_IR_MODES
+#undef DDSP_IR_LAUNCH
 }
 
 }  // namespace ddsp
