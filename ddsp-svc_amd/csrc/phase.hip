@@ -176,6 +176,7 @@ void launch_remove_above_fmax(const float* amps, const float* pitch, long rows, 
 PhaseCfg make_phase_cfg(double sr, int infer, int has_ip) {
   PhaseCfg c;
   c.sr_d = sr;
+  c.rsr_d = 1.0 / sr;
   c.sr_f = (float)sr;
   c.infer = infer;
   c.has_ip = has_ip;

@@ -225,6 +225,7 @@ static inline double __dadd_rn(double a, double b) { volatile double r = a + b; 
 static inline double __fma_rn(double a, double b, double c) { return fma(a, b, c); }
 static inline float __builtin_amdgcn_sinf(float turns) { return (float)sin(2.0 * M_PI * (double)turns); }   // v_sin_f32
 static inline float __builtin_amdgcn_cosf(float turns) { return (float)cos(2.0 * M_PI * (double)turns); }   // v_cos_f32
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }                                            // v_rcp_f32
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }                                         // v_exp_f32
 static inline float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }                                    // v_fract_f32
 #define __sinf(x) sinf(x)

@@ -45,3 +45,25 @@ for rows in (64 * 256, 64 * 512, 32 * 862, 64 * 768, 64 * 1024):
     res["rows%d_complex_roll_us" % rows] = timeit(lambda: _ffi.check(L.ddsp_hip_impulse_response(
         c.data_ptr(), n, im.data_ptr(), n, 0, 1.0, 0, None, rows, n, tab.data_ptr(), tp.data_ptr(), st)))
 print(json.dumps(res, indent=1))
+
+# the same kernels on the step's real operands: strided torch.split views of one [B,F,768] control tensor and the
+# half widths of the synthetic f0 curves
+import bench
+from ddsp_svc_amd import synth
+B, F = 32, 862
+f0, ctrls, noise = bench.make_inputs("combsub", B, F, (n, n, n), dev, 1234)
+rows = B * F
+tp = torch.empty(rows, N, device=dev)
+hw = (1.5 * 44100.0) / (f0.reshape(-1) + 1e-3)
+res2 = {}
+for name, c in (("split1_ld768", ctrls[1]), ("split2_ld768", ctrls[2]), ("contig", ctrls[1].contiguous())):
+    ld = c.stride(1)
+    res2["step_real_exp_dyn_%s_us" % name] = timeit(lambda: _ffi.check(L.ddsp_hip_impulse_response(
+        c.data_ptr(), ld, None, 0, 1, 1.0, 2, hw.data_ptr(), rows, n, tab.data_ptr(), tp.data_ptr(), st)))
+    res2["step_real_exp_hann_%s_us" % name] = timeit(lambda: _ffi.check(L.ddsp_hip_impulse_response(
+        c.data_ptr(), ld, None, 0, 1, 1.0 / 128, 1, None, rows, n, tab.data_ptr(), tp.data_ptr(), st)))
+hw2 = torch.rand(rows, device=dev) * 300 + 50
+cc = ctrls[1].contiguous()
+res2["step_real_exp_dyn_contig_randhw_us"] = timeit(lambda: _ffi.check(L.ddsp_hip_impulse_response(
+    cc.data_ptr(), n, None, 0, 1, 1.0, 2, hw2.data_ptr(), rows, n, tab.data_ptr(), tp.data_ptr(), st)))
+print(json.dumps(res2, indent=1))
