@@ -119,6 +119,80 @@ def cpu_baseline(kind, F, sizes, budget_s=12.0):
                       % (done, F, F * HOP / SR, cores, wall)}
 
 
+def _cpu_mel_worker(args):
+    seed, T = args
+    import numpy as _np
+    from oracle import ddsp_oracle as O
+    y = O.synth_gauss(1, T, seed=seed) * _np.float32(0.1)
+    return float(O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)).max())
+
+
+def bench_mel(a, rank, world, device):
+    """waveform -> log-mel front-end of the cascade (SURVEY.md 8-f #2): one k_mel launch over B x 10 s of audio"""
+    import multiprocessing as mp
+    import torch.distributed as dist
+    from ddsp_svc_amd import mel as M
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1
+    T = F * HOP
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    y = (torch.randn(B, T, generator=g) * 0.1).to(device)
+    stft = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        out = stft.get_mel(y)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = stft.get_mel(y)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        stft.get_mel(y)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 20
+    if rank != 0:
+        return
+    alg = (4.0 + 4.0 * 128 / HOP) * B * T                       # waveform in, [B,F,128] log-mel out
+    ms = elapsed / a.steps * 1e3
+    res = {"metric": "audio samples/sec, log-mel front-end 44.1kHz n_fft2048 hop512 128 mels",
+           "value": B * world * T * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "STFT.get_mel of B=%d/GPU x %.0f s waveforms (T=%d) -> [B,128,%d] log-mel"
+                                  % (B, a.seconds, T, F), "batch_per_gpu": B, "samples_per_utterance": T,
+                      "parallelism": "utterance-shard x%d" % world},
+           "roofline": {"kernel": "k_mel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+                        "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg, "avg_ms": k_ms, "launches_per_step": 1}}
+    if world == 1 and not a.no_cpu_baseline:
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        with mp.get_context("fork").Pool(cores, initializer=_cpu_worker_init) as pool:
+            pool.map(_cpu_mel_worker, [(i, 4096) for i in range(cores)])
+            t1 = time.perf_counter()
+            rounds = 0
+            while time.perf_counter() - t1 < 8.0 and rounds < 64:
+                pool.map(_cpu_mel_worker, [(rounds * cores + i, T) for i in range(cores)])
+                rounds += 1
+            wall = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": rounds * cores * T / wall, "unit": "samples/s", "cores": cores, "kind": "port",
+                               "sample": "%d waveforms of %.1f s, numpy oracle get_mel, %d worker processes, %.1f s wall"
+                                         % (rounds * cores, T / SR, cores, wall)}
+    print(json.dumps(res))
+
+
 def report_fast(a, rank, world, B, F, T, sizes, elapsed, gather_ms, f0, ctrls, noise, window, win):
     """JSON line for CombSubFast / CombSubSuperFast (SURVEY.md 8-f #1): the dominant kernel is the fused
     short-time spectral filter k_stft_filter, timed alone with events on the launch stream."""
@@ -186,7 +260,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast"])
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -208,6 +282,13 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from ddsp_svc_amd import _ffi, core, synth, sharding
+
+    if a.model == "mel":
+        bench_mel(a, rank, world, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B = a.batch_per_gpu
     F = int(a.seconds * SR) // HOP + 1              # the reference's frame-count rule (vocoder.py:222)

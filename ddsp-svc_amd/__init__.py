@@ -5,8 +5,9 @@ Sins/CombSub forward pass of yxlllc/DDSP-SVC).  Import name: ``ddsp_svc_amd`` (t
   core      -- ddsp/core.py functions (upsample, frequency_filter, ...) on HIP kernels
   synth     -- phase state, exciters, fused Sins / CombSub DSP tails
   vocoder   -- nn.Module drop-ins + patch_reference()
+  mel       -- nsf_hifigan.nvSTFT.STFT.get_mel (the cascade's waveform -> log-mel front-end)
   sharding  -- utterance sharding across the GPUs of a node (+ optional RCCL gather)
 """
-from . import _ffi, build, core, synth  # noqa: F401
+from . import _ffi, build, core, mel, synth  # noqa: F401
 
 __version__ = "0.1.0"

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 110          /* 0.1.1: + CombSubFast / CombSubSuperFast */
+#define DDSP_HIP_VERSION 120          /* 0.1.2: + CombSubFast / CombSubSuperFast, hop-block FIR, log-mel front-end */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -164,6 +164,21 @@ int ddsp_hip_combsubsuperfast_synth(const float* f0_frames, const float* rad_acc
                                     double sr, float* signal, void* ws, size_t ws_bytes, void* stream);
 
 size_t ddsp_hip_stft_workspace_bytes(int B, int F, int hop);
+
+/* ---- log-mel front-end of the cascade (nsf_hifigan/nvSTFT.py:73-117) ---- */
+
+/* STFT.get_mel(y, keyshift=0, speed=1, center=False): pad (win-hop)/2 both sides (reflect, or zeros when
+ * the right pad is not shorter than the signal, :97-103), frames of n_fft every hop, window[n_fft] (periodic
+ * Hann, :93-94), rfft, sqrt(re^2+im^2+1e-9) (:108), mel_basis[n_mels, n_fft/2+1] @ spec (:115),
+ * log(clamp(., clip_val)) (:116).
+ *   audio[B,T]; band[n_mels][2] = first / one-past-last non-zero bin of every mel_basis row (int32; the
+ *   projection only visits that band); out element (b, mel, frame) is written at
+ *   out[b*stride_b + mel*stride_mel + frame*stride_frame], frames = ddsp_hip_mel_frames(T, n_fft, hop).
+ * Supported: n_fft == win == 2048, hop == 512 (the 44.1 kHz NSF-HiFiGAN configuration). */
+int ddsp_hip_mel_frames(int T, int n_fft, int hop);
+int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* window, int n_fft, int hop,
+                             const float* mel_basis, const int* band, int n_mels, float clip_val,
+                             float* out, long stride_b, long stride_mel, long stride_frame, void* stream);
 
 #ifdef __cplusplus
 }

@@ -463,3 +463,61 @@ def synth_gauss(B: int, T: int, seed: int = 77) -> np.ndarray:
     """standard normal noise as ``randn_like`` draws it (vocoder.py:687), float32."""
     rng = np.random.default_rng(seed)
     return rng.standard_normal((B, T)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# 8-f #2  waveform -> log-mel front-end of the cascade           nsf_hifigan/nvSTFT.py:73-117
+# --------------------------------------------------------------------------------------
+def mel_filterbank_slaney(sr: float, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """Restatement of ``librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)`` with its defaults (``htk=False``,
+    ``norm='slaney'``), which nvSTFT.py:90 calls: Slaney's auditory-toolbox scale (linear below 1 kHz, 200/3 Hz
+    per mel; logarithmic above with step log(6.4)/27), triangular filters between consecutive band edges,
+    each scaled by ``2 / (f[m+2] - f[m])``.  librosa is not installed in this image (pinned version unknown:
+    requirements.txt lists it without one), so this function is checked against librosa's published algorithm
+    only -- PARITY UNPINNED for the filterbank itself; ``get_mel`` is pinned with this basis injected into
+    the reference (tests/golden/make_golden.py).  float32 result like librosa's."""
+    f_sp = 200.0 / 3.0
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=F64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=F64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    weights = np.maximum(0.0, np.minimum(lower, upper))
+    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return weights.astype(F32)
+
+
+def get_mel(y: np.ndarray, mel_basis: np.ndarray, n_fft: int = 2048, win_size: int = 2048, hop: int = 512,
+            clip_val: float = 1e-5, window=None) -> np.ndarray:
+    """``STFT.get_mel(y, keyshift=0, speed=1, center=False)`` (nvSTFT.py:73-117): manual padding of
+    ``(win-hop)//2`` left and ``max((win-hop+1)//2, win-len-pad_left)`` right (reflect when the right pad is shorter
+    than the signal, else zeros, :97-103), ``torch.stft(center=False)`` with the periodic Hann window (:106),
+    ``sqrt(re^2 + im^2 + 1e-9)`` (:108), mel matmul (:115), ``log(clamp(., clip_val))`` (:116) -> ``[B, n_mels, frames]``.
+    float64 arithmetic."""
+    y = np.asarray(y, dtype=F64)
+    B, T = y.shape
+    if window is None:
+        window = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_size) / win_size)).astype(F32)
+    w = np.asarray(window, dtype=F32).astype(F64)
+    pad_left = (win_size - hop) // 2
+    pad_right = max((win_size - hop + 1) // 2, win_size - T - pad_left)
+    mode = "reflect" if pad_right < T else "constant"
+    yp = np.pad(y, ((0, 0), (pad_left, pad_right)), mode=mode)
+    nfr = (yp.shape[1] - n_fft) // hop + 1
+    idx = (np.arange(nfr) * hop)[:, None] + np.arange(n_fft)[None, :]
+    spec = np.fft.rfft(yp[:, idx] * w, n_fft)                                  # [B, frames, bins]
+    mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
+    mel = np.einsum("mk,bfk->bmf", np.asarray(mel_basis, dtype=F32).astype(F64), mag)
+    return np.log(np.maximum(mel, clip_val))

@@ -13,6 +13,7 @@ Fixtures (all float32 unless noted):
   fastsrc.npz       CombSubSuperFast.fast_source_gen                     vocoder.py:639-651
   csfast_*.npz      CombSubFast.forward, captured controls, injected uniform noise      vocoder.py:735-786
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
+  mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
 """
 import os
 import sys
@@ -185,6 +186,20 @@ def main():
     np.savez(os.path.join(HERE, "cssuper_a.npz"), **run_fast("super", 2, 20, 43))
     np.savez(os.path.join(HERE, "cssuper_short.npz"), **run_fast("super", 1, 2, 44))     # T <= win/2: zero padding
     np.savez(os.path.join(HERE, "cssuper_f3.npz"), **run_fast("super", 1, 3, 45))        # shortest reflect case
+    # ---- log-mel front-end ---------------------------------------------------
+    import nsf_hifigan.nvSTFT as nv
+    basis = O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)
+    with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis):
+        for tag, Tn in (("a", 20 * 512), ("t1024", 1024), ("t512", 512)):
+            g = torch.Generator().manual_seed(len(tag) + Tn)
+            t = torch.arange(Tn) / 44100.0
+            y = sum(0.3 / k * torch.sin(2 * np.pi * 220.0 * k * t + k) for k in range(1, 40))
+            y = torch.stack([y + 0.05 * torch.randn(Tn, generator=g), 0.2 * torch.randn(Tn, generator=g)])
+            stft = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000)
+            mel = stft.get_mel(y)
+            np.savez(os.path.join(HERE, f"mel_{tag}.npz"), audio=y.numpy(), mel=mel.numpy(),
+                     basis=basis if tag == "a" else np.zeros(0, np.float32))
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

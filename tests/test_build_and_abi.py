@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ddsp_hip_version() == 110
+    assert lib.ddsp_hip_version() == 120
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -32,6 +32,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ddsp_hip_synth_workspace_bytes(1, 4, 512, 256) > 3 * 4 * 512 * 4
     assert b"workspace" in lib.ddsp_hip_error_string(-4)
     assert lib.ddsp_hip_stft_workspace_bytes(2, 4, 512) == 2 * 4 * 512 * 4
+    assert lib.ddsp_hip_mel_frames(20 * 512, 2048, 512) == 20 and lib.ddsp_hip_mel_frames(100, 2048, 512) == 1
     assert lib.ddsp_hip_fast_source(None, 1, 0, 512, 44100.0, None, None, None, None) == -1   # F <= 0
     assert lib.ddsp_hip_stft_filter(None, None, 0, None, 1025, None, 1025, None, 1024, None, 0, 1.0, None, 2048,
                                     1, 1, 1, 4, 512, None, None) == -1                      # row stride < n bins
