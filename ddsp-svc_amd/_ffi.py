@@ -45,7 +45,7 @@ SIGNATURES = {
                                                 c_int, c_int, c_int, c_double, P, P, c_size_t, P]),
     "ddsp_hip_stft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ddsp_hip_mel_frames": (c_int, [c_int, c_int, c_int]),
-    "ddsp_hip_mel_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, c_int, c_float, P,
+    "ddsp_hip_mel_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_float, P,
                                          c_long, c_long, c_long, P]),
 }
 

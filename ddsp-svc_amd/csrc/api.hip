@@ -322,13 +322,14 @@ int ddsp_hip_mel_frames(int T, int n_fft, int hop) {
 }
 
 int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* window, int n_fft, int hop,
-                             const float* mel_basis, const int* band, int n_mels, float clip_val, float* out,
-                             long stride_b, long stride_mel, long stride_frame, void* stream) {
+                             const float* mel_basis, const int* band, const float* band_weights, int n_band_weights,
+                             int n_mels, float clip_val, float* out, long stride_b, long stride_mel, long stride_frame,
+                             void* stream) {
   if (B < 0 || T < 1 || n_fft < 2 || hop < 1 || hop > n_fft || n_mels < 1) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
   if (!audio || !window || !mel_basis || !band || !out) return DDSP_HIP_EINVAL;
-  if (launch_mel(audio, B, T, window, n_fft, hop, mel_basis, band, n_mels, clip_val, out, stride_b, stride_mel,
-                 stride_frame, S(stream)) != 0)
+  if (launch_mel(audio, B, T, window, n_fft, hop, mel_basis, band, band_weights, n_band_weights, n_mels, clip_val, out,
+                 stride_b, stride_mel, stride_frame, S(stream)) != 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }

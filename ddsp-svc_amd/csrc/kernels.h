@@ -37,6 +37,7 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
                        long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize, int B,
                        int F, int hop, float* out, hipStream_t st);
 int launch_mel(const float* audio, int B, int T, const float* window, int n_fft, int hop, const float* basis,
-               const int* band, int n_mels, float clip, float* out, long sb, long sm, long sf, hipStream_t st);
+               const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
+               long sm, long sf, hipStream_t st);
 int mel_frames(int T, int n_fft, int hop);
 }  // namespace ddsp

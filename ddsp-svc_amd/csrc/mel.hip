@@ -19,12 +19,14 @@
 namespace ddsp {
 
 constexpr int ME_HOP = 512;
+constexpr int ME_WPACK = 4096;                                 // LDS floats for the packed band weights (Slaney-128: 1460)
 
 struct MelGeom {
   int T, frames, pairs;     // samples per utterance, frames per utterance, ceil(frames / 2)
   int run, runs_per_utt;    // pairs per workgroup
   int reflect;              // padding mode (nvSTFT.py:99-102)
   int n_mels;
+  int packed_len;           // floats of band weights staged in LDS (0: read the dense basis from global memory)
   float clip;
   long sb, sm, sf;          // output strides (floats): utterance, mel channel, frame
 };
@@ -32,13 +34,15 @@ struct MelGeom {
 template <int WPS>
 __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audio, const float* __restrict__ window,
                                                  const float* __restrict__ basis, const int* __restrict__ band,
-                                                 float* __restrict__ out, MelGeom g) {
+                                                 const float* __restrict__ packed, float* __restrict__ out,
+                                                 MelGeom g) {
   using PL = fft::Plan<4>;
   constexpr int N = PL::N, P = PL::P, S = 8;
   constexpr int BINS = N / 2 + 1;
   constexpr int PAD = (N - ME_HOP) / 2;                         // 768 (nvSTFT.py:97)
   constexpr int MROW = 1032;                                   // floats per magnitude row in LDS
   __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
+  __shared__ float wl[ME_WPACK];                               // every filter's band weights, back to back
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -52,34 +56,50 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
   float w[S];
 #pragma unroll
   for (int m = 0; m < S; ++m) w[m] = window[P * m + tid];
+  for (int i = tid; i < g.packed_len; i += P) wl[i] = packed[i];     // visible after the first barrier below
   int cur = 0;
 
+  // raw samples of a frame pair: issued unconditionally from clamped (reflected) addresses for the NEXT pair before
+  // the current one is transformed, masked when used
+  struct Raw { float v[S][2]; };
+  auto load_pair = [&](int pr) -> Raw {
+    Raw r;
+    const int s0 = 2 * pr * ME_HOP - PAD;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int i = s0 + h * ME_HOP + P * m + tid;
+        if (g.reflect) {
+          if (i < 0) i = -i;
+          if (i >= g.T) i = 2 * (g.T - 1) - i;
+        }
+        i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
+        r.v[m][h] = ab[i];
+      }
+    }
+    return r;
+  };
+  Raw nxt = load_pair(p_first);
   for (int pr = p_first; pr < p_last; ++pr) {
     const int j0 = 2 * pr;
     const bool live1 = j0 + 1 < g.frames;
+    const Raw cr = nxt;
+    if (pr + 1 < p_last) nxt = load_pair(pr + 1);
     // the two windowed frames: j0 in the real, j0 + 1 in the imaginary part
     f32x2 z[S];
     const int s0 = j0 * ME_HOP - PAD;
-    if (live1 && s0 >= 0 && s0 + ME_HOP + N <= g.T) {           // both frames inside the signal (workgroup-uniform)
-      const float* src = ab + s0 + tid;
 #pragma unroll
-      for (int m = 0; m < S; ++m) z[m] = f32x2{w[m] * src[P * m], w[m] * src[P * m + ME_HOP]};
-    } else {
+    for (int m = 0; m < S; ++m) {
+      float v[2];
 #pragma unroll
-      for (int m = 0; m < S; ++m) {
-        float v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int i = s0 + h * ME_HOP + P * m + tid;
-          if (g.reflect) {
-            if (i < 0) i = -i;
-            if (i >= g.T) i = 2 * (g.T - 1) - i;
-          }
-          const bool ok = i >= 0 && i < g.T && (h == 0 || live1);
-          v[h] = ok ? ab[i] : 0.f;
-        }
-        z[m] = f32x2{w[m] * v[0], w[m] * v[1]};
+      for (int h = 0; h < 2; ++h) {
+        int i = s0 + h * ME_HOP + P * m + tid;
+        // zero padding (constant mode) and the frame past the end of an odd count
+        const bool ok = (g.reflect || (i >= 0 && i < g.T)) && (h == 0 || live1);
+        v[h] = ok ? cr.v[m][h] : 0.f;
       }
+      z[m] = f32x2{w[m] * v[0], w[m] * v[1]};
     }
     f32x2* A = ex[cur];
     f32x2* Bx = ex[cur ^ 1];
@@ -106,11 +126,16 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
     const int h = tid >> 7;
     if (h == 0 || live1) {
       for (int c = tid & 127; c < g.n_mels; c += 128) {
-        const int lo = band[2 * c], hi = band[2 * c + 1];
-        const float* wr = basis + (long)c * BINS;
+        const int lo = band[4 * c], hi = band[4 * c + 1];
         const float* mg = mags + h * MROW;
         float acc = 0.f;
-        for (int k = lo; k < hi; ++k) acc = fmaf(wr[k], mg[k], acc);
+        if (g.packed_len > 0) {
+          const float* wr = wl + band[4 * c + 2] - lo;
+          for (int k = lo; k < hi; ++k) acc = fmaf(wr[k], mg[k], acc);
+        } else {
+          const float* wr = basis + (long)c * BINS;
+          for (int k = lo; k < hi; ++k) acc = fmaf(wr[k], mg[k], acc);
+        }
         out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
       }
     }
@@ -120,7 +145,8 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
 }
 
 int launch_mel(const float* audio, int B, int T, const float* window, int n_fft, int hop, const float* basis,
-               const int* band, int n_mels, float clip, float* out, long sb, long sm, long sf, hipStream_t st) {
+               const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
+               long sm, long sf, hipStream_t st) {
   if (n_fft != 2048 || hop != ME_HOP || T < 1 || T >= (1 << 30) || n_mels < 1) return -1;
   MelGeom g;
   const int pad_left = (n_fft - hop) / 2;
@@ -131,6 +157,7 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
   g.pairs = (g.frames + 1) / 2;
   g.reflect = pad_right < T ? 1 : 0;
   g.n_mels = n_mels; g.clip = clip;
+  g.packed_len = (packed && packed_len > 0 && packed_len <= ME_WPACK) ? packed_len : 0;
   g.sb = sb; g.sm = sm; g.sf = sf;
   // pairs are independent; a run only amortises the twiddle set-up.  One round of workgroups on the chip.
   int wps = 3;
@@ -147,11 +174,11 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   if (wps >= 4)
-    hipLaunchKernelGGL(k_mel<4>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, out, g);
+    hipLaunchKernelGGL(k_mel<4>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, packed, out, g);
   else if (wps == 3)
-    hipLaunchKernelGGL(k_mel<3>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, out, g);
+    hipLaunchKernelGGL(k_mel<3>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, packed, out, g);
   else
-    hipLaunchKernelGGL(k_mel<2>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, out, g);
+    hipLaunchKernelGGL(k_mel<2>, dim3((unsigned)wgs), dim3(256), 0, st, audio, window, basis, band, packed, out, g);
   return 0;
 }
 

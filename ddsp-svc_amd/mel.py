@@ -42,7 +42,8 @@ def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
 
 
 def _bands(basis):
-    """first / one-past-last non-zero bin of every row, int32 ``[n_mels, 2]`` (all-zero rows get an empty band)"""
+    """Band table of a mel basis: int32 ``[n_mels, 4]`` = (first, one-past-last non-zero bin, offset of the row's
+    band in the packed weights, 0) and the packed band weights (all-zero rows get an empty band)."""
     nz = basis != 0
     any_ = nz.any(dim=1)
     n_bins = basis.shape[1]
@@ -51,13 +52,19 @@ def _bands(basis):
     hi = torch.where(nz, idx + 1, 0).max(dim=1).values
     lo = torch.where(any_, lo, torch.zeros_like(lo))
     hi = torch.where(any_, hi, torch.zeros_like(hi))
-    return torch.stack([lo, hi], dim=1).to(torch.int32).contiguous()
+    length = hi - lo
+    off = torch.cumsum(length, 0) - length
+    table = torch.stack([lo, hi, off, torch.zeros_like(lo)], dim=1).to(torch.int32).contiguous()
+    inband = (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
+    packed = basis[inband].contiguous()                        # row-major order == band after band
+    return table, packed
 
 
 def mel_spectrogram(audio, window, mel_basis, band, hop_length, clip_val=1e-5):
+    band, packed = band
     """``[B,T]`` waveform -> ``[B, n_mels, frames]`` log-mel (nvSTFT.py:97-116).  The result is laid out
     frame-major in memory, so the ``transpose(1, 2)`` every caller applies (diffusion/vocoder.py:147) is free."""
-    _ffi.check_device(audio, window, mel_basis, band)
+    _ffi.check_device(audio, window, mel_basis, band, packed)
     if audio.dim() != 2:
         raise ValueError("audio must be [B, T]")
     a = audio if (audio.dtype == torch.float32 and audio.is_contiguous()) else audio.float().contiguous()
@@ -69,8 +76,8 @@ def mel_spectrogram(audio, window, mel_basis, band, hop_length, clip_val=1e-5):
     if frames < 1:
         raise ValueError("empty audio")
     store = torch.empty(B, frames, n_mels, dtype=torch.float32, device=a.device)
-    _ffi.check(_ffi.lib().ddsp_hip_mel_spectrogram(ptr(a), B, T, ptr(window), n_fft, hop, ptr(mel_basis), ptr(band), n_mels,
-                                                   float(clip_val), ptr(store), frames * n_mels, 1, n_mels,
+    _ffi.check(_ffi.lib().ddsp_hip_mel_spectrogram(ptr(a), B, T, ptr(window), n_fft, hop, ptr(mel_basis), ptr(band),
+                                                   ptr(packed), packed.numel(), n_mels, float(clip_val), ptr(store), frames * n_mels, 1, n_mels,
                                                    _ffi.stream_of(a)))
     return store.transpose(1, 2)
 

@@ -171,13 +171,16 @@ size_t ddsp_hip_stft_workspace_bytes(int B, int F, int hop);
  * the right pad is not shorter than the signal, :97-103), frames of n_fft every hop, window[n_fft] (periodic
  * Hann, :93-94), rfft, sqrt(re^2+im^2+1e-9) (:108), mel_basis[n_mels, n_fft/2+1] @ spec (:115),
  * log(clamp(., clip_val)) (:116).
- *   audio[B,T]; band[n_mels][2] = first / one-past-last non-zero bin of every mel_basis row (int32; the
- *   projection only visits that band); out element (b, mel, frame) is written at
+ *   audio[B,T]; band[n_mels][4] (int32) = {first, one-past-last non-zero bin of the mel_basis row, offset of
+ *   the row's band weights in band_weights, 0}: the projection only visits that band; band_weights (or NULL)
+ *   holds every row's band back to back (n_band_weights floats, staged on chip when <= 4096, else the dense
+ *   basis is read); out element (b, mel, frame) is written at
  *   out[b*stride_b + mel*stride_mel + frame*stride_frame], frames = ddsp_hip_mel_frames(T, n_fft, hop).
  * Supported: n_fft == win == 2048, hop == 512 (the 44.1 kHz NSF-HiFiGAN configuration). */
 int ddsp_hip_mel_frames(int T, int n_fft, int hop);
 int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* window, int n_fft, int hop,
-                             const float* mel_basis, const int* band, int n_mels, float clip_val,
+                             const float* mel_basis, const int* band, const float* band_weights,
+                             int n_band_weights, int n_mels, float clip_val,
                              float* out, long stride_b, long stride_mel, long stride_frame, void* stream);
 
 #ifdef __cplusplus
