@@ -39,6 +39,8 @@ SIGNATURES = {
     "ddsp_hip_fast_source": (c_int, [P, c_int, c_int, c_int, c_double, P, P, P, P]),
     "ddsp_hip_stft_filter": (c_int, [P, P, c_int, P, c_long, P, c_long, P, c_long, P, c_long, c_float, P, c_int,
                                      c_int, c_int, c_int, c_int, c_int, P, P]),
+    "ddsp_hip_stft_filter_backward": (c_int, [P, P, c_int, P, c_long, P, c_long, P, c_long, P, c_long, c_float, P,
+                                              c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),
     "ddsp_hip_combsubfast_synth": (c_int, [P, P, P, P, c_long, P, c_long, P, c_long, P, c_int, P,
                                            c_int, c_int, c_int, c_double, c_int, P, P, c_size_t, P]),
     "ddsp_hip_combsubsuperfast_synth": (c_int, [P, P, P, c_long, P, c_long, P, c_long, P, c_long, P, P, c_int,

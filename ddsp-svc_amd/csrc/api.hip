@@ -269,6 +269,27 @@ int ddsp_hip_stft_filter(const float* exciter, const float* noise, int noise_is_
   return finish();
 }
 
+int ddsp_hip_stft_filter_backward(const float* exciter, const float* noise, int noise_is_u01, const float* c_hmag,
+                                  long ld_hmag, const float* c_hphase, long ld_hphase, const float* c_nmag,
+                                  long ld_nmag, const float* c_nphase, long ld_nphase, float noise_scale,
+                                  const float* window, int win, int pad_reflect, int normalize,
+                                  const float* grad_signal, int B, int F, int hop, float* d_hmag, float* d_hphase,
+                                  float* d_nmag, float* d_nphase, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || win < 2 || (win & 1)) return DDSP_HIP_EINVAL;
+  const int n = win / 2 + 1;
+  if (ld_hmag < n || ld_hphase < n || ld_nmag < n || (c_nphase && ld_nphase < n)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!exciter || !noise || !c_hmag || !c_hphase || !c_nmag || !window || !grad_signal || !d_hmag || !d_hphase || !d_nmag)
+    return DDSP_HIP_EINVAL;
+  if ((c_nphase == nullptr) != (d_nphase == nullptr)) return DDSP_HIP_EINVAL;
+  if (pad_reflect && (long)F * hop <= win / 2) return DDSP_HIP_EINVAL;
+  if (launch_stft_filter_bwd(exciter, noise, noise_is_u01, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, c_nphase,
+                             ld_nphase, noise_scale, window, win, pad_reflect, normalize, grad_signal, B, F, hop, d_hmag,
+                             d_hphase, d_nmag, d_nphase, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 int ddsp_hip_combsubfast_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
                                const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
                                const float* c_nmag, long ld_nmag, const float* noise, int noise_is_u01,

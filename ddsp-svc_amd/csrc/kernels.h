@@ -36,6 +36,11 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
                        const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
                        long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize, int B,
                        int F, int hop, float* out, hipStream_t st);
+int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
+                           const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
+                           long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize,
+                           const float* grad_out, int B, int F, int hop, float* d_hmag, float* d_hphase, float* d_nmag,
+                           float* d_nphase, hipStream_t st);
 int launch_mel(const float* audio, int B, int T, const float* window, int n_fft, int hop, const float* basis,
                const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
                long sm, long sf, hipStream_t st);

@@ -334,6 +334,180 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gradient of the spectral filter w.r.t. its four control streams (what autograd returns for the controls of
+// CombSubFast / CombSubSuperFast.forward given dL/dsignal):
+//   gamma_j = w * (grad_out / env)[frame j]     adjoint of crop, envelope division, synthesis window and overlap-add
+//   G_j[k]  = c_k / N * rfft(gamma_j)[k]        adjoint of irfft (c_0 = c_N/2 = 1 with the imaginary part dropped, else 2)
+//   dL/dmag = Re(conj(G) E H),  dL/dphase = -pi Im(conj(G) E H)     per filter (E: exciter or noise frame spectrum)
+// Same machinery as the forward kernel: exciter and noise frames share one transform, the cotangent frames of a
+// pair share another (1.5 transforms per frame), no inverse transform and no overlap-add, so pairs are independent.
+// The repeated last filter frame (vocoder.py:662,664) adds frame F's gradient onto control row F-1: the workgroup
+// that owns frame F-1 processes frame F right after it and accumulates into the values it just wrote.
+// ------------------------------------------------------------------------------------------------
+template <int R, int WPS>
+__global__ void __launch_bounds__(64 * R, WPS)
+k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise, const float* __restrict__ c_hmag,
+                  const float* __restrict__ c_hphase, const float* __restrict__ c_nmag,
+                  const float* __restrict__ c_nphase, const float* __restrict__ window,
+                  const float* __restrict__ grad_out, float* d_hmag, float* d_hphase, float* d_nmag, float* d_nphase,
+                  StftGeom g) {
+  using PL = fft::Plan<R>;
+  constexpr int N = PL::N, P = PL::P, S = 8;
+  constexpr int PAD = N / 2;
+  constexpr int EMIT = ST_HOP / P;
+  constexpr int OVL = N / ST_HOP;
+  constexpr int NB = S / 2 + 1;                                // bins per thread: k = P m + tid (m < 4) + Nyquist on thread 0
+  constexpr int NBINS = N / 2 + 1;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.runs_per_utt;
+  const int run_no = blockIdx.x - b * g.runs_per_utt;
+  const int p_first = run_no * g.run;
+  int p_last = p_first + g.run;
+  if (p_last > g.pairs) p_last = g.pairs;                      // pairs cover frames 0..F-1 here
+  const long ob = (long)b * g.T;
+  const float* eb = exc + ob;
+  const float* nb = noise + ob;
+  const float* gb = grad_out + ob;
+
+  typename PL::Tw tw;
+  tw.init(tid);
+  float w[S];
+#pragma unroll
+  for (int m = 0; m < S; ++m) w[m] = window[P * m + tid];
+  f32x2* A = ex[0];
+  f32x2* Bx = ex[1];
+
+  // natural-order copy of a transform in Bx, one barrier: the next transform may write A at once (its last-pass
+  // readers are through) and Bx after its own first barrier
+  auto transform = [&](f32x2 (&z)[S]) {
+    PL::forward(z, tw, A, Bx, tid);
+#pragma unroll
+    for (int m = 0; m < S; ++m) Bx[P * m + tid] = z[m];
+    __syncthreads();
+  };
+  // windowed cotangent of frame jj at slot m: w * grad / env, zero outside the cropped range
+  auto gamma = [&](int jj, int m) -> float {
+    const int t = jj * ST_HOP - PAD + P * m + tid;
+    if (jj > g.F || t < 0 || t >= g.T) return 0.f;
+    float v = gb[t];
+    if (g.normalize) {
+      float env = 0.f;
+#pragma unroll
+      for (int q = 0; q < OVL; ++q) {
+        const int jf = jj + m / EMIT - q;
+        const float wq = w[(m % EMIT) + q * EMIT];
+        if (jf >= 0 && jf <= g.F) env = fmaf(wq, wq, env);
+      }
+      v = v / env;
+    }
+    return w[m] * v;
+  };
+  // Gs = c_k / (4 N) * 2 Gamma for the thread's bins of frames ja (real part of the packed transform) and ja + 1
+  auto cotangent_pair = [&](int ja, f32x2 (&G0)[NB], f32x2 (&G1)[NB]) {
+    f32x2 z[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) z[m] = f32x2{gamma(ja, m), gamma(ja + 1, m)};
+    transform(z);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      const int k = P * m + tid;
+      const f32x2 zneg = Bx[(N - k) & (N - 1)];
+      const f32x2 p = fft::add_conj(z[m], zneg);                // 2 Gamma_ja
+      const f32x2 d = fft::sub_conj(z[m], zneg);                // 2i Gamma_ja+1
+      const bool edge = (m == 0 && tid == 0) || m == NB - 1;    // DC and Nyquist bins
+      const float c = (edge ? 0.25f : 0.5f) / (float)N;
+      G0[m] = f32x2{p.x * c, edge ? 0.f : p.y * c};
+      G1[m] = f32x2{d.y * c, edge ? 0.f : -d.x * c};            // d / i
+    }
+  };
+  // one frame: spectra of exciter and noise, filters, products, store (accumulate: add onto what this thread wrote)
+  auto frame = [&](int jj, const f32x2 (&Gs)[NB], bool accumulate) {
+    const int row = jj < g.F ? jj : g.F - 1;
+    const long rb = (long)b * g.F + row;
+    float hm[NB], hp[NB], nm[NB], np_[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      hm[m] = hp[m] = nm[m] = np_[m] = 0.f;
+      if (m < NB - 1 || tid == 0) {
+        const int k = P * m + tid;
+        hm[m] = c_hmag[rb * g.ld_hm + k];
+        hp[m] = c_hphase[rb * g.ld_hp + k];
+        nm[m] = c_nmag[rb * g.ld_nm + k];
+        if (c_nphase) np_[m] = c_nphase[rb * g.ld_np + k];
+      }
+    }
+    f32x2 z[S];
+    const int s0 = jj * ST_HOP - PAD;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      int i = s0 + P * m + tid;
+      if (g.reflect) {
+        if (i < 0) i = -i;
+        if (i >= g.T) i = 2 * (g.T - 1) - i;
+      }
+      float e = 0.f, u = 0.f;
+      if (i >= 0 && i < g.T) {
+        e = eb[i];
+        u = nb[i];
+        if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+      }
+      z[m] = f32x2{w[m] * e, w[m] * u};
+    }
+    transform(z);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      if (m < NB - 1 || tid == 0) {
+        const int k = P * m + tid;
+        const f32x2 zneg = Bx[(N - k) & (N - 1)];
+        const f32x2 e2 = fft::add_conj(z[m], zneg);             // 2 E[k]
+        const f32x2 u2 = fft::sub_conj(z[m], zneg);             // 2i U[k]
+        const f32x2 ch = cis_pi(hp[m]), cz = cis_pi(np_[m]);
+        const float ah = exp_hw(hm[m]);
+        const float an = g.noise_scale * exp_hw(nm[m]);
+        const f32x2 a = cmul(e2, f32x2{ah * ch.x, ah * ch.y});    // 2 E Hs
+        const f32x2 n = cmul(u2, f32x2{an * cz.y, -an * cz.x});   // 2 U Hn  (U = u2 / 2i)
+        // conj(G) x: real part G.x x.x + G.y x.y, imaginary part G.x x.y - G.y x.x
+        const float gx = Gs[m].x, gy = Gs[m].y;
+        float v0 = fmaf(gx, a.x, gy * a.y);
+        float v1 = -kPiF * fmaf(gx, a.y, -(gy * a.x));
+        float v2 = fmaf(gx, n.x, gy * n.y);
+        float v3 = -kPiF * fmaf(gx, n.y, -(gy * n.x));
+        const long o = rb * NBINS + k;
+        if (accumulate) {
+          v0 += d_hmag[o];
+          v1 += d_hphase[o];
+          v2 += d_nmag[o];
+          if (d_nphase) v3 += d_nphase[o];
+        }
+        d_hmag[o] = v0;
+        d_hphase[o] = v1;
+        d_nmag[o] = v2;
+        if (d_nphase) d_nphase[o] = v3;
+      }
+    }
+  };
+
+  for (int pr = p_first; pr < p_last; ++pr) {
+    const int j0 = 2 * pr;
+    f32x2 G0[NB], G1[NB];
+    cotangent_pair(j0, G0, G1);
+    frame(j0, G0, false);
+    if (j0 + 1 < g.F) frame(j0 + 1, G1, false);
+    if (pr == g.pairs - 1) {
+      // the repeated last frame F: its cotangent is G1 when F is odd (frame F = j0 + 1), else a transform of its own
+      if (j0 + 1 == g.F) {
+        frame(g.F, G1, true);
+      } else {
+        f32x2 GF[NB], Gdrop[NB];
+        cotangent_pair(g.F, GF, Gdrop);
+        frame(g.F, GF, true);
+      }
+    }
+  }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 int launch_fast_combtooth(const float* f0_frames, const float* rad_acc, int B, int F, int hop, double sr, float* out,
                           hipStream_t st) {
@@ -399,6 +573,38 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
     else DDSP_STFT_LAUNCH(2, 2);
   }
 #undef DDSP_STFT_LAUNCH
+  return 0;
+}
+
+int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
+                           const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
+                           long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize,
+                           const float* grad_out, int B, int F, int hop, float* d_hmag, float* d_hphase, float* d_nmag,
+                           float* d_nphase, hipStream_t st) {
+  if (hop != ST_HOP || (win != 1024 && win != 2048) || (long)F * hop >= (1L << 30)) return -1;
+  StftGeom g;
+  g.F = F; g.T = F * hop;
+  g.pairs = (F + 1) / 2;                                       // frames 0..F-1; frame F rides with the last pair
+  g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
+  g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
+  const int wg_per_cu = win == 2048 ? 3 : 4;
+  const long slots = (long)wg_per_cu * 256;
+  long per_utt = slots / (B > 0 ? B : 1);
+  if (per_utt < 1) per_utt = 1;
+  int run = (int)((g.pairs + per_utt - 1) / per_utt);
+  if (run < 2) run = 2;
+  if (const char* e = getenv("DDSP_HIP_STFT_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (run > g.pairs) run = g.pairs;
+  g.run = run;
+  g.runs_per_utt = (g.pairs + run - 1) / run;
+  const long wgs = (long)B * g.runs_per_utt;
+  if (wgs > 0x7fffffffL) return -1;
+  if (win == 2048)
+    hipLaunchKernelGGL((k_stft_filter_bwd<4, 3>), dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase,
+                       c_nmag, c_nphase, window, grad_out, d_hmag, d_hphase, d_nmag, d_nphase, g);
+  else
+    hipLaunchKernelGGL((k_stft_filter_bwd<2, 2>), dim3((unsigned)wgs), dim3(128), 0, st, exc, noise, c_hmag, c_hphase,
+                       c_nmag, c_nphase, window, grad_out, d_hmag, d_hphase, d_nmag, d_nphase, g);
   return 0;
 }
 

@@ -214,6 +214,57 @@ def stft_filter(exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnit
     return out
 
 
+def stft_filter_backward(grad_signal, exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase,
+                         window, block_size, noise_scale=1.0 / 128.0, pad_reflect=True, normalize=True,
+                         noise_is_u01=False):
+    """Gradients of ``stft_filter`` w.r.t. its control streams for the cotangent ``grad_signal [B,T]``:
+    ``(d_hmag, d_hphase, d_nmag, d_nphase|None)``, each ``[B,F,n]``."""
+    _ffi.check_device(grad_signal, exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnitude, window)
+    B, T = exciter.shape
+    hop = int(block_size)
+    F = T // hop
+    win = window.numel()
+    n = win // 2 + 1
+    hm, ldhm = _rows(harmonic_magnitude, n)
+    hp, ldhp = _rows(harmonic_phase, n)
+    nm, ldnm = _rows(noise_magnitude, n)
+    npz, ldnp = (None, 0) if noise_phase is None else _rows(noise_phase, n)
+    dev = exciter.device
+    d_hm, d_hp, d_nm = (torch.empty(B, F, n, dtype=torch.float32, device=dev) for _ in range(3))
+    d_np = None if noise_phase is None else torch.empty(B, F, n, dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().ddsp_hip_stft_filter_backward(
+        ptr(_f32c(exciter)), ptr(_f32c(noise)), int(noise_is_u01), ptr(hm), ldhm, ptr(hp), ldhp, ptr(nm), ldnm,
+        ptr(npz), ldnp, float(noise_scale), ptr(_f32c(window)), win, int(pad_reflect), int(normalize),
+        ptr(_f32c(grad_signal.reshape(B, T))), B, F, hop, ptr(d_hm), ptr(d_hp), ptr(d_nm), ptr(d_np),
+        _ffi.stream_of(exciter)))
+    return d_hm, d_hp, d_nm, d_np
+
+
+class StftFilterFunction(torch.autograd.Function):
+    """``stft_filter`` with autograd w.r.t. the control streams (exciter, noise and window are data).  Training
+    back-propagates through CombSubFast / CombSubSuperFast.forward into Unit2Control (solver.py:93-103)."""
+
+    @staticmethod
+    def forward(ctx, exciter, noise, hmag, hphase, nmag, nphase, window, block_size, noise_scale, pad_reflect,
+                normalize, noise_is_u01):
+        ctx.save_for_backward(exciter, noise, hmag, hphase, nmag, nphase if nphase is not None else hmag.new_empty(0),
+                              window)
+        ctx.cfg = (int(block_size), float(noise_scale), bool(pad_reflect), bool(normalize), bool(noise_is_u01),
+                   nphase is not None)
+        return stft_filter(exciter, noise, hmag.detach(), hphase.detach(), nmag.detach(),
+                           None if nphase is None else nphase.detach(), window, block_size, noise_scale=noise_scale,
+                           pad_reflect=pad_reflect, normalize=normalize, noise_is_u01=noise_is_u01)
+
+    @staticmethod
+    def backward(ctx, grad_signal):
+        exciter, noise, hmag, hphase, nmag, nphase, window = ctx.saved_tensors
+        hop, scale, reflect, normalize, u01, has_np = ctx.cfg
+        d_hm, d_hp, d_nm, d_np = stft_filter_backward(grad_signal.contiguous(), exciter, noise, hmag, hphase, nmag,
+                                                      nphase if has_np else None, window, hop, noise_scale=scale,
+                                                      pad_reflect=reflect, normalize=normalize, noise_is_u01=u01)
+        return None, None, d_hm, d_hp, d_nm, d_np, None, None, None, None, None, None
+
+
 def combsubfast_synth(f0_frames, state: PhaseState, harmonic_magnitude, harmonic_phase, noise_magnitude, noise,
                       window, sampling_rate, block_size, noise_is_u01=False):
     """DSP tail of ``CombSubFast.forward`` (vocoder.py:758-784) from raw controls -> ``signal [B,T]``."""
@@ -225,10 +276,15 @@ def combsubfast_synth(f0_frames, state: PhaseState, harmonic_magnitude, harmonic
     n = hop + 1
     if window.numel() != 2 * hop:
         raise ValueError("CombSubFast window must hold 2 * block_size samples")
+    nz = _f32c(noise.reshape(B, T))
+    if torch.is_grad_enabled() and any(c.requires_grad for c in (harmonic_magnitude, harmonic_phase, noise_magnitude)):
+        # training: exciter materialised once (it carries no gradient), the spectral tail through autograd
+        comb = combtooth(f0_frames, state, sampling_rate, block_size)
+        return StftFilterFunction.apply(comb, nz, harmonic_magnitude, harmonic_phase, noise_magnitude, None, window,
+                                        hop, 1.0 / 128.0, False, False, noise_is_u01)
     hm, ldhm = _rows(harmonic_magnitude, n)
     hp, ldhp = _rows(harmonic_phase, n)
     nm, ldnm = _rows(noise_magnitude, n)
-    nz = _f32c(noise.reshape(B, T))
     dev = f0.device
     ws, need = _stft_ws(B, F, hop, dev)
     signal = torch.empty(B, T, dtype=torch.float32, device=dev)
@@ -251,11 +307,16 @@ def combsubsuperfast_synth(f0_frames, state: FastSourceState, harmonic_magnitude
     T = F * hop
     win = window.numel()
     n = win // 2 + 1
+    nz = _f32c(noise.reshape(B, T))
+    if torch.is_grad_enabled() and any(c.requires_grad for c in (harmonic_magnitude, harmonic_phase, noise_magnitude,
+                                                                  noise_phase)):
+        comb = fast_source(f0_frames, sampling_rate, block_size, want_combtooth=True).combtooth
+        return StftFilterFunction.apply(comb, nz, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase,
+                                        window, hop, 1.0 / 128.0, T > win // 2, True, False)
     hm, ldhm = _rows(harmonic_magnitude, n)
     hp, ldhp = _rows(harmonic_phase, n)
     nm, ldnm = _rows(noise_magnitude, n)
     npz, ldnp = _rows(noise_phase, n)
-    nz = _f32c(noise.reshape(B, T))
     dev = f0.device
     ws, need = _stft_ws(B, F, hop, dev)
     signal = torch.empty(B, T, dtype=torch.float32, device=dev)

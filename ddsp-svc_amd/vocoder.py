@@ -112,7 +112,6 @@ class CombSubFast(_SynthBase):
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :743-753
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :756
-        self._check_inference_only(*ctrls.values())
         B, F = f0_frames.shape[0], f0_frames.shape[1]
         u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :771
         signal = synth.combsubfast_synth(f0_frames, st, ctrls["harmonic_magnitude"], ctrls["harmonic_phase"],
@@ -145,7 +144,6 @@ class CombSubSuperFast(_SynthBase):
         st = synth.fast_source(f0_frames, self._sr, self._hop)                                  # :653
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :656
-        self._check_inference_only(*ctrls.values())
         B, F = f0_frames.shape[0], f0_frames.shape[1]
         gauss = torch.randn(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)     # randn_like, :687
         signal = synth.combsubsuperfast_synth(f0_frames, st, ctrls["harmonic_magnitude"], ctrls["harmonic_phase"],

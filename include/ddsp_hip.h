@@ -144,6 +144,17 @@ int ddsp_hip_stft_filter(const float* exciter, const float* noise, int noise_is_
                          float noise_scale, const float* window, int win, int pad_reflect, int normalize,
                          int B, int F, int hop, float* signal, void* stream);
 
+/* What autograd returns for the four control streams of ddsp_hip_stft_filter given grad_signal[B,T] =
+ * dL/dsignal (training: solver.py:93-103 back-propagates through CombSubFast / CombSubSuperFast.forward):
+ * d_hmag, d_hphase, d_nmag [B,F,win/2+1] contiguous, d_nphase likewise or NULL when c_nphase is NULL.
+ * Same arguments and supported shapes as the forward entry point. */
+int ddsp_hip_stft_filter_backward(const float* exciter, const float* noise, int noise_is_u01,
+                                  const float* c_hmag, long ld_hmag, const float* c_hphase, long ld_hphase,
+                                  const float* c_nmag, long ld_nmag, const float* c_nphase, long ld_nphase,
+                                  float noise_scale, const float* window, int win, int pad_reflect, int normalize,
+                                  const float* grad_signal, int B, int F, int hop,
+                                  float* d_hmag, float* d_hphase, float* d_nmag, float* d_nphase, void* stream);
+
 /* DSP tail of CombSubFast.forward (ddsp/vocoder.py:758-784) from raw controls and the phase state of
  * ddsp_hip_phase: combtooth (:764) -> sqrt-Hann frames of 2*hop -> filters -> overlap-add.
  * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1, :771); window[2*hop] is the

@@ -521,3 +521,53 @@ def get_mel(y: np.ndarray, mel_basis: np.ndarray, n_fft: int = 2048, win_size: i
     mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
     mel = np.einsum("mk,bfk->bmf", np.asarray(mel_basis, dtype=F32).astype(F64), mag)
     return np.log(np.maximum(mel, clip_val))
+
+
+# --------------------------------------------------------------------------------------
+# 8-f #3 (first part)  gradient of the short-time spectral tail w.r.t. the controls
+# --------------------------------------------------------------------------------------
+def stft_filter_backward(grad_out, exciter, noise, c_hmag, c_hphase, c_nmag, c_nphase, window, hop=512,
+                         pad_mode="reflect", normalize=True, noise_scale=1.0 / 128.0):
+    """What autograd returns for the controls of ``CombSubSuperFast.forward`` (vocoder.py:661-708; with
+    ``pad_mode='constant'``, ``normalize=False``, ``c_nphase=None`` and the sqrt-Hann window: ``CombSubFast``,
+    :758-784) given ``grad_out = dL/dsignal [B,T]``, written out analytically in float64:
+
+      gamma_j = w * (grad_out / env)[frame j]                  (adjoint of crop + envelope division + window + overlap-add)
+      G_j[k]  = c_k / N * rfft(gamma_j)[k]                     (adjoint of irfft; c_0 = c_N/2 = 1 and imaginary part 0, else 2)
+      dL/dmag   = Re(conj(G) E H),   dL/dphase = -pi Im(conj(G) E H)        per filter, E = rfft of the windowed
+      exciter (noise) frame, H the filter; the last control row also receives the repeated last frame (:662,:664).
+
+    Returns ``(d_hmag, d_hphase, d_nmag, d_nphase|None)``, each ``[B,F,n]``."""
+    w = np.asarray(window, dtype=F32).astype(F64)
+    win = w.shape[0]
+    g = np.asarray(grad_out, dtype=F64)
+    B, T = g.shape
+    Fr = T // hop
+    Hs = spectral_filters(c_hmag, c_hphase)
+    Hn = spectral_filters(c_nmag, c_nphase, noise_scale)
+    E = np.fft.rfft(_frames(exciter, win, hop, pad_mode) * w, win)
+    U = np.fft.rfft(_frames(noise, win, hop, pad_mode) * w, win)
+    nfr = E.shape[1]
+    half = win // 2
+    if normalize:
+        env = np.zeros(win + hop * (nfr - 1))
+        for j in range(nfr):
+            env[j * hop:j * hop + win] += w * w
+        g = g / env[half:half + T]
+    gp = np.pad(g, ((0, 0), (half, half)))                      # zero gradient outside the cropped range
+    idx = (np.arange(nfr) * hop)[:, None] + np.arange(win)[None, :]
+    Gam = np.fft.rfft(gp[:, idx] * w, win)
+    ck = np.full(half + 1, 2.0)
+    ck[0] = ck[half] = 1.0
+    G = Gam * ck / win
+    G[..., 0] = G[..., 0].real
+    G[..., half] = G[..., half].real
+
+    def fold(x):                                                # frame F shares the last control row
+        out = x[:, :Fr].copy()
+        out[:, Fr - 1] += x[:, Fr]
+        return out
+    ps = np.conj(G) * E * Hs
+    pn = np.conj(G) * U * Hn
+    return (fold(ps.real), fold(-np.pi * ps.imag), fold(pn.real),
+            None if c_nphase is None else fold(-np.pi * pn.imag))

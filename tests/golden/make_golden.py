@@ -14,6 +14,8 @@ Fixtures (all float32 unless noted):
   csfast_*.npz      CombSubFast.forward, captured controls, injected uniform noise      vocoder.py:735-786
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
   mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
+  *_grad.npz        autograd of CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
+                    for a random cotangent R: d(sum(signal * R)) / d ctrl
 """
 import os
 import sys
@@ -186,6 +188,41 @@ def main():
     np.savez(os.path.join(HERE, "cssuper_a.npz"), **run_fast("super", 2, 20, 43))
     np.savez(os.path.join(HERE, "cssuper_short.npz"), **run_fast("super", 1, 2, 44))     # T <= win/2: zero padding
     np.savez(os.path.join(HERE, "cssuper_f3.npz"), **run_fast("super", 1, 3, 45))        # shortest reflect case
+    # ---- gradients of the spectral tails w.r.t. the controls -----------------
+    def run_grad(kind, B, Fr, seed):
+        torch.manual_seed(seed)
+        model = (V.CombSubFast(sr, hop, n_unit=64, n_spk=1) if kind == "fast"
+                 else V.CombSubSuperFast(sr, hop, 2048, n_unit=64, n_spk=1)).eval()
+        with torch.no_grad():
+            model.unit2ctrl.dense_out.weight_g.mul_(2.0)
+        g = torch.Generator().manual_seed(seed + 1)
+        units = torch.randn(B, Fr, 64, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=seed + 2))
+        vol = torch.rand(B, Fr, 1, generator=g) * 0.1
+        draw = torch.rand(B, Fr * hop, generator=g) if kind == "fast" else torch.randn(B, Fr * hop, generator=g)
+        R = torch.randn(B, Fr * hop, generator=g)
+        cap = {}
+
+        def hook(mod, i, o):
+            for v in o[0].values():
+                v.retain_grad()
+            cap.update(ctrls=o[0])
+        hk = model.unit2ctrl.register_forward_hook(hook)
+        name = "torch.rand_like" if kind == "fast" else "torch.randn_like"
+        with mock.patch(name, side_effect=lambda t: draw.to(t)):
+            signal, _, _ = model(units, f0f, vol, infer=True)
+        hk.remove()
+        (signal * R).sum().backward()
+        out = dict(f0_frames=f0f.numpy(), noise=(draw * 2 - 1 if kind == "fast" else draw).numpy(), cotangent=R.numpy(),
+                   signal=signal.detach().numpy(), window=model.window.numpy())
+        for k, v in cap["ctrls"].items():
+            out["ctrl_" + k] = v.detach().numpy()
+            out["grad_" + k] = v.grad.numpy()
+        return out
+
+    np.savez(os.path.join(HERE, "cssuper_grad.npz"), **run_grad("super", 2, 9, 51))
+    np.savez(os.path.join(HERE, "csfast_grad.npz"), **run_grad("fast", 2, 8, 52))
+
     # ---- log-mel front-end ---------------------------------------------------
     import nsf_hifigan.nvSTFT as nv
     basis = O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)

@@ -1,0 +1,160 @@
+"""Gradient of the short-time spectral tail w.r.t. its controls (first part: CombSubFast /
+CombSubSuperFast, the models the shipped configs and the cascades train): oracle pinning against the reference's own
+autograd (fixtures *_grad.npz), parity of the HIP backward kernel, and the autograd wiring of the drop-in modules.
+
+Tolerance: gradients <= 5e-6 relative RMS per control stream (float32 path vs float64 oracle; the oracle sits 2e-7
+from the reference's autograd)."""
+import os
+import sys
+from unittest import mock
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddsp_oracle as O
+from tests.backends import BACKENDS, dev  # noqa: F401
+
+SR, HOP = 44100, 512
+KEYS = ("harmonic_magnitude", "harmonic_phase", "noise_magnitude", "noise_phase")
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+def T_(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def hann(win):
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)).astype(np.float32)
+
+
+def test_oracle_backward_against_reference_autograd(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cssuper_grad.npz"))
+    comb, _, _ = O.fast_source_gen(g["f0_frames"], SR, HOP)
+    got = O.stft_filter_backward(g["cotangent"], comb, g["noise"], *[g["ctrl_" + k] for k in KEYS], g["window"])
+    for a, k in zip(got, KEYS):
+        assert rms(a - g["grad_" + k]) <= 1e-6 * rms(g["grad_" + k]), k
+    g = np.load(os.path.join(golden_dir, "csfast_grad.npz"))
+    x, _ = O.wrapped_phase(g["f0_frames"], SR, HOP)
+    comb = O.combtooth(x, g["f0_frames"], SR, HOP)
+    got = O.stft_filter_backward(g["cotangent"], comb, g["noise"], *[g["ctrl_" + k] for k in KEYS[:3]], None,
+                                 g["window"], HOP, "constant", False)
+    for a, k in zip(got[:3], KEYS[:3]):
+        assert rms(a - g["grad_" + k]) <= 1e-6 * rms(g["grad_" + k]), k
+    assert got[3] is None
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("win,B,F,reflect,normalize,nphase,run", [
+    (2048, 2, 9, True, True, True, 1000),       # odd frame count: frame F shares the last pair's transform
+    (2048, 1, 8, True, True, True, 2),          # even: frame F gets a transform of its own; several runs
+    (2048, 1, 3, True, True, True, 1),
+    (2048, 1, 2, False, True, True, 1000),      # zero padding (T <= win/2)
+    (2048, 1, 1, False, True, True, 1000),
+    (1024, 2, 8, False, False, False, 3),       # CombSubFast geometry
+    (1024, 1, 5, False, False, False, 1000),
+    (1024, 1, 1, False, False, False, 1000),
+])
+def test_stft_filter_backward(dev, win, B, F, reflect, normalize, nphase, run, monkeypatch):
+    from ddsp_svc_amd import synth
+    monkeypatch.setenv("DDSP_HIP_STFT_RUN", str(run))
+    rng = np.random.default_rng(win + 10 * F + B)
+    n, T = win // 2 + 1, F * HOP
+    exc = rng.standard_normal((B, T)).astype(np.float32)
+    nz = rng.standard_normal((B, T)).astype(np.float32)
+    hm, hp, nm, nph = [(s * rng.standard_normal((B, F, n))).astype(np.float32) for s in (1.0, 1.5, 1.0, 1.5)]
+    R = rng.standard_normal((B, T)).astype(np.float32)
+    w = hann(win) if normalize else np.sqrt(hann(win)).astype(np.float32)
+    got = synth.stft_filter_backward(T_(R, dev), T_(exc, dev), T_(nz, dev), T_(hm, dev), T_(hp, dev), T_(nm, dev),
+                                     T_(nph, dev) if nphase else None, T_(w, dev), HOP, pad_reflect=reflect,
+                                     normalize=normalize)
+    ref = O.stft_filter_backward(R, exc, nz, hm, hp, nm, nph if nphase else None, w, HOP,
+                                 "reflect" if reflect else "constant", normalize)
+    for a, b, k in zip(got, ref, KEYS):
+        if b is None:
+            assert a is None
+            continue
+        assert rms(a.cpu().numpy() - b) <= 5e-6 * rms(b), (k, rms(a.cpu().numpy() - b), rms(b))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("kind", ["super", "fast"])
+def test_backward_golden_and_autograd(dev, golden_dir, kind):
+    """autograd through the functional tails reproduces the reference's control gradients; strided split views"""
+    from ddsp_svc_amd import synth
+    g = np.load(os.path.join(golden_dir, "cssuper_grad.npz" if kind == "super" else "csfast_grad.npz"))
+    keys = KEYS if kind == "super" else KEYS[:3]
+    f0 = T_(g["f0_frames"], dev)
+    packed = T_(np.concatenate([g["ctrl_" + k] for k in keys], axis=-1), dev).requires_grad_(True)
+    views = torch.split(packed, [g["ctrl_" + keys[0]].shape[-1]] * len(keys), dim=-1)
+    if kind == "super":
+        st = synth.fast_source(f0, SR, HOP)
+        sig = synth.combsubsuperfast_synth(f0, st, *views, T_(g["noise"], dev), T_(g["window"], dev), SR, HOP)
+    else:
+        st = synth.phase(f0, SR, HOP)
+        sig = synth.combsubfast_synth(f0, st, *views, T_(g["noise"], dev), T_(g["window"], dev), SR, HOP)
+    assert sig.requires_grad
+    assert rms(sig.detach().cpu().numpy() - g["signal"]) <= 1e-5 * rms(g["signal"])
+    (sig * T_(g["cotangent"], dev)).sum().backward()
+    grads = torch.split(packed.grad, [g["ctrl_" + keys[0]].shape[-1]] * len(keys), dim=-1)
+    for a, k in zip(grads, keys):
+        ref = g["grad_" + k]
+        assert rms(a.cpu().numpy() - ref) <= 5e-6 * rms(ref), (k, rms(a.cpu().numpy() - ref), rms(ref))
+
+
+@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("kind", ["fast", "superfast"])
+def test_module_training_step_matches_reference(dev, kind):
+    """one backward pass through the drop-in module (reference Unit2Control inside): the parameter gradients equal the
+    reference module's (same weights, inputs, noise, cotangent)"""
+    ref_root = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "ddsp")):
+        pytest.skip("reference checkout not present (only in the build container)")
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    for name in ["transformers", "pyworld", "parselmouth", "torchcrepe", "resampy", "fairseq", "torchaudio",
+                 "torchaudio.transforms", "gin", "local_attention", "librosa", "librosa.sequence", "librosa.util",
+                 "librosa.filters", "librosa.core", "soundfile"]:
+        sys.modules.setdefault(name, MagicMock())
+    import ddsp.vocoder as rvoc
+    from ddsp_svc_amd import vocoder as V
+    name = {"fast": "CombSubFast", "superfast": "CombSubSuperFast"}[kind]
+    ref_cls = getattr(rvoc, "_reference_" + name, getattr(rvoc, name))
+    torch.manual_seed(3)
+    B, F, n_unit = 2, 6, 16
+    args = (SR, HOP) if kind == "fast" else (SR, HOP, 2048)
+    ref = ref_cls(*args, n_unit=n_unit, n_spk=1).train()
+    ours = getattr(V, name)(*args, n_unit=n_unit, n_spk=1).train()
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    for m in (ref, ours):                                       # dropout off, everything else in training mode
+        for sub in m.modules():
+            if isinstance(sub, torch.nn.Dropout):
+                sub.p = 0.0
+    g = torch.Generator().manual_seed(4)
+    units = torch.randn(B, F, n_unit, generator=g)
+    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=9))
+    vol = torch.rand(B, F, 1, generator=g) * 0.1
+    u = torch.rand(B, F * HOP, generator=g)
+    gz = torch.randn(B, F * HOP, generator=g)
+    R = torch.randn(B, F * HOP, generator=g)
+    with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)), \
+            mock.patch("torch.randn_like", side_effect=lambda t: gz.reshape(t.shape)):
+        r_sig, _, _ = ref(units, f0, vol, infer=True)
+    with mock.patch("torch.rand", side_effect=lambda *a, **k: u), mock.patch("torch.randn", side_effect=lambda *a, **k: gz):
+        o_sig, _, _ = ours(units, f0, vol, infer=True)
+    (r_sig * R).sum().backward()
+    (o_sig * R).sum().backward()
+    checked = 0
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert n1 == n2
+        if p1.grad is None:
+            assert p2.grad is None
+            continue
+        scale = max(rms(p1.grad.numpy()), 1e-12)
+        assert rms((p2.grad - p1.grad).numpy()) <= 2e-5 * scale + 1e-9, (n1, rms((p2.grad - p1.grad).numpy()), scale)
+        checked += 1
+    assert checked > 10
