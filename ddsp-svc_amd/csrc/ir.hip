@@ -233,14 +233,22 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
       av[rb][0] = lo.x; av[rb][1] = lo.y; av[rb][2] = lo.z; av[rb][3] = lo.w;
       av[rb][4] = hi.x; av[rb][5] = hi.y; av[rb][6] = hi.z; av[rb][7] = hi.w;
     }
+    // all B operands of the chunk are read before the first MFMA (16 registers): with one read per step the
+    // compiler re-uses two registers and every group of four MFMAs waits for its LDS read
     const float* bp = Bs + (8 * h) * LDB + wc * 64 + li;
+    float bv[8][2];
 #pragma unroll
     for (int sidx = 0; sidx < 8; ++sidx) {
-      const float b0 = bp[sidx * LDB], b1 = bp[sidx * LDB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b1, acc[1][1], 0, 0, 0);
+      bv[sidx][0] = bp[sidx * LDB];
+      bv[sidx][1] = bp[sidx * LDB + 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);                // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], bv[sidx][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], bv[sidx][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], bv[sidx][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], bv[sidx][1], acc[1][1], 0, 0, 0);
     }
   };
 
