@@ -39,11 +39,20 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_max - 1);
   w.buf0 = c.take<float>(BT);
   w.buf1 = c.take<float>(BT);
-  w.harm = c.take<float>(BT);
   w.taps = c.take<float>(R * N);
-  w.re = c.take<float>(R * n_max);
-  w.im = c.take<float>(R * n_max);
   w.hw = c.take<float>(R);
+  // The all-pass response (re, im) is dead once its taps are synthesised, before the exciter is written: when it
+  // fits (2 n <= hop) it lives in buf0, and the harmonic signal re-uses buf0 after the first filter has consumed
+  // the exciter -- the step then cycles through three [B,T]-sized buffers instead of six (less of it falls out of
+  // the 256 MB MALL between kernels).
+  if (2 * R * n_max <= BT) {
+    w.re = w.buf0;
+    w.im = w.buf0 + R * n_max;
+  } else {
+    w.re = c.take<float>(R * n_max);
+    w.im = c.take<float>(R * n_max);
+  }
+  w.harm = w.buf0;
   return align_up(c.used, 256);
 }
 
@@ -175,15 +184,16 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
-  float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
+  // all-pass taps first (their response lives in buf0 until the exciter overwrites it)
+  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
+  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                 w.taps, st);
   // exciter: sinusoid bank (vocoder.py:585-594)
   int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
   if (r == -1) return DDSP_HIP_EHOP;
   if (r == -2) return DDSP_HIP_ESHAPE;
   // harmonic = all-pass(group delay) applied to the sinusoids (vocoder.py:597-600)
-  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
-  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                 w.taps, st);
+  float* harmonic = harmonic_or_null ? harmonic_or_null : w.buf1;
   if (launch_fir(w.buf0, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise, added to harmonic (vocoder.py:603-609)
@@ -215,12 +225,12 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   hipStream_t st = S(stream);
   const long R = (long)B * F;
   float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
-  // exciter: combtooth (vocoder.py:839-840)
-  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st) != 0) return DDSP_HIP_EHOP;
-  // all-pass (vocoder.py:843-846)
+  // all-pass taps first (vocoder.py:843-846; their response lives in buf0 until the exciter overwrites it)
   launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
   launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
                  w.taps, st);
+  // exciter: combtooth (vocoder.py:839-840)
+  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st) != 0) return DDSP_HIP_EHOP;
   if (launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851)
