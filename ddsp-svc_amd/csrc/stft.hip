@@ -201,17 +201,25 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
       const long rb = (long)b * g.F + row;
       // raw controls of the bins this thread evaluates: k = P m + tid for m < 4, plus the Nyquist bin on thread 0
       // (the upper half of the spectrum is the conjugate mirror, handed over through LDS below)
+      // (loads are unconditional, from clamped addresses, and masked where they are used: a load feeding a select
+      // right away is waited for on the spot instead of staying in flight across the transform)
       constexpr int NB = S / 2 + 1;
       float hm[NB], hp[NB], nm[NB], np_[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) {
-        hm[m] = hp[m] = nm[m] = np_[m] = 0.f;
-        if (live && (m < NB - 1 || tid == 0)) {
-          const int k = P * m + tid;
-          hm[m] = c_hmag[rb * g.ld_hm + k];
-          hp[m] = c_hphase[rb * g.ld_hp + k];
-          nm[m] = c_nmag[rb * g.ld_nm + k];
-          if (c_nphase) np_[m] = c_nphase[rb * g.ld_np + k];
+        int k = P * m + tid;
+        k = k > N / 2 ? N / 2 : k;                             // m = NB - 1 is the Nyquist bin, used by thread 0 only
+        hm[m] = c_hmag[rb * g.ld_hm + k];
+        hp[m] = c_hphase[rb * g.ld_hp + k];
+        nm[m] = c_nmag[rb * g.ld_nm + k];
+        np_[m] = 0.f;
+      }
+      if (c_nphase) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          int k = P * m + tid;
+          k = k > N / 2 ? N / 2 : k;
+          np_[m] = c_nphase[rb * g.ld_np + k];
         }
       }
       // windowed input frame: exciter in the real, noise in the imaginary part
@@ -228,6 +236,7 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
           z[m] = f32x2{w[m] * e, w[m] * u};
         }
       } else {
+        float ev[S], uv[S];
 #pragma unroll
         for (int m = 0; m < S; ++m) {
           int i = s0 + P * m + tid;
@@ -235,13 +244,17 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
             if (i < 0) i = -i;
             if (i >= g.T) i = 2 * (g.T - 1) - i;
           }
-          float e = 0.f, u = 0.f;
-          if (live && i >= 0 && i < g.T) {
-            e = eb[i];
-            u = nb[i];
-            if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
-          }
-          z[m] = f32x2{w[m] * e, w[m] * u};
+          i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
+          ev[m] = eb[i];
+          uv[m] = nb[i];
+        }
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+          const int i = s0 + P * m + tid;
+          const bool ok = live && (g.reflect || (i >= 0 && i < g.T));
+          float u = uv[m];
+          if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+          z[m] = f32x2{ok ? w[m] * ev[m] : 0.f, ok ? w[m] * u : 0.f};
         }
       }
       f32x2* A = ex[cur];
@@ -390,8 +403,8 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
   // windowed cotangent of frame jj at slot m: w * grad / env, zero outside the cropped range
   auto gamma = [&](int jj, int m) -> float {
     const int t = jj * ST_HOP - PAD + P * m + tid;
-    if (jj > g.F || t < 0 || t >= g.T) return 0.f;
-    float v = gb[t];
+    const bool ok = jj <= g.F && t >= 0 && t < g.T;
+    float v = gb[t < 0 ? 0 : (t >= g.T ? g.T - 1 : t)];
     if (g.normalize) {
       float env = 0.f;
 #pragma unroll
@@ -400,9 +413,9 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
         const float wq = w[(m % EMIT) + q * EMIT];
         if (jf >= 0 && jf <= g.F) env = fmaf(wq, wq, env);
       }
-      v = v / env;
+      v = v / (ok ? env : 1.0f);
     }
-    return w[m] * v;
+    return ok ? w[m] * v : 0.f;
   };
   // Gs = c_k / (4 N) * 2 Gamma for the thread's bins of frames ja (real part of the packed transform) and ja + 1
   auto cotangent_pair = [&](int ja, f32x2 (&G0)[NB], f32x2 (&G1)[NB]) {
@@ -428,32 +441,45 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
     const long rb = (long)b * g.F + row;
     float hm[NB], hp[NB], nm[NB], np_[NB];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) {
-      hm[m] = hp[m] = nm[m] = np_[m] = 0.f;
-      if (m < NB - 1 || tid == 0) {
-        const int k = P * m + tid;
-        hm[m] = c_hmag[rb * g.ld_hm + k];
-        hp[m] = c_hphase[rb * g.ld_hp + k];
-        nm[m] = c_nmag[rb * g.ld_nm + k];
-        if (c_nphase) np_[m] = c_nphase[rb * g.ld_np + k];
+    for (int m = 0; m < NB; ++m) {                             // unconditional, clamped; masked at use (see the forward kernel)
+      int k = P * m + tid;
+      k = k > N / 2 ? N / 2 : k;
+      hm[m] = c_hmag[rb * g.ld_hm + k];
+      hp[m] = c_hphase[rb * g.ld_hp + k];
+      nm[m] = c_nmag[rb * g.ld_nm + k];
+      np_[m] = 0.f;
+    }
+    if (c_nphase) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        int k = P * m + tid;
+        k = k > N / 2 ? N / 2 : k;
+        np_[m] = c_nphase[rb * g.ld_np + k];
       }
     }
     f32x2 z[S];
     const int s0 = jj * ST_HOP - PAD;
+    {
+      float ev[S], uv[S];
 #pragma unroll
-    for (int m = 0; m < S; ++m) {
-      int i = s0 + P * m + tid;
-      if (g.reflect) {
-        if (i < 0) i = -i;
-        if (i >= g.T) i = 2 * (g.T - 1) - i;
+      for (int m = 0; m < S; ++m) {
+        int i = s0 + P * m + tid;
+        if (g.reflect) {
+          if (i < 0) i = -i;
+          if (i >= g.T) i = 2 * (g.T - 1) - i;
+        }
+        i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
+        ev[m] = eb[i];
+        uv[m] = nb[i];
       }
-      float e = 0.f, u = 0.f;
-      if (i >= 0 && i < g.T) {
-        e = eb[i];
-        u = nb[i];
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        const int i = s0 + P * m + tid;
+        const bool ok = g.reflect || (i >= 0 && i < g.T);
+        float u = uv[m];
         if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+        z[m] = f32x2{ok ? w[m] * ev[m] : 0.f, ok ? w[m] * u : 0.f};
       }
-      z[m] = f32x2{w[m] * e, w[m] * u};
     }
     transform(z);
 #pragma unroll
@@ -541,10 +567,11 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
   g.pairs = (F + 2) / 2;
   g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
   g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
-  // waves per SIMD the kernel variant is compiled for (register budget = 512 / wps): the natural register demand
-  // (~190) spills heavily at 128, so 3 (168 VGPRs, three 256-thread workgroups per CU) for win 2048 and 2 (four
-  // 128-thread workgroups per CU) for win 1024 -- measured in profiles/r01_v5_stft_variants.json
-  int wps = win == 2048 ? 3 : 2;
+  // waves per SIMD the kernel variant is compiled for (register budget = 512 / wps): the natural register demand is
+  // ~190, and a spilled control value has to be waited for the moment it is loaded instead of staying in flight
+  // across the transform, so 2 waves per SIMD for both sizes (win 2048: 0.30 ms against 0.39 ms at 168 VGPRs with
+  // 16 spills, 0.61 ms at 128; profiles/r01_v5_stft_variants.json)
+  int wps = 2;
   if (const char* e = getenv("DDSP_HIP_STFT_WPS")) { int v = atoi(e); if (v >= 1) wps = v; }
   const int wg_per_cu = wps * 4 / (win == 2048 ? 4 : 2);
   const int warm = win == 2048 ? 2 : 1;
@@ -587,7 +614,7 @@ int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u0
   g.pairs = (F + 1) / 2;                                       // frames 0..F-1; frame F rides with the last pair
   g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
   g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
-  const int wg_per_cu = win == 2048 ? 3 : 4;
+  const int wg_per_cu = win == 2048 ? 3 : 4;                   // win 2048: 3 waves per SIMD measured faster (0.39 ms) than 2 (0.45 ms)
   const long slots = (long)wg_per_cu * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
