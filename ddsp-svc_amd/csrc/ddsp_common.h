@@ -32,6 +32,26 @@ struct Upsampler {
     i0 = k < F - 1 ? k : F - 1;
     i1 = k1 < F - 1 ? k1 : F - 1;
   }
+  // The same for the samples of ONE frame f of a stride-1 row: the three rows a sample of that frame can touch
+  // (f-1 only through a rounding of scale*t at a frame boundary) are fetched once per frame and selected by index,
+  // instead of two dependent loads per sample.
+  struct Row3 { float a, b, c; int f; };
+  __device__ __forceinline__ Row3 load3(const float* __restrict__ row, int f) const {
+    Row3 r;
+    r.f = f;
+    r.a = row[f > 0 ? f - 1 : 0];
+    r.b = row[f];
+    r.c = row[f + 1 < F ? f + 1 : F - 1];
+    return r;
+  }
+  __device__ __forceinline__ float at3(const Row3& r, long t) const {
+    int i0, i1;
+    float l0, l1;
+    locate(t, i0, i1, l0, l1);
+    const float a = i0 < r.f ? r.a : (i0 == r.f ? r.b : r.c);
+    const float b = i1 < r.f ? r.a : (i1 == r.f ? r.b : r.c);
+    return fmaf(l0, a, l1 * b);
+  }
   __device__ __forceinline__ float at(const float* __restrict__ row, long stride, long t) const {
     int i0, i1;
     float l0, l1;

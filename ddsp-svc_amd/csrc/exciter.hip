@@ -23,12 +23,13 @@ __device__ __forceinline__ void frame_phase(const float* __restrict__ f0_row, in
                                             FramePhase<SPL>& o) {
   double pre[SPL];
   double acc = 0.0;
+  const Upsampler::Row3 rows = up.load3(f0_row, f);
 #pragma unroll
   for (int r = 0; r < SPL; ++r) {
     int j = lane * SPL + r;
     float v = 0.f;
     if (j < hop) {
-      v = up.at(f0_row, 1, (long)f * hop + j);
+      v = up.at3(rows, (long)f * hop + j);
       acc += cfg.term(v);
     }
     o.f0u[r] = v;

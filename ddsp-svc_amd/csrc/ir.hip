@@ -61,47 +61,52 @@ __global__ void __launch_bounds__(256) k_ir_table(int n, float* __restrict__ tab
 // (cos theta, sin theta).  One wave per frame; float64 scan, reduced mod 2pi before the float sincos.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_allpass_response(const float* __restrict__ c, long ld, long rows, int n,
-                                                          float* __restrict__ re, float* __restrict__ im) {
+                                                          float* __restrict__ re, float* __restrict__ im, int vec4) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + wave;
   if (r >= rows) return;
   const float* cr = c + r * ld;
-  const int per = (n + 63) / 64;
-  const int k0 = lane * per;
-  constexpr int PER_MAX = 8;                                    // bins per lane kept in registers (n <= 512)
-  float gd[PER_MAX];
-  double local = 0.0;
-  if (per <= PER_MAX) {
-#pragma unroll
-    for (int q = 0; q < PER_MAX; ++q) {
-      const int k = k0 + q;
-      gd[q] = (q < per && k < n) ? kPiF * tanhf(cr[k]) : 0.f;   // vocoder.py:581 / :834
-      local += (double)gd[q];
-    }
-  } else {
-    for (int q = 0; q < per; ++q) {
-      const int k = k0 + q;
-      if (k < n) local += (double)(kPiF * tanhf(cr[k]));
-    }
-  }
-  double run = wave_excl_scan(local, lane);
   const double inv_2pi = 0.15915494309189533577;
   // exp(1j * theta): theta reduced to revolutions in float64, then the hardware sine / cosine (abs error <= 4e-7
   // on a unit-magnitude response)
-  auto put = [&](int k, float g) {
-    run += (double)g;
+  auto cis = [&](double run, float& co, float& si) {
     const double rev = run * inv_2pi;
     const float fr = (float)(rev - rint(rev));
-    re[r * n + k] = __builtin_amdgcn_cosf(fr);
-    im[r * n + k] = __builtin_amdgcn_sinf(fr);
+    co = __builtin_amdgcn_cosf(fr);
+    si = __builtin_amdgcn_sinf(fr);
   };
-  if (per <= PER_MAX) {
-#pragma unroll
-    for (int q = 0; q < PER_MAX; ++q)
-      if (q < per && k0 + q < n) put(k0 + q, gd[q]);
-  } else {
-    for (int q = 0; q < per; ++q)
-      if (k0 + q < n) put(k0 + q, kPiF * tanhf(cr[k0 + q]));
+  if (vec4) {
+    // n == 256 with 16-byte aligned rows: a lane owns 4 consecutive bins -- one 16-byte load, two 16-byte stores
+    const float4 cv = *reinterpret_cast<const float4*>(cr + 4 * lane);
+    const float g0 = kPiF * tanhf(cv.x), g1 = kPiF * tanhf(cv.y), g2 = kPiF * tanhf(cv.z), g3 = kPiF * tanhf(cv.w);
+    const double local = (((double)g0 + (double)g1) + (double)g2) + (double)g3;   // same order as the scalar path
+    double run = wave_excl_scan(local, lane);
+    float4 co, si;
+    run += (double)g0; cis(run, co.x, si.x);
+    run += (double)g1; cis(run, co.y, si.y);
+    run += (double)g2; cis(run, co.z, si.z);
+    run += (double)g3; cis(run, co.w, si.w);
+    *reinterpret_cast<float4*>(re + r * n + 4 * lane) = co;
+    *reinterpret_cast<float4*>(im + r * n + 4 * lane) = si;
+    return;
+  }
+  const int per = (n + 63) / 64;
+  const int k0 = lane * per;
+  double local = 0.0;
+  for (int q = 0; q < per; ++q) {
+    const int k = k0 + q;
+    if (k < n) local += (double)(kPiF * tanhf(cr[k]));          // vocoder.py:581 / :834
+  }
+  double run = wave_excl_scan(local, lane);
+  for (int q = 0; q < per; ++q) {
+    const int k = k0 + q;
+    if (k < n) {
+      run += (double)(kPiF * tanhf(cr[k]));
+      float co, si;
+      cis(run, co, si);
+      re[r * n + k] = co;
+      im[r * n + k] = si;
+    }
   }
 }
 
@@ -351,7 +356,9 @@ void launch_ir_table(int n, float* table, hipStream_t st) {
 
 void launch_allpass_response(const float* c, long ld, long rows, int n, float* re, float* im, hipStream_t st) {
   if (rows == 0) return;
-  hipLaunchKernelGGL(k_allpass_response, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, c, ld, rows, n, re, im);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec4 = (n == 256 && (ld & 3) == 0 && al16(c) && al16(re) && al16(im)) ? 1 : 0;
+  hipLaunchKernelGGL(k_allpass_response, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, c, ld, rows, n, re, im, vec4);
 }
 
 void launch_half_width(const float* f0_frames, long rows, float sr, float* hw, hipStream_t st) {

@@ -56,11 +56,12 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
   long b = fr / F;
   int f = (int)(fr % F);
   const float* row = f0_frames + b * F;
+  const Upsampler::Row3 rows = up.load3(row, f);
   double acc = 0.0;
 #pragma unroll
   for (int r = 0; r < SPL; ++r) {
     int j = lane * SPL + r;
-    if (j < hop) acc += cfg.term(up.at(row, 1, (long)f * hop + j));
+    if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
   }
   acc = wave_sum(acc);
   if (lane == 0) sums[fr] = acc;
@@ -122,10 +123,11 @@ __global__ void __launch_bounds__(256) k_phase_expand(const float* __restrict__ 
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   double pre[SPL];
   double acc = 0.0;
+  const Upsampler::Row3 rows = up.load3(row, f);
 #pragma unroll
   for (int r = 0; r < SPL; ++r) {
     int j = lane * SPL + r;
-    if (j < hop) acc += cfg.term(up.at(row, 1, (long)f * hop + j));
+    if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
     pre[r] = acc;
   }
   double base = phase0[fr] + wave_excl_scan(acc, lane);
