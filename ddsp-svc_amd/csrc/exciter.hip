@@ -7,6 +7,7 @@
 // amplitude rows it interpolates between in LDS and never materialises the reference's
 // [B,T,32] temporaries.
 #include "ddsp_common.h"
+#include <stdlib.h>
 
 namespace ddsp {
 
@@ -153,6 +154,130 @@ __global__ void __launch_bounds__(256) k_sins_bank(const float* __restrict__ f0_
   store_frame<SPL>(out + fr * (long)hop, hop, lane, acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// sinusoid bank, block angle-addition form (hop = 512): one 256-thread workgroup per frame, two consecutive
+// samples per thread.  Per sample the harmonics are generated 16 at a time from
+//     sin((16 b + j) theta) = sin(16 b theta) cos(j theta) + cos(16 b theta) sin(j theta),   j = 1..16,
+// with the table cis(j theta) built once per sample (15 rotations from an accurately evaluated cis(theta)) and the
+// block seeds cis(16 b theta) evaluated accurately for every fourth block (exact float32 product split + hardware
+// sine/cosine) and rotated in between.  A harmonic then costs two packed multiply-adds for the sine and two for the
+// two amplitude rows (both samples at once) instead of a range reduction and a hardware sine per sample.
+//
+// Numerics: the reference evaluates sin(fl32(k * phase)) -- the float32 rounding of k*phase (up to 3e-5 rad at
+// k = 256) is part of its result.  This form evaluates sin(k * phase) for the float32 phase without that rounding;
+// on the reference-generated fixtures the two differ by 3.5e-6 (H = 256) / 7e-7 (H = 128) relative RMS of the
+// exciter, inside the 1e-5 the tails are held to.  Rotation errors stay below 1e-6 (<= 15 steps for the table,
+// <= 3 for the seeds).
+// ------------------------------------------------------------------------------------------------
+// (cos, sin) of angle a (radians, |a| up to ~1e3) evaluated for the float32 product k * theta WITHOUT rounding it:
+// p_hi = fl32(k theta), p_lo = k theta - p_hi (exact, fma); revolutions = p_hi / 2pi (two-constant) + p_lo / 2pi
+__device__ __forceinline__ void cis_product(float k, float theta, float& co, float& si) {
+  const float inv_hi = 0.15915494f, inv_lo = 6.4206383e-9f;
+  const float p_hi = k * theta;
+  const float p_lo = fmaf(k, theta, -p_hi);
+  const float n = rintf(p_hi * inv_hi);
+  float r = fmaf(p_hi, inv_hi, -n);
+  r = fmaf(p_hi, inv_lo, r);
+  r = fmaf(p_lo, inv_hi, r);
+  co = __builtin_amdgcn_cosf(r);
+  si = __builtin_amdgcn_sinf(r);
+}
+
+__global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0_frames,
+                                                    const float* __restrict__ initial_phase,
+                                                    const float* __restrict__ c_amp, long ld_amp, int F, int H,
+                                                    Upsampler up, PhaseCfg cfg, const double* __restrict__ phase0,
+                                                    float* __restrict__ out) {
+  constexpr int HOP = 512;
+  HIP_DYNAMIC_SHARED(float, amp)                    // [HP][2]: (A[f][k], A[f+1][k]) for k < H, zero up to HP
+  __shared__ double wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long fr = blockIdx.x;
+  const long b = fr / F;
+  const int f = (int)(fr - b * F);
+  const int HP = (H + 15) & ~15;
+  const float* f0_row = f0_frames + b * F;
+  const float nyq = cfg.sr_f / 2.0f;
+  const int f1 = f + 1 < F ? f + 1 : F - 1;           // last frame held (core.py:68)
+  for (int i = tid; i < 2 * HP; i += 256) {
+    const int k = i >> 1, side = i & 1;
+    float v = 0.f;
+    if (k < H) {
+      const int ff = side ? f1 : f;
+      const float a = expf(c_amp[(b * F + ff) * ld_amp + k]) / 128.0f;      // vocoder.py:580
+      const float p = f0_row[ff] * (float)(k + 1);
+      v = a * ((p < nyq ? 1.0f : 0.0f) + 1e-7f);                          // core.py:75-76
+    }
+    amp[i] = v;
+  }
+  // wrapped phase of this thread's two samples (vocoder.py:564-572): float64 terms, block-wide exclusive scan
+  const Upsampler::Row3 rows = up.load3(f0_row, f);
+  const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
+  const long t0 = (long)f * HOP + 2 * tid;
+  const double q0 = cfg.term(up.at3(rows, t0));
+  const double q1 = cfg.term(up.at3(rows, t0 + 1));
+  const double mine = q0 + q1;
+  const double excl = wave_excl_scan(mine, lane);
+  if (lane == 63) wsum[wave] = excl + mine;
+  __syncthreads();                                  // also publishes amp[]
+  double base = phase0[fr] + excl;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const float xa = cfg.wrap(base + q0, ip), xb = cfg.wrap(base + q0 + q1, ip);
+  const f32x2 theta = {kTwoPiF * xa, kTwoPiF * xb};                       // vocoder.py:574
+  // table cis(j theta), j = 1..16, as (cos_A, cos_B) / (sin_A, sin_B) pairs
+  f32x2 tc[16], ts[16];
+  {
+    float c0, s0, c1, s1;
+    cis_product(1.0f, theta.x, c0, s0);
+    cis_product(1.0f, theta.y, c1, s1);
+    tc[0] = f32x2{c0, c1};
+    ts[0] = f32x2{s0, s1};
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      tc[j] = __builtin_elementwise_fma(tc[j - 1], tc[0], -(ts[j - 1] * ts[0]));
+      ts[j] = __builtin_elementwise_fma(ts[j - 1], tc[0], tc[j - 1] * ts[0]);
+    }
+  }
+  f32x2 S0 = {0.f, 0.f}, S1 = {0.f, 0.f};            // sum_k sin(k theta) A[f][k] and ... A[f+1][k], per sample
+  f32x2 Cb = {1.f, 1.f}, Sb = {0.f, 0.f};            // cis(16 b theta)
+  const int nblk = HP >> 4;
+  for (int blk = 0; blk < nblk; ++blk) {
+    if (blk > 0) {
+      if ((blk & 3) == 0) {                         // accurate re-seed
+        float c0, s0, c1, s1;
+        cis_product((float)(16 * blk), theta.x, c0, s0);
+        cis_product((float)(16 * blk), theta.y, c1, s1);
+        Cb = f32x2{c0, c1};
+        Sb = f32x2{s0, s1};
+      } else {                                      // rotate by cis(16 theta)
+        const f32x2 cn = __builtin_elementwise_fma(Cb, tc[15], -(Sb * ts[15]));
+        Sb = __builtin_elementwise_fma(Sb, tc[15], Cb * ts[15]);
+        Cb = cn;
+      }
+    }
+    const float* ap = amp + 32 * blk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a0 = ap[2 * j], a1 = ap[2 * j + 1];
+      const f32x2 sv = __builtin_elementwise_fma(Cb, ts[j], Sb * tc[j]);  // sin((16 blk + j + 1) theta), both samples
+      S0 = __builtin_elementwise_fma(sv, f32x2{a0, a0}, S0);
+      S1 = __builtin_elementwise_fma(sv, f32x2{a1, a1}, S1);
+    }
+  }
+  // upsample(A)[t] = w0 A[f] + w1 A[f+1] (core.py:66-70) applied to the two partial sums
+  float r[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int i0, i1;
+    float w0, w1;
+    up.locate(t0 + q, i0, i1, w0, w1);
+    r[q] = fmaf(w0, S0[q], w1 * S1[q]);
+  }
+  float* dst = out + b * (long)F * HOP + t0;
+  if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
+  else { dst[0] = r[0]; dst[1] = r[1]; }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 Upsampler make_upsampler_pub(int F, int hop);
 PhaseCfg make_phase_cfg(double sr, int infer, int has_ip);
@@ -184,6 +309,13 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
   if ((long)B * F == 0) return 0;
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
+  if (hop == 512 && (long)B * F <= 0x7fffffffL && !getenv("DDSP_HIP_SINS_V1")) {
+    // block angle-addition form: one workgroup per frame
+    const size_t sh2 = (size_t)2 * ((H + 15) & ~15) * sizeof(float);
+    hipLaunchKernelGGL(k_sins_bank2, dim3((unsigned)((long)B * F)), dim3(256), sh2, st, f0_frames, initial_phase, c_amp,
+                       ld_amp, F, H, up, cfg, phase0, out);
+    return 0;
+  }
   const int groups = (F + 3) / 4;
   dim3 grid((unsigned)((long)B * groups)), block(256);
   size_t sh = (size_t)5 * H * sizeof(float);

