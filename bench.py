@@ -127,6 +127,59 @@ def _cpu_mel_worker(args):
     return float(O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)).max())
 
 
+def bench_sinesrc(a, rank, world, device):
+    """harmonic source of NSF-HiFiGAN (SURVEY.md 8-f #4): SineGen + merge for B x 10 s, 9 harmonics, noise resident"""
+    import torch.distributed as dist
+    from ddsp_svc_amd import nsf_source as S
+    from oracle import ddsp_oracle as O
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1
+    T = F * HOP
+    g = torch.Generator(device="cpu").manual_seed(777 + rank)
+    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=55 + rank)[..., 0]).to(device)
+    w = (torch.randn(9, generator=g) * 0.3).to(device)
+    b = torch.zeros(1, device=device)
+    ri = torch.rand(9, generator=g).to(device)
+    ri[0] = 0
+    noise = torch.randn(B, T, 9, device=device)
+
+    def step():
+        return S.sine_source(f0, HOP, SR, w, b, ri, noise)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+    if rank != 0:
+        return
+    alg = 40.0 * B * T                                            # 9 noise values in, one sample out
+    ms = elapsed / a.steps * 1e3
+    print(json.dumps({
+        "metric": "audio samples/sec, NSF-HiFiGAN harmonic source 44.1kHz upp512 9 harmonics",
+        "value": B * world * T * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SourceModuleHnNSF.forward for B=%d/GPU x %.0f s (T=%d), 9 harmonics, resident noise draw"
+                               % (B, a.seconds, T), "batch_per_gpu": B, "samples_per_utterance": T,
+                   "parallelism": "utterance-shard x%d" % world},
+        "roofline": {"kernel": "k_sinegen<9>", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_ms": ms, "launches_per_step": 1}}))
+
+
 def bench_mel(a, rank, world, device):
     """waveform -> log-mel front-end of the cascade (SURVEY.md 8-f #2): one k_mel launch over B x 10 s of audio"""
     import multiprocessing as mp
@@ -260,7 +313,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel"])
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -283,6 +336,12 @@ def main():
 
     from ddsp_svc_amd import _ffi, core, synth, sharding
 
+    if a.model == "sinesrc":
+        bench_sinesrc(a, rank, world, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.model == "mel":
         bench_mel(a, rank, world, device)
         if world > 1:

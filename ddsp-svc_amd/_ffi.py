@@ -46,6 +46,8 @@ SIGNATURES = {
     "ddsp_hip_combsubsuperfast_synth": (c_int, [P, P, P, c_long, P, c_long, P, c_long, P, c_long, P, P, c_int,
                                                 c_int, c_int, c_int, c_double, P, P, c_size_t, P]),
     "ddsp_hip_stft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ddsp_hip_sine_source": (c_int, [P, c_int, c_int, c_int, c_double, P, P, P, P, c_int, c_float, c_float, c_float,
+                                     P, P, P]),
     "ddsp_hip_mel_frames": (c_int, [c_int, c_int, c_int]),
     "ddsp_hip_mel_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_float, P,
                                          c_long, c_long, c_long, P]),

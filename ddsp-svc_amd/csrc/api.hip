@@ -365,4 +365,16 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
   return finish();
 }
 
+int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
+                         const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
+                         float voiced_threshold, float* rad_acc, float* out, void* stream) {
+  if (B < 0 || L <= 0 || upp <= 0 || dim <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0 || !rand_ini || !noise || !weight || !bias || !rad_acc || !out) return DDSP_HIP_EINVAL;
+  if (launch_sine_source(f0, B, L, upp, sr, rand_ini, noise, weight, bias, dim, sine_amp, noise_std, voiced_threshold,
+                         rad_acc, out, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 }  // extern "C"

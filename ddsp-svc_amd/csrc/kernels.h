@@ -45,4 +45,7 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
                const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
                long sm, long sf, hipStream_t st);
 int mel_frames(int T, int n_fft, int hop);
+int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
+                       const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
+                       float voiced_threshold, float* rad_acc, float* out, hipStream_t st);
 }  // namespace ddsp

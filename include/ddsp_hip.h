@@ -194,6 +194,16 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
                              int n_band_weights, int n_mels, float clip_val,
                              float* out, long stride_b, long stride_mel, long stride_frame, void* stream);
 
+/* ---- harmonic source of NSF-HiFiGAN (nsf_hifigan/models.py:101-204) ---- */
+
+/* SourceModuleHnNSF.forward(f0, upp) = tanh(Linear(SineGen(f0, upp))) with SineGen's two random draws supplied:
+ * rand_ini[dim] (initial phase per harmonic, entry 0 must be 0, models.py:150-152) and noise[B, L*upp, dim]
+ * (standard normal, models.py:168).  f0[B,L] (0 = unvoiced); weight[dim], bias[1] of the 9 -> 1 linear layer;
+ * rad_acc[B,L] scratch; out[B, L*upp].  dim = harmonic_num + 1; supported: 9 (the shipped vocoders) and 1. */
+int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini,
+                         const float* noise, const float* weight, const float* bias, int dim, float sine_amp,
+                         float noise_std, float voiced_threshold, float* rad_acc, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -571,3 +571,39 @@ def stft_filter_backward(grad_out, exciter, noise, c_hmag, c_hphase, c_nmag, c_n
     pn = np.conj(G) * U * Hn
     return (fold(ps.real), fold(-np.pi * ps.imag), fold(pn.real),
             None if c_nphase is None else fold(-np.pi * pn.imag))
+
+
+# --------------------------------------------------------------------------------------
+# 8-f #4  harmonic source of NSF-HiFiGAN                       nsf_hifigan/models.py:101-204
+# --------------------------------------------------------------------------------------
+def sine_source(f0, upp: int, sr: float, weight, bias, rand_ini, noise, sine_amp: float = 0.1,
+                noise_std: float = 0.003, voiced_threshold: float = 0.0):
+    """``SourceModuleHnNSF.forward(f0, upp)`` (models.py:198-204) = ``tanh(Linear(SineGen(f0, upp)))`` with the two
+    random draws of ``SineGen`` supplied: ``rand_ini [dim]`` (random initial phase per harmonic, first entry 0,
+    models.py:150-152) and ``noise [B, L*upp, dim]`` (``randn_like``, models.py:168).
+
+    ``_f02sine`` (models.py:140-154) in the reference's float32 operation order: ``rad = f0/sr * (i+1)`` inside a
+    frame, frame totals wrapped by ``fmod(.+0.5, 1)-0.5``, ``cumsum`` over frames (float64 running sum, float32
+    outputs) ``.fmod(1)`` shifted by one frame, times the harmonic number, plus ``rand_ini``; the sine of the float32
+    product ``2*pi*rad`` is taken in float64 here.  ``forward`` (models.py:156-171): ``* sine_amp``, voiced mask
+    ``f0 > threshold`` held over the frame (nearest upsampling), noise amplitude ``uv*noise_std + (1-uv)*sine_amp/3``.
+    Returns ``[B, L*upp]`` float64."""
+    f0 = np.asarray(f0, dtype=F32)
+    B, L = f0.shape
+    dim = np.asarray(weight).reshape(-1).shape[0]
+    i1 = np.arange(1, upp + 1, dtype=F32)[None, None, :]
+    s = (f0 / F32(sr)).astype(F32)[:, :, None]
+    rad = (s * i1).astype(F32)                                                  # :141
+    rad2 = (np.fmod((rad[..., -1:] + F32(0.5)).astype(F32), F32(1.0)).astype(F32) - F32(0.5)).astype(F32)   # :142
+    acc = np.fmod(np.cumsum(rad2.astype(F64), axis=1).astype(F32), F32(1.0)).astype(F32)                    # :143
+    shifted = np.concatenate([np.zeros((B, 1, 1), F32), acc[:, :-1]], axis=1)                               # :144
+    rad = (rad + shifted).astype(F32).reshape(B, L * upp, 1)
+    h = np.arange(1, dim + 1, dtype=F32)[None, None, :]
+    rad = ((rad * h).astype(F32) + np.asarray(rand_ini, dtype=F32).reshape(1, 1, dim)).astype(F32)          # :146-149
+    arg = (TWO_PI32 * rad).astype(F32).astype(F64)
+    sines = np.sin(arg) * F64(F32(sine_amp))                                    # :150, :162
+    uv = np.repeat((f0 > F32(voiced_threshold)).astype(F64), upp, axis=1)[:, :, None]                       # :163-164
+    noise_amp = uv * F64(F32(noise_std)) + (1.0 - uv) * F64(F32(sine_amp) / F32(3.0))                       # :165
+    waves = sines * uv + noise_amp * np.asarray(noise, dtype=F32).astype(F64)                               # :166-167
+    merged = waves @ np.asarray(weight, dtype=F32).astype(F64).reshape(dim) + F64(np.asarray(bias, dtype=F32).reshape(()))
+    return np.tanh(merged)

@@ -14,6 +14,7 @@ Fixtures (all float32 unless noted):
   csfast_*.npz      CombSubFast.forward, captured controls, injected uniform noise      vocoder.py:735-786
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
   mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
+  sinesrc.npz       nsf_hifigan.models.SourceModuleHnNSF.forward with its two random draws injected  models.py:140-204
   *_grad.npz        autograd of CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
                     for a random cotangent R: d(sum(signal * R)) / d ctrl
 """
@@ -222,6 +223,27 @@ def main():
 
     np.savez(os.path.join(HERE, "cssuper_grad.npz"), **run_grad("super", 2, 9, 51))
     np.savez(os.path.join(HERE, "csfast_grad.npz"), **run_grad("fast", 2, 8, 52))
+
+    # ---- harmonic source of NSF-HiFiGAN --------------------------------------
+    import nsf_hifigan.models as nm
+    torch.manual_seed(61)
+    src = nm.SourceModuleHnNSF(44100, harmonic_num=8)
+    Bs, Ls = 2, 24
+    f0s = torch.from_numpy(O.synth_f0(Bs, Ls, sr, hop, seed=62))[..., 0].clone()
+    f0s[0, 5:9] = 0.0                                          # unvoiced stretches (uv mask, noise amplitude switch)
+    f0s[1, 0:2] = 0.0
+    f0s[1, -1] = 0.0
+    g = torch.Generator().manual_seed(63)
+    ri = torch.rand(1, 1, 9, generator=g)
+    nzs = torch.randn(Bs, Ls * hop, 9, generator=g)
+    with mock.patch("torch.rand", side_effect=lambda *a, **k: ri.clone()), \
+            mock.patch("torch.randn_like", side_effect=lambda t: nzs), torch.no_grad():
+        merged = src(f0s, hop)
+    ri0 = ri.clone()
+    ri0[..., 0] = 0
+    np.savez(os.path.join(HERE, "sinesrc.npz"), f0=f0s.numpy(), rand_ini=ri0.numpy().reshape(-1), noise=nzs.numpy(),
+             weight=src.l_linear.weight.detach().numpy(), bias=src.l_linear.bias.detach().numpy(),
+             out=merged.numpy()[..., 0])
 
     # ---- log-mel front-end ---------------------------------------------------
     import nsf_hifigan.nvSTFT as nv
