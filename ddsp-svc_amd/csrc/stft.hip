@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(256) k_fast_source_scan(const float* __restric
   }
 }
 
-// combtooth = sinc(rad / (s0 + 1e-5)) (vocoder.py:643-649); 4 consecutive samples per thread
+// combtooth = sinc(rad / (s0 + 1e-5)) (vocoder.py:643-649); 4 consecutive samples per thread.  When the hop is a
+// multiple of 4 the four samples share their frame, so s0 / ds0 (two float32 divisions) are formed once.
 __global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict__ f0_frames,
                                                         const float* __restrict__ rad_acc, FastSrc cfg, long total,
                                                         float* __restrict__ out) {
@@ -98,21 +99,35 @@ __global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict_
   if (i0 >= total) return;
   const long T = (long)cfg.F * cfg.hop;
   float v[4];
+  auto sample = [&](float s0, float ds0, float shift, int n) -> float {
+    float rad = cfg.rad_local(s0, ds0, n);
+    const float s0n = s0 + (ds0 * (float)n) / (float)cfg.hop;                      // :644
+    rad = rad + shift;                                                             // :647
+    rad = rad - rintf(rad);                                                        // :648
+    return sinc_f32(rad / (s0n + 1e-5f));                                          // :649
+  };
+  if ((cfg.hop & 3) == 0 && i0 + 3 < total) {
+    const long b = i0 / T;
+    const int t = (int)(i0 - b * T);
+    const int f = t / cfg.hop, n = t - f * cfg.hop;
+    float s0, ds0;
+    cfg.frame(f0_frames + b * cfg.F, f, s0, ds0);
+    const float shift = f > 0 ? rad_acc[b * cfg.F + f - 1] : 0.0f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long i = i0 + r;
-    v[r] = 0.f;
-    if (i < total) {
-      const long b = i / T;
-      const int t = (int)(i - b * T);
-      const int f = t / cfg.hop, n = t - f * cfg.hop;
-      float s0, ds0;
-      cfg.frame(f0_frames + b * cfg.F, f, s0, ds0);
-      float rad = cfg.rad_local(s0, ds0, n);
-      const float s0n = s0 + (ds0 * (float)n) / (float)cfg.hop;                    // :644
-      rad = rad + (f > 0 ? rad_acc[b * cfg.F + f - 1] : 0.0f);                     // :647
-      rad = rad - rintf(rad);                                                      // :648
-      v[r] = sinc_f32(rad / (s0n + 1e-5f));                                        // :649
+    for (int r = 0; r < 4; ++r) v[r] = sample(s0, ds0, shift, n + r);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long i = i0 + r;
+      v[r] = 0.f;
+      if (i < total) {
+        const long b = i / T;
+        const int t = (int)(i - b * T);
+        const int f = t / cfg.hop, n = t - f * cfg.hop;
+        float s0, ds0;
+        cfg.frame(f0_frames + b * cfg.F, f, s0, ds0);
+        v[r] = sample(s0, ds0, f > 0 ? rad_acc[b * cfg.F + f - 1] : 0.0f, n);
+      }
     }
   }
   if (i0 + 3 < total && (reinterpret_cast<uintptr_t>(out + i0) & 15) == 0) {
