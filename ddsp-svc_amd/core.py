@@ -102,9 +102,51 @@ def frequency_impulse_response(magnitudes, hann_window=True, half_width_frames=N
     return taps
 
 
+def _fft_convolve_forward(x, ir, impl):
+    B, T = x.shape
+    _, F, N = ir.shape
+    hop = T // F
+    out = torch.empty(B, T, dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ptr(x), 0, ptr(ir), None, ptr(out), None, B, F, hop, N, int(impl),
+                                                _ffi.stream_of(x)))
+    return out
+
+
+def fft_convolve_backward(grad_out, audio, impulse_response, need_audio_grad=True):
+    """Adjoints of ``fft_convolve``: ``(d_audio|None, d_impulse_response)`` for ``grad_out = dL/dout [B,T]``
+    (hop 512, N <= 512)."""
+    x, ir, g = _f32c(audio), _f32c(impulse_response), _f32c(grad_out)
+    B, T = x.shape
+    _, F, N = ir.shape
+    hop = T // F
+    d_x = torch.empty_like(x) if need_audio_grad else None
+    d_ir = torch.empty_like(ir)
+    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve_backward(ptr(x), 0, ptr(ir), ptr(g), ptr(d_x), ptr(d_ir), B, F, hop, N,
+                                                         _ffi.stream_of(x)))
+    return d_x, d_ir
+
+
+class FftConvolveFunction(torch.autograd.Function):
+    """``fft_convolve`` with autograd through the HIP adjoint kernel (csrc/fir_blk_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, audio, impulse_response, impl):
+        x, ir = _f32c(audio.detach()), _f32c(impulse_response.detach())
+        ctx.save_for_backward(x, ir)
+        ctx.need_x = audio.requires_grad
+        return _fft_convolve_forward(x, ir, impl)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, ir = ctx.saved_tensors
+        d_x, d_ir = fft_convolve_backward(grad_out.contiguous(), x, ir, need_audio_grad=ctx.need_x)
+        return d_x, d_ir, None
+
+
 def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
     """core.py:120-182: time-varying FIR of ``audio [B,T]`` with ``impulse_response [B,F,N]``
-    (or ``[B,N]`` for a single filter), ``T = F*hop``; returns ``[B,T]``."""
+    (or ``[B,N]`` for a single filter), ``T = F*hop``; returns ``[B,T]``.  Differentiable w.r.t. both arguments
+    (hop 512, N <= 512)."""
     _ffi.check_device(audio, impulse_response)
     if impulse_response.dim() == 2:
         impulse_response = impulse_response.unsqueeze(1)
@@ -115,11 +157,9 @@ def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
     hop = int(T / F)
     if hop * F != T:
         raise ValueError("audio length {} is not a multiple of the {} impulse-response frames".format(T, F))
-    x, ir = _f32c(audio), _f32c(impulse_response)
-    out = torch.empty(B, T, dtype=torch.float32, device=x.device)
-    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ptr(x), 0, ptr(ir), None, ptr(out), None, B, F, hop, N, int(impl),
-                                                _ffi.stream_of(x)))
-    return out
+    if torch.is_grad_enabled() and (audio.requires_grad or impulse_response.requires_grad):
+        return FftConvolveFunction.apply(audio, impulse_response, impl)
+    return _fft_convolve_forward(_f32c(audio), _f32c(impulse_response), impl)
 
 
 def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None):

@@ -139,6 +139,16 @@ int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, c
   return finish();
 }
 
+int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float* taps, const float* grad_out,
+                                   float* d_audio, float* d_taps, int B, int F, int hop, int N, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!audio || !taps || !grad_out || !d_taps) return DDSP_HIP_EINVAL;
+  if (launch_fir_blk_bwd(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 int ddsp_hip_combtooth(const float* f0_frames, const float* initial_phase, const double* phase0, int B, int F, int hop,
                        double sr, int infer, float* out, void* stream) {
   if (B < 0 || F <= 0 || hop <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;

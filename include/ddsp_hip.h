@@ -89,6 +89,12 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
 int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, const float* addend,
                           float* out, float* out_plain, int B, int F, int hop, int N, int impl, void* stream);
 
+/* What autograd returns for ddsp_hip_fft_convolve given grad_out[B,T] = dL/dout: d_taps[B,F,N] and, if
+ * d_audio is not NULL, d_audio[B,T] (the adjoints of core.py:120-182; training back-propagates through them,
+ * solver.py:93-103).  Supported: hop 512, N <= 512 (the hop-block FFT form). */
+int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float* taps, const float* grad_out,
+                                   float* d_audio, float* d_taps, int B, int F, int hop, int N, void* stream);
+
 /* DSP tail of Sins.forward (ddsp/vocoder.py:580-611) from raw controls and the phase state.
  * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1); tables for n_ap / n_nz bins.
  * signal[B,T]; harmonic_or_null / noise_out_or_null [B,T] only if the caller wants the tuple. */

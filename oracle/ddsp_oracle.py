@@ -607,3 +607,43 @@ def sine_source(f0, upp: int, sr: float, weight, bias, rand_ini, noise, sine_amp
     waves = sines * uv + noise_amp * np.asarray(noise, dtype=F32).astype(F64)                               # :166-167
     merged = waves @ np.asarray(weight, dtype=F32).astype(F64).reshape(dim) + F64(np.asarray(bias, dtype=F32).reshape(()))
     return np.tanh(merged)
+
+
+# --------------------------------------------------------------------------------------
+# 8-f #3 (second part)  adjoints of the time-varying FIR                  core.py:120-182
+# --------------------------------------------------------------------------------------
+def ltv_fir_backward(grad_out, audio, ir):
+    """What autograd returns for ``fft_convolve(audio, impulse_response)`` (core.py:120-182) given
+    ``grad_out = dL/dout [B,T]``: ``(d_audio [B,T], d_ir [B,F,N])``, written out from the hop-block form of the
+    operator (``ltv_fir_direct``): block ``b`` contributes ``conv(x_b (1-lambda), ir_b) + conv(x_b lambda,
+    ir_min(b+1,F-1))`` at output offset ``b hop - N/2``, so with ``seg_b[n] = grad_out[b hop - N/2 + n]``
+
+      d_ir[b]            += sum_s x_b[s] (1 - lambda_s) seg_b[s + m]
+      d_ir[min(b+1,F-1)] += sum_s x_b[s] lambda_s       seg_b[s + m]
+      d_audio[b hop + s]  = (1 - lambda_s) sum_m seg_b[s + m] ir_b[m] + lambda_s sum_m seg_b[s + m] ir_b+1[m].
+
+    float64; correlations through numpy FFTs of a size that cannot alias."""
+    g = np.asarray(grad_out, dtype=F64)
+    x = np.asarray(audio, dtype=F64)
+    ir = np.asarray(ir, dtype=F64)
+    B, T = x.shape
+    Fr, N = ir.shape[1], ir.shape[2]
+    hop = T // Fr
+    D = N // 2
+    L = hop + N - 1
+    nfft = 1 << int(np.ceil(np.log2(L + max(hop, N))))
+    lam = np.arange(hop) / hop
+    d_x = np.zeros_like(x)
+    d_ir = np.zeros_like(ir)
+    gp = np.pad(g, ((0, 0), (D, L)))                            # gp[:, t + D] = g[:, t]
+    for b in range(Fr):
+        b1 = min(b + 1, Fr - 1)
+        seg = gp[:, b * hop:b * hop + L]                        # seg[n] = g[b hop - D + n]
+        S = np.fft.rfft(seg, nfft)
+        xb = x[:, b * hop:(b + 1) * hop]
+        for rows, wgt in ((b, 1.0 - lam), (b1, lam)):
+            X = np.fft.rfft(xb * wgt, nfft)
+            d_ir[:, rows] += np.fft.irfft(np.conj(X) * S, nfft)[:, :N]          # sum_s x[s] seg[s + m]
+            H = np.fft.rfft(ir[:, rows], nfft)
+            d_x[:, b * hop:(b + 1) * hop] += wgt * np.fft.irfft(np.conj(H) * S, nfft)[:, :hop]
+    return d_x, d_ir
