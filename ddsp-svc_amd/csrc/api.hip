@@ -129,6 +129,29 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
   return finish();
 }
 
+int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, int mode,
+                                       const float* half_width, long rows, int n_mag, const float* table, float* d_re,
+                                       float* d_im, void* stream) {
+  if (rows < 0 || n_mag < 2 || mode < 0 || mode > 2 || act < 0 || act > 1) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!d_taps || !table || !d_re) return DDSP_HIP_EINVAL;
+  if (act == DDSP_HIP_ACT_EXP && (!ctrl || ld_ctrl < n_mag)) return DDSP_HIP_EINVAL;
+  if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
+  if (d_im && (act != DDSP_HIP_ACT_NONE || mode != DDSP_HIP_MODE_ROLL)) return DDSP_HIP_ESHAPE;
+  launch_ir_gemm_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
+                     S(stream));
+  return finish();
+}
+
+int ddsp_hip_allpass_backward(const float* c, long ld, long rows, int n_mag, const float* d_re, const float* d_im,
+                              float* d_c, void* stream) {
+  if (rows < 0 || n_mag < 2 || ld < n_mag) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!c || !d_re || !d_im || !d_c) return DDSP_HIP_EINVAL;
+  launch_allpass_backward(c, ld, rows, n_mag, d_re, d_im, d_c, S(stream));
+  return finish();
+}
+
 int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, const float* addend, float* out,
                           float* out_plain, int B, int F, int hop, int N, int impl, void* stream) {
   if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;

@@ -344,6 +344,206 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the tap synthesis: d_taps [rows, N] -> gradient of the one-sided response (or of the raw control
+// through the exp activation).  With dE[m] = w+ dt[N/2 + m] + w- dt[N/2 - m] and dO[m] = w+ dt[N/2 + m] - w- dt[N/2 - m]
+// (window factors of the two taps a bin pair feeds; m = 0 and m = N/2 have one tap only)
+//     d re_k = sum_m dE[m] TE[k][m] = c_k sum_m (dE[m] / c_m) TE[m][k],      d im_k = sum_m dO[m] TO[m][k]
+// (TE[k][m] / c_k is symmetric, TO is symmetric where it is not zero), i.e. the SAME contraction against the SAME
+// basis table as the forward kernel with the roles of bin and tap index swapped: same tiling, staging and MFMA loop;
+// only the A-operand staging (built from two mirrored tap gradients and their window factors) and the epilogue
+// (scale by c_k, activation derivative, [rows, n] stores) differ.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, bool HAS_IM, int MODE>
+__global__ void __launch_bounds__(256, 2) k_ir_gemm_bwd(const float* __restrict__ d_taps, const float* __restrict__ ctrl,
+                                                     long ld_ctrl, float scale, const float* __restrict__ table,
+                                                     const float* __restrict__ half_width, long rows, int n,
+                                                     float* __restrict__ d_re, float* __restrict__ d_im) {
+  __shared__ __attribute__((aligned(16))) float stage[2 * IR_STAGE];
+  const int tid = threadIdx.x;
+  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int li = l & 31, h = l >> 5;
+  const long row0 = (long)blockIdx.x * GM;
+  const int col0 = blockIdx.y * GN;
+  const int N = 2 * (n - 1);
+  const int half = N / 2;
+  const int KP = (int)ir_kp(n);
+  const long NP = ir_np(n);
+  const long plane = (long)KP * NP;
+  const int nch = KP / KC;
+  const int total_ch = HAS_IM ? 2 * nch : nch;
+  const float* hann = table + 2 * plane;
+
+  f32x16 accE[2][2], accO[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accE[rb][cb][i] = 0.f; accO[rb][cb][i] = 0.f; }
+
+  const int a_row = tid >> 2, a_kq = (tid & 3) * 4;
+  const int b_k = tid >> 6, b_c4 = (tid & 63) * 4;
+  const long ar = row0 + a_row;
+  const bool a_live = ar < rows;
+  const float* dt = d_taps + (a_live ? ar : 0) * (long)N;
+  const float hw = (MODE == IR_MODE_DYNAMIC && a_live) ? half_width[ar] : 1.f;
+  struct Chunk { float up[4], dn[4]; float4 b0, b1, b2, b3; };
+
+  // tap gradients of the four contraction indices m = k0 + a_kq .. + 3 (clamped addresses, masked in park)
+  auto fetch = [&](int cc) -> Chunk {
+    const int part = (HAS_IM && cc >= nch) ? 1 : 0;
+    const int k0 = (cc - part * nch) * KC;
+    Chunk c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int m = k0 + a_kq + q;
+      m = m > half ? half : m;
+      c.up[q] = dt[half + (m < half ? m : 0)];
+      c.dn[q] = dt[half - m];
+    }
+    const float* Tb = table + (part ? plane : 0) + (long)(k0 + b_k) * NP + col0 + b_c4;
+    c.b0 = *reinterpret_cast<const float4*>(Tb);
+    c.b1 = *reinterpret_cast<const float4*>(Tb + 4 * NP);
+    c.b2 = *reinterpret_cast<const float4*>(Tb + 8 * NP);
+    c.b3 = *reinterpret_cast<const float4*>(Tb + 12 * NP);
+    return c;
+  };
+  auto park = [&](int buf, int cc, const Chunk& c) {
+    float* As = stage + buf * IR_STAGE;
+    float* Bs = As + GM * LDA;
+    const int part = (HAS_IM && cc >= nch) ? 1 : 0;
+    const int k0 = (cc - part * nch) * KC;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = k0 + a_kq + q;
+      float wp = 1.f, wm = 1.f;
+      if (MODE == IR_MODE_HANN) {
+        const int mm = m > half ? half : m;
+        wp = hann[half + (mm < half ? mm : 0)];
+        wm = hann[half - mm];
+      } else if (MODE == IR_MODE_DYNAMIC) {
+        float u = (float)m / hw;                                // core.py:244, tap N/2 + m
+        const float un = -u;                                    // tap N/2 - m: never above 1, never clamped
+        if (u > 1.0f) u = 0.0f;                                 // core.py:245
+        wp = (1.0f + cos_turns(kPiF * u)) / 2.0f;
+        wm = (1.0f + cos_turns(kPiF * un)) / 2.0f;
+      }
+      const float up = (a_live && m < half) ? wp * c.up[q] : 0.f;        // taps[N/2 + m] exists for m < N/2
+      const float dn = (a_live && m >= 1 && m <= half) ? wm * c.dn[q] : 0.f;   // taps[N/2 - m] for 1 <= m <= N/2
+      const float ce = (m == 0 || m == half) ? 1.0f : 0.5f;      // 1 / c_m
+      v[q] = part ? (up - dn) : ce * (up + dn);
+    }
+    *reinterpret_cast<float4*>(As + a_row * LDA + a_kq) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(Bs + (b_k + 0) * LDB + b_c4) = c.b0;
+    *reinterpret_cast<float4*>(Bs + (b_k + 4) * LDB + b_c4) = c.b1;
+    *reinterpret_cast<float4*>(Bs + (b_k + 8) * LDB + b_c4) = c.b2;
+    *reinterpret_cast<float4*>(Bs + (b_k + 12) * LDB + b_c4) = c.b3;
+  };
+  auto contract = [&](int buf, f32x16 (&acc)[2][2]) {
+    const float* As = stage + buf * IR_STAGE;
+    const float* Bs = As + GM * LDA;
+    float av[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float4 lo = *reinterpret_cast<const float4*>(As + (rb * 32 + li) * LDA + 8 * h);
+      const float4 hi = *reinterpret_cast<const float4*>(As + (rb * 32 + li) * LDA + 8 * h + 4);
+      av[rb][0] = lo.x; av[rb][1] = lo.y; av[rb][2] = lo.z; av[rb][3] = lo.w;
+      av[rb][4] = hi.x; av[rb][5] = hi.y; av[rb][6] = hi.z; av[rb][7] = hi.w;
+    }
+    const float* bp = Bs + (8 * h) * LDB + wc * 64 + li;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const float b0 = bp[sidx * LDB], b1 = bp[sidx * LDB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][sidx], b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][sidx], b1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  Chunk nxt = fetch(0);
+  park(0, 0, nxt);
+  __syncthreads();
+  for (int cc = 0; cc < total_ch; ++cc) {
+    const bool more = cc + 1 < total_ch;
+    if (more) nxt = fetch(cc + 1);
+    if (!HAS_IM || cc < nch) contract(cc & 1, accE);
+    else contract(cc & 1, accO);
+    if (more) park((cc + 1) & 1, cc + 1, nxt);
+    __syncthreads();
+  }
+
+  // epilogue: column = bin k; d re_k = c_k accE, d im_k = accO; through the exp activation d c = d re * scale * exp(c)
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int k = col0 + wc * 64 + cb * 32 + li;
+    if (k >= n) continue;
+    const float ck = (k == 0 || k == n - 1) ? 1.0f : 2.0f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long r = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (r >= rows) continue;
+        float g = ck * accE[rb][cb][reg];
+        if (ACT == IR_ACT_EXP) g = g * (scale * expf(ctrl[r * ld_ctrl + k]));
+        d_re[r * n + k] = g;
+        if (HAS_IM) d_im[r * n + k] = accO[rb][cb][reg];
+      }
+    }
+  }
+}
+
+// adjoint of k_allpass_response: (d_re, d_im) [rows, n] -> gradient of the raw group-delay control.  One wave per row:
+// theta rebuilt as in the forward kernel, d theta = -sin d_re + cos d_im, suffix sums over the bins, times
+// pi (1 - tanh^2 c).
+__global__ void __launch_bounds__(256) k_allpass_backward(const float* __restrict__ c, long ld, long rows, int n,
+                                                          const float* __restrict__ d_re, const float* __restrict__ d_im,
+                                                          float* __restrict__ d_c) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const float* cr = c + r * ld;
+  const int per = (n + 63) / 64;
+  const int k0 = lane * per;
+  const double inv_2pi = 0.15915494309189533577;
+  double local = 0.0;
+  for (int q = 0; q < per; ++q) {
+    const int k = k0 + q;
+    if (k < n) local += (double)(kPiF * tanhf(cr[k]));
+  }
+  double run = wave_excl_scan(local, lane);
+  // first pass: d theta of the lane's bins and their sum
+  double dth_sum = 0.0;
+  for (int q = 0; q < per; ++q) {
+    const int k = k0 + q;
+    if (k < n) {
+      run += (double)(kPiF * tanhf(cr[k]));
+      const double rev = run * inv_2pi;
+      const float fr = (float)(rev - rint(rev));
+      const float co = __builtin_amdgcn_cosf(fr), si = __builtin_amdgcn_sinf(fr);
+      const float dth = fmaf(-si, d_re[r * n + k], co * d_im[r * n + k]);
+      d_c[r * n + k] = dth;                                     // parked; turned into the suffix sum below
+      dth_sum += (double)dth;
+    }
+  }
+  // suffix sums: total of the lanes after this one, then a backward walk over the lane's own bins
+  const double incl_before = wave_excl_scan(dth_sum, lane);    // sum over lanes < this one
+  const double total = wave_sum(dth_sum);
+  double suffix = total - incl_before - dth_sum;                // sum over lanes > this one
+  for (int q = per - 1; q >= 0; --q) {
+    const int k = k0 + q;
+    if (k < n) {
+      suffix += (double)d_c[r * n + k];
+      const float th = tanhf(cr[k]);
+      d_c[r * n + k] = (float)suffix * (kPiF * (1.0f - th * th));
+    }
+  }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 size_t ir_table_floats(int n) { return (size_t)(2 * ir_kp(n) * ir_np(n)) + 2 * (size_t)(n - 1); }
 
@@ -391,6 +591,34 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
   }
 #undef DDSP_IR_MODES
 #undef DDSP_IR_LAUNCH
+}
+
+void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
+                        int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
+                        hipStream_t st) {
+  if (rows == 0) return;
+  dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)(ir_np(n) / GN)), block(256);
+#define DDSP_IRB_LAUNCH(ACT_, IM_, MODE_)                                                                        \
+  hipLaunchKernelGGL((k_ir_gemm_bwd<ACT_, IM_, MODE_>), grid, block, 0, st, d_taps, ctrl, ld_ctrl, scale, table, \
+                     half_width, rows, n, d_re, d_im)
+  if (has_im) {
+    DDSP_IRB_LAUNCH(IR_ACT_NONE, true, IR_MODE_ROLL);           // the all-pass response is the only complex one
+  } else if (act == IR_ACT_EXP) {
+    if (mode == IR_MODE_HANN) DDSP_IRB_LAUNCH(IR_ACT_EXP, false, IR_MODE_HANN);
+    else if (mode == IR_MODE_DYNAMIC) DDSP_IRB_LAUNCH(IR_ACT_EXP, false, IR_MODE_DYNAMIC);
+    else DDSP_IRB_LAUNCH(IR_ACT_EXP, false, IR_MODE_ROLL);
+  } else {
+    if (mode == IR_MODE_HANN) DDSP_IRB_LAUNCH(IR_ACT_NONE, false, IR_MODE_HANN);
+    else if (mode == IR_MODE_DYNAMIC) DDSP_IRB_LAUNCH(IR_ACT_NONE, false, IR_MODE_DYNAMIC);
+    else DDSP_IRB_LAUNCH(IR_ACT_NONE, false, IR_MODE_ROLL);
+  }
+#undef DDSP_IRB_LAUNCH
+}
+
+void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
+                             hipStream_t st) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_allpass_backward, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, c, ld, rows, n, d_re, d_im, d_c);
 }
 
 }  // namespace ddsp

@@ -21,6 +21,11 @@ void launch_half_width(const float* f0_frames, long rows, float sr, float* hw, h
 void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale,
                     const float* table, int mode, const float* half_width, long rows, int n, float* taps,
                     hipStream_t st);
+void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
+                        int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
+                        hipStream_t st);
+void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
+                             hipStream_t st);
 size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves);
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                int B, int F, int hop, int N, int impl, hipStream_t st);

@@ -133,10 +133,109 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
     return signal, harm, nzo
 
 
+# ---- differentiable tap synthesis from raw controls (training path of CombSub) --------------------------------
+def _rows2(t, n):
+    """[B,F,n] control -> (tensor usable as [B*F, n] rows, row stride)"""
+    t, ld = _rows(t, n)
+    return t, ld
+
+
+class MagnitudeTapsFunction(torch.autograd.Function):
+    """taps = window(roll(irfft(scale * exp(c)))) (vocoder.py:835-836 + core.py:254-270) with the gradient back to
+    the raw control ``c [B,F,n]``; ``mode`` HANN or DYNAMIC (``half_width [B,F]``)."""
+
+    @staticmethod
+    def forward(ctx, c, scale, mode, half_width):
+        B, F, n = c.shape
+        cc, ld = _rows(c.detach(), n)
+        N = 2 * (n - 1)
+        dev = c.device
+        taps = torch.empty(B, F, N, dtype=torch.float32, device=dev)
+        hw = None if half_width is None else _f32c(half_width.reshape(B * F))
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(cc), ld, None, 0, _ffi.ACT_EXP, float(scale), int(mode),
+                                                        ptr(hw), B * F, n, ptr(ir_table(n, dev)), ptr(taps),
+                                                        _ffi.stream_of(cc)))
+        ctx.save_for_backward(cc, hw if hw is not None else cc.new_empty(0))
+        ctx.cfg = (ld, float(scale), int(mode), hw is not None)
+        return taps
+
+    @staticmethod
+    def backward(ctx, d_taps):
+        cc, hw = ctx.saved_tensors
+        ld, scale, mode, has_hw = ctx.cfg
+        B, F, n = cc.shape
+        d_c = torch.empty(B, F, n, dtype=torch.float32, device=cc.device)
+        g = _f32c(d_taps)
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(g), ptr(cc), ld, _ffi.ACT_EXP, scale, mode,
+                                                                 ptr(hw) if has_hw else None, B * F, n,
+                                                                 ptr(ir_table(n, cc.device)), ptr(d_c), None,
+                                                                 _ffi.stream_of(cc)))
+        return d_c, None, None, None
+
+
+class AllpassTapsFunction(torch.autograd.Function):
+    """taps = roll(irfft(exp(1j * cumsum(pi * tanh(c))))) (vocoder.py:834,845 + core.py:254-270, no window) with the
+    gradient back to the raw group-delay control ``c [B,F,n]``."""
+
+    @staticmethod
+    def forward(ctx, c):
+        B, F, n = c.shape
+        cc, ld = _rows(c.detach(), n)
+        dev = c.device
+        N = 2 * (n - 1)
+        re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
+        im = torch.empty_like(re)
+        taps = torch.empty(B, F, N, dtype=torch.float32, device=dev)
+        st = _ffi.stream_of(cc)
+        _ffi.check(_ffi.lib().ddsp_hip_allpass_response(ptr(cc), ld, B * F, n, ptr(re), ptr(im), st))
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(re), n, ptr(im), n, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
+                                                        B * F, n, ptr(ir_table(n, dev)), ptr(taps), st))
+        ctx.save_for_backward(cc)
+        ctx.ld = ld
+        return taps
+
+    @staticmethod
+    def backward(ctx, d_taps):
+        (cc,) = ctx.saved_tensors
+        B, F, n = cc.shape
+        dev = cc.device
+        d_re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
+        d_im = torch.empty_like(d_re)
+        d_c = torch.empty(B, F, n, dtype=torch.float32, device=dev)
+        g = _f32c(d_taps)
+        st = _ffi.stream_of(cc)
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(g), None, 0, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
+                                                                 B * F, n, ptr(ir_table(n, dev)), ptr(d_re), ptr(d_im), st))
+        _ffi.check(_ffi.lib().ddsp_hip_allpass_backward(ptr(cc), ctx.ld, B * F, n, ptr(d_re), ptr(d_im), ptr(d_c), st))
+        return d_c
+
+
+def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, noise_magnitude, noise, sampling_rate,
+                         block_size, noise_is_u01):
+    """CombSub DSP tail as a composition of differentiable primitives (training, solver.py:93-103): the same kernels as
+    the fused entry point, intermediates kept for the backward pass.  Returns (signal, harmonic, noise)."""
+    from .core import fft_convolve
+    f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+    B, F = f0.shape
+    comb = combtooth(f0_frames, state, sampling_rate, block_size)                             # vocoder.py:839-840
+    h1 = fft_convolve(comb, AllpassTapsFunction.apply(group_delay))                           # :843-846
+    hw = (1.5 * float(sampling_rate)) / (f0 + 1e-3)                                           # :851
+    harmonic = fft_convolve(h1, MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw))   # :847-851
+    nz = _f32c(noise.reshape(B, -1))
+    if noise_is_u01:
+        nz = nz * 2 - 1                                                                        # :854
+    noise_f = fft_convolve(nz, MagnitudeTapsFunction.apply(noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None))   # :855-858
+    return harmonic + noise_f, harmonic, noise_f
+
+
 def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude, noise_magnitude, noise,
                   sampling_rate, block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
-    """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls."""
+    """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls.  With gradients enabled and a control
+    that requires grad the differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, state.phase0)
+    if torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):
+        return _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, noise_magnitude, noise,
+                                    sampling_rate, block_size, noise_is_u01)
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
     B, F = f0.shape
     hop = int(block_size)

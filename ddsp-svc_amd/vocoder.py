@@ -85,7 +85,6 @@ class CombSub(_SynthBase):
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :819-829
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :832
-        self._check_inference_only(*ctrls.values())
         B, F = f0_frames.shape[0], f0_frames.shape[1]
         u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :854
         signal, harmonic, noise = synth.combsub_synth(

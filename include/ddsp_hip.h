@@ -82,6 +82,18 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
                               float scale, int mode, const float* half_width, long rows, int n_mag,
                               const float* table, float* taps, void* stream);
 
+/* Adjoints of the two calls above (what autograd returns for the response / the raw control):
+ *   impulse_response_backward: d_taps[rows,N] -> d_re[rows,n_mag] (+ d_im[rows,n_mag] when d_im is not NULL:
+ *   the complex case, act NONE / mode ROLL only).  With act EXP the result is the gradient of the raw control
+ *   itself (d_re = dL/dc = dL/dresp * scale * exp(c), ctrl/ld_ctrl = the forward's resp_re/ld_re); the window
+ *   (mode, half_width) is a constant factor.
+ *   allpass_backward: (d_re, d_im)[rows,n_mag] of exp(1j*cumsum(pi*tanh(c))) -> d_c[rows,n_mag]. */
+int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale,
+                                       int mode, const float* half_width, long rows, int n_mag, const float* table,
+                                       float* d_re, float* d_im, void* stream);
+int ddsp_hip_allpass_backward(const float* c, long ld, long rows, int n_mag, const float* d_re, const float* d_im,
+                              float* d_c, void* stream);
+
 /* ddsp/core.py:120-182  fft_convolve(audio[B,T], taps[B,F,N]) -> out[B,T]  (T = F*hop).
  * x_is_u01: the input is a raw U[0,1) draw and 2*u-1 is applied on load (vocoder.py:603,854);
  * addend[B,T] or NULL is added to the result (vocoder.py:609,860); out_plain[B,T] or NULL also

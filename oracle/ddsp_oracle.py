@@ -647,3 +647,42 @@ def ltv_fir_backward(grad_out, audio, ir):
             H = np.fft.rfft(ir[:, rows], nfft)
             d_x[:, b * hop:(b + 1) * hop] += wgt * np.fft.irfft(np.conj(H) * S, nfft)[:, :hop]
     return d_x, d_ir
+
+
+def impulse_response_backward(d_taps, mode: int, half_width=None):
+    """Adjoint of ``impulse_response`` w.r.t. the one-sided response: ``d_taps [B,F,N] -> (d_re, d_im) [B,F,n]``
+    (what autograd returns for the real and imaginary part of ``magnitudes`` in core.py:254-270; the window of
+    core.py:185-251 depends on f0 only and is a constant factor here).  float64."""
+    dt = np.asarray(d_taps, dtype=F64)
+    N = dt.shape[-1]
+    n = N // 2 + 1
+    if mode == MODE_HANN:
+        dt = dt * (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N) / N))
+    elif mode == MODE_DYNAMIC:
+        hw = np.asarray(half_width, dtype=F32)
+        if hw.ndim == 2:
+            hw = hw[:, :, None]
+        w = (np.arange(-(N // 2), (N + 1) // 2, dtype=F32)[None, None, :] / hw).astype(F32)
+        w = np.where(w > F32(1.0), F32(0.0), w).astype(F32)
+        dt = dt * ((1.0 + np.cos((PI32 * w).astype(F32).astype(F64))) / 2.0)
+    d_ir = np.roll(dt, -(N // 2), axis=-1)                      # adjoint of roll(ir, N/2)
+    m = np.arange(N)
+    k = np.arange(n)
+    ang = 2.0 * np.pi * ((k[:, None] * m[None, :]) % N) / N      # [n, N]
+    ck = np.full(n, 2.0)
+    ck[0] = ck[n - 1] = 1.0
+    d_re = (d_ir @ np.cos(ang).T) * ck / N
+    d_im = -(d_ir @ np.sin(ang).T) * 2.0 / N
+    d_im[..., 0] = 0.0
+    d_im[..., n - 1] = 0.0
+    return d_re, d_im
+
+
+def allpass_backward(gd_ctrl, d_re, d_im):
+    """Adjoint of ``allpass_response``: gradients of (cos theta, sin theta), ``theta = cumsum(pi tanh(c))``, back to
+    the raw group-delay control ``c`` (vocoder.py:581,599 / :834,845)."""
+    c = np.asarray(gd_ctrl, dtype=F32).astype(F64)
+    th = np.cumsum(np.pi * np.tanh(c), axis=-1)
+    d_th = -np.sin(th) * np.asarray(d_re, dtype=F64) + np.cos(th) * np.asarray(d_im, dtype=F64)
+    d_gd = np.flip(np.cumsum(np.flip(d_th, axis=-1), axis=-1), axis=-1)          # suffix sums
+    return d_gd * np.pi * (1.0 - np.tanh(c) ** 2)
