@@ -39,6 +39,9 @@ SIGNATURES = {
     "ddsp_hip_synth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddsp_hip_combtooth": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_int, P, P]),
     "ddsp_hip_sinusoid_bank": (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_double, c_int, P, P]),
+    "ddsp_hip_sinusoid_bank_backward_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ddsp_hip_sinusoid_bank_backward": (c_int, [P, P, P, P, c_long, P, c_int, c_int, c_int, c_int, c_double, c_int,
+                                                P, P, P]),
     "ddsp_hip_fast_source": (c_int, [P, c_int, c_int, c_int, c_double, P, P, P, P]),
     "ddsp_hip_stft_filter": (c_int, [P, P, c_int, P, c_long, P, c_long, P, c_long, P, c_long, c_float, P, c_int,
                                      c_int, c_int, c_int, c_int, c_int, P, P]),

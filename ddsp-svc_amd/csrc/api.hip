@@ -192,6 +192,23 @@ int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, c
   return finish();
 }
 
+size_t ddsp_hip_sinusoid_bank_backward_scratch_bytes(int B, int F, int H) {
+  if (B <= 0 || F <= 0 || H <= 0) return 0;
+  return sins_bank_bwd_scratch_floats(B, F, H) * sizeof(float);
+}
+
+int ddsp_hip_sinusoid_bank_backward(const float* f0_frames, const float* initial_phase, const double* phase0,
+                                    const float* c_amp, long ld_amp, const float* grad_out, int B, int F, int hop, int H,
+                                    double sr, int infer, void* scratch, float* d_c_amp, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || H <= 0 || ld_amp < H || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0_frames || !phase0 || !c_amp || !grad_out || !scratch || !d_c_amp) return DDSP_HIP_EINVAL;
+  if (launch_sins_bank_bwd(f0_frames, initial_phase, c_amp, ld_amp, grad_out, B, F, hop, H, sr, infer, phase0,
+                           static_cast<float*>(scratch), d_c_amp, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max) {
   if (B <= 0 || F <= 0 || hop <= 0 || n_max < 2) return 0;
   Carver c(nullptr, (size_t)-1);

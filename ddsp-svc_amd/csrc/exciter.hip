@@ -278,6 +278,130 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
   else { dst[0] = r[0]; dst[1] = r[1]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the sinusoid bank w.r.t. the amplitudes (hop = 512): for the frame of the workgroup,
+//     R0[k] = sum_t g[t] w0[t] sin(k theta_t)     (goes to amplitude row f)
+//     R1[k] = sum_t g[t] w1[t] sin(k theta_t)     (goes to amplitude row min(f+1, F-1))
+// The sines are generated exactly as in k_sins_bank2 (same table, same seeds); per block of 16 harmonics every
+// thread's 32 products (16 harmonics x two rows, its two samples already added) go through an LDS tile
+// [32][256 (+1 pad)] and are summed column-block-wise: thread (v = tid & 31, chunk = tid >> 5) adds 32 entries, the
+// two chunks of a wave meet by one cross-lane exchange, the four waves through a second small LDS array.
+// k_sins_bank_bwd_combine then forms dc[f][k] = A[f][k] (R0[f][k] + R1[f-1][k] (+ R1[F-1][k] on the last row)).
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_TILE_LD = 257;
+
+__global__ void __launch_bounds__(256) k_sins_bank2_bwd(const float* __restrict__ f0_frames,
+                                                        const float* __restrict__ initial_phase,
+                                                        const float* __restrict__ grad_out, int F, int H, Upsampler up,
+                                                        PhaseCfg cfg, const double* __restrict__ phase0,
+                                                        float* __restrict__ partial /* [B*F][HP][2] */) {
+  constexpr int HOP = 512;
+  __shared__ float tile[32 * SB_TILE_LD];
+  __shared__ float part[4][32];
+  __shared__ double wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long fr = blockIdx.x;
+  const long b = fr / F;
+  const int f = (int)(fr - b * F);
+  const int HP = (H + 15) & ~15;
+  const float* f0_row = f0_frames + b * F;
+  const Upsampler::Row3 rows = up.load3(f0_row, f);
+  const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
+  const long t0 = (long)f * HOP + 2 * tid;
+  const double q0 = cfg.term(up.at3(rows, t0));
+  const double q1 = cfg.term(up.at3(rows, t0 + 1));
+  const double mine = q0 + q1;
+  const double excl = wave_excl_scan(mine, lane);
+  if (lane == 63) wsum[wave] = excl + mine;
+  __syncthreads();
+  double base = phase0[fr] + excl;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const float xa = cfg.wrap(base + q0, ip), xb = cfg.wrap(base + q0 + q1, ip);
+  const f32x2 theta = {kTwoPiF * xa, kTwoPiF * xb};
+  f32x2 tc[16], ts[16];
+  {
+    float c0, s0, c1, s1;
+    cis_product(1.0f, theta.x, c0, s0);
+    cis_product(1.0f, theta.y, c1, s1);
+    tc[0] = f32x2{c0, c1};
+    ts[0] = f32x2{s0, s1};
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      tc[j] = __builtin_elementwise_fma(tc[j - 1], tc[0], -(ts[j - 1] * ts[0]));
+      ts[j] = __builtin_elementwise_fma(ts[j - 1], tc[0], tc[j - 1] * ts[0]);
+    }
+  }
+  // cotangent of the two samples times the interpolation weights of the two amplitude rows (core.py:66-70)
+  f32x2 gw0, gw1;
+  {
+    const float* gp = grad_out + b * (long)F * HOP + t0;
+    float w0[2], w1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int i0, i1;
+      up.locate(t0 + q, i0, i1, w0[q], w1[q]);
+    }
+    gw0 = f32x2{gp[0] * w0[0], gp[1] * w0[1]};
+    gw1 = f32x2{gp[0] * w1[0], gp[1] * w1[1]};
+  }
+  f32x2 Cb = {1.f, 1.f}, Sb = {0.f, 0.f};
+  const int nblk = HP >> 4;
+  const int v = tid & 31, chunk = tid >> 5;
+  for (int blk = 0; blk < nblk; ++blk) {
+    if (blk > 0) {
+      if ((blk & 3) == 0) {
+        float c0, s0, c1, s1;
+        cis_product((float)(16 * blk), theta.x, c0, s0);
+        cis_product((float)(16 * blk), theta.y, c1, s1);
+        Cb = f32x2{c0, c1};
+        Sb = f32x2{s0, s1};
+      } else {
+        const f32x2 cn = __builtin_elementwise_fma(Cb, tc[15], -(Sb * ts[15]));
+        Sb = __builtin_elementwise_fma(Sb, tc[15], Cb * ts[15]);
+        Cb = cn;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const f32x2 sv = __builtin_elementwise_fma(Cb, ts[j], Sb * tc[j]);
+      const f32x2 p0 = sv * gw0, p1 = sv * gw1;
+      tile[(2 * j) * SB_TILE_LD + tid] = p0.x + p0.y;
+      tile[(2 * j + 1) * SB_TILE_LD + tid] = p1.x + p1.y;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const float* col = tile + v * SB_TILE_LD + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc += col[i];
+    acc += __shfl_xor(acc, 32);                                  // the wave's two chunks
+    if (lane < 32) part[wave][v] = acc;
+    __syncthreads();
+    if (tid < 32) {
+      const float tot = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      partial[(fr * HP + 16 * blk + (tid >> 1)) * 2 + (tid & 1)] = tot;
+    }
+    // the next block's tile writes come after this barrier pair; part[] is rewritten only after the next first barrier
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sins_bank_bwd_combine(const float* __restrict__ f0_frames,
+                                                               const float* __restrict__ c_amp, long ld_amp,
+                                                               const float* __restrict__ partial, int F, int H, int HP,
+                                                               float nyq, long total, float* __restrict__ d_c) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % H);
+  const long fr = i / H;
+  const int f = (int)(fr % F);
+  const long b = fr / F;
+  float dA = partial[(fr * HP + k) * 2];
+  if (f > 0) dA += partial[((fr - 1) * HP + k) * 2 + 1];
+  if (f == F - 1) dA += partial[(fr * HP + k) * 2 + 1];         // the held last frame (core.py:68)
+  const float a = expf(c_amp[fr * ld_amp + k]) / 128.0f;
+  const float p = f0_frames[b * F + f] * (float)(k + 1);
+  d_c[i] = dA * (a * ((p < nyq ? 1.0f : 0.0f) + 1e-7f));
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 Upsampler make_upsampler_pub(int F, int hop);
 PhaseCfg make_phase_cfg(double sr, int infer, int has_ip);
@@ -325,6 +449,24 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
     hipLaunchKernelGGL(k_sins_bank<16>, grid, block, sh, st, f0_frames, initial_phase, c_amp, ld_amp, F, hop, H, up, cfg, phase0, out);
   else
     hipLaunchKernelGGL(k_sins_bank<32>, grid, block, sh, st, f0_frames, initial_phase, c_amp, ld_amp, F, hop, H, up, cfg, phase0, out);
+  return 0;
+}
+
+size_t sins_bank_bwd_scratch_floats(int B, int F, int H) { return (size_t)B * F * ((H + 15) & ~15) * 2; }
+
+int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, const float* c_amp, long ld_amp,
+                         const float* grad_out, int B, int F, int hop, int H, double sr, int infer, const double* phase0,
+                         float* scratch, float* d_c, hipStream_t st) {
+  if (hop != 512 || (long)B * F > 0x7fffffffL) return -1;
+  if ((long)B * F == 0) return 0;
+  Upsampler up = make_upsampler_pub(F, hop);
+  PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
+  const int HP = (H + 15) & ~15;
+  hipLaunchKernelGGL(k_sins_bank2_bwd, dim3((unsigned)((long)B * F)), dim3(256), 0, st, f0_frames, initial_phase, grad_out, F,
+                     H, up, cfg, phase0, scratch);
+  const long total = (long)B * F * H;
+  hipLaunchKernelGGL(k_sins_bank_bwd_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0_frames, c_amp,
+                     ld_amp, scratch, F, H, HP, (float)sr / 2.0f, total, d_c);
   return 0;
 }
 

@@ -14,6 +14,10 @@ int launch_combtooth(const float* f0_frames, const float* initial_phase, int B, 
                      const double* phase0, float* out, hipStream_t st);
 int launch_sins_bank(const float* f0_frames, const float* initial_phase, const float* c_amp, long ld_amp, int B, int F,
                      int hop, int H, double sr, int infer, const double* phase0, float* out, hipStream_t st);
+size_t sins_bank_bwd_scratch_floats(int B, int F, int H);
+int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, const float* c_amp, long ld_amp,
+                         const float* grad_out, int B, int F, int hop, int H, double sr, int infer, const double* phase0,
+                         float* scratch, float* d_c, hipStream_t st);
 size_t ir_table_floats(int n);
 void launch_ir_table(int n, float* table, hipStream_t st);
 void launch_allpass_response(const float* c, long ld, long rows, int n, float* re, float* im, hipStream_t st);

@@ -111,8 +111,12 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
                block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
     """DSP tail of ``Sins.forward`` (vocoder.py:580-611) from raw controls.  ``noise [B,T]`` is the
     uniform draw (``noise_is_u01``: raw ``rand_like`` output, else already ``2u-1``).
-    Returns ``(signal, harmonic|None, noise|None)``."""
+    Returns ``(signal, harmonic|None, noise|None)``.  With gradients enabled and a control that requires grad the
+    differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, amplitudes, group_delay, noise_magnitude, noise, state.phase0)
+    if torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
+        return _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude, noise, sampling_rate,
+                                 block_size, noise_is_u01)
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
     B, F = f0.shape
     hop = int(block_size)
@@ -133,7 +137,34 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
     return signal, harm, nzo
 
 
-# ---- differentiable tap synthesis from raw controls (training path of CombSub) --------------------------------
+class SinusoidBankFunction(torch.autograd.Function):
+    """``sinusoid_bank`` with the gradient back to the raw ``amplitudes`` control (hop 512)."""
+
+    @staticmethod
+    def forward(ctx, f0_frames, state, amplitudes_ctrl, sampling_rate, block_size):
+        out = sinusoid_bank(f0_frames, state, amplitudes_ctrl.detach(), sampling_rate, block_size)
+        ctx.save_for_backward(_f32c(f0_frames.reshape(f0_frames.shape[0], -1)), amplitudes_ctrl.detach())
+        ctx.cfg = (state, float(sampling_rate), int(block_size))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f0, c_amp = ctx.saved_tensors
+        state, sr, hop = ctx.cfg
+        B, F = f0.shape
+        H = c_amp.shape[-1]
+        c, ld = _rows(c_amp, H)
+        g = _f32c(grad_out.reshape(B, F * hop))
+        lib = _ffi.lib()
+        scratch = torch.empty(lib.ddsp_hip_sinusoid_bank_backward_scratch_bytes(B, F, H), dtype=torch.uint8, device=f0.device)
+        d_c = torch.empty(B, F, H, dtype=torch.float32, device=f0.device)
+        _ffi.check(lib.ddsp_hip_sinusoid_bank_backward(ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(c), ld,
+                                                       ptr(g), B, F, hop, H, sr, int(state.infer), ptr(scratch), ptr(d_c),
+                                                       _ffi.stream_of(f0)))
+        return None, None, d_c, None, None
+
+
+# ---- differentiable tap synthesis from raw controls (training path of Sins / CombSub) ------------------------
 def _rows2(t, n):
     """[B,F,n] control -> (tensor usable as [B*F, n] rows, row stride)"""
     t, ld = _rows(t, n)
@@ -225,6 +256,20 @@ def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, nois
     if noise_is_u01:
         nz = nz * 2 - 1                                                                        # :854
     noise_f = fft_convolve(nz, MagnitudeTapsFunction.apply(noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None))   # :855-858
+    return harmonic + noise_f, harmonic, noise_f
+
+
+def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude, noise, sampling_rate, block_size,
+                      noise_is_u01):
+    """Sins DSP tail as a composition of differentiable primitives (training).  Returns (signal, harmonic, noise)."""
+    from .core import fft_convolve
+    B = f0_frames.shape[0]
+    sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)       # vocoder.py:585-594
+    harmonic = fft_convolve(sinus, AllpassTapsFunction.apply(group_delay))                            # :597-600
+    nz = _f32c(noise.reshape(B, -1))
+    if noise_is_u01:
+        nz = nz * 2 - 1                                                                                # :603
+    noise_f = fft_convolve(nz, MagnitudeTapsFunction.apply(noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None))   # :604-607
     return harmonic + noise_f, harmonic, noise_f
 
 

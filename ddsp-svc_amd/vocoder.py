@@ -42,11 +42,6 @@ class _SynthBase(torch.nn.Module):
         self._sr = float(self.sampling_rate)
         self._hop = int(self.block_size)
 
-    def _check_inference_only(self, *tensors):
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-            raise NotImplementedError("ddsp_svc_amd synthesisers are forward-only (no autograd through the "
-                                      "HIP kernels yet); call under torch.no_grad()")
-
 
 class Sins(_SynthBase):
     """Sinusoids additive synthesiser, ddsp/vocoder.py:532-611."""
@@ -61,7 +56,6 @@ class Sins(_SynthBase):
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :564-575
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :578
-        self._check_inference_only(*ctrls.values())
         B, F = f0_frames.shape[0], f0_frames.shape[1]
         u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :603
         signal, harmonic, noise = synth.sins_synth(

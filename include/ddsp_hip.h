@@ -138,6 +138,13 @@ int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, c
                            const float* c_amp, long ld_amp, int B, int F, int hop, int H, double sr, int infer,
                            float* out, void* stream);
 
+/* Adjoint of ddsp_hip_sinusoid_bank w.r.t. the raw amplitude control: grad_out[B,T] -> d_c_amp[B,F,H]
+ * (contiguous).  scratch: ddsp_hip_sinusoid_bank_backward_scratch_bytes(B, F, H) bytes.  Supported: hop 512. */
+size_t ddsp_hip_sinusoid_bank_backward_scratch_bytes(int B, int F, int H);
+int ddsp_hip_sinusoid_bank_backward(const float* f0_frames, const float* initial_phase, const double* phase0,
+                                    const float* c_amp, long ld_amp, const float* grad_out, int B, int F, int hop,
+                                    int H, double sr, int infer, void* scratch, float* d_c_amp, void* stream);
+
 /* ---- CombSubFast / CombSubSuperFast (ddsp/vocoder.py:613-786): short-time spectral filtering ---- */
 
 /* ddsp/vocoder.py:639-651  CombSubSuperFast.fast_source_gen(f0_frames[B,F]): closed-form per-frame

@@ -686,3 +686,31 @@ def allpass_backward(gd_ctrl, d_re, d_im):
     d_th = -np.sin(th) * np.asarray(d_re, dtype=F64) + np.cos(th) * np.asarray(d_im, dtype=F64)
     d_gd = np.flip(np.cumsum(np.flip(d_th, axis=-1), axis=-1), axis=-1)          # suffix sums
     return d_gd * np.pi * (1.0 - np.tanh(c) ** 2)
+
+
+def sinusoid_bank_backward(grad_out, x, f0_frames, amp_ctrl, sr: float, hop: int):
+    """Adjoint of ``sinusoid_bank`` w.r.t. the raw amplitude control (what autograd returns through
+    vocoder.py:580,585-594): with ``A = mask * exp(c)/128`` and ``w0/w1`` the interpolation weights of core.py:66-70,
+    ``dA[f,k] = sum_{t in frame f} g[t] w0[t] sin(k phase[t]) + sum_{t in frame f-1} g[t] w1[t] sin(k phase[t])``
+    (the held last frame also takes its own w1 part) and ``dc = dA * A``.  float64; the sine argument is rounded to
+    float32 exactly as in the forward oracle."""
+    amp_ctrl = np.asarray(amp_ctrl, dtype=F32)
+    B, Fr, H = amp_ctrl.shape
+    A = (np.exp(amp_ctrl.astype(F64)) / 128.0).astype(F32)
+    A = remove_above_fmax(A, f0_frames, F32(sr) / F32(2.0), 1).astype(F64)
+    phase = (TWO_PI32 * np.asarray(x, dtype=F32)).astype(F32)
+    g = np.asarray(grad_out, dtype=F64)
+    w0, w1 = _lerp_weights(hop)
+    G0 = (g.reshape(B, Fr, hop) * w0.astype(F64))
+    G1 = (g.reshape(B, Fr, hop) * w1.astype(F64))
+    dA = np.zeros((B, Fr, H), dtype=F64)
+    ks = np.arange(1, H + 1, dtype=F32)
+    for h0 in range(0, H, 16):
+        kk = ks[h0:h0 + 16]
+        S = np.sin((phase[:, :, None] * kk[None, None, :]).astype(F32).astype(F64)).reshape(B, Fr, hop, -1)
+        R0 = np.einsum("bft,bftk->bfk", G0, S)
+        R1 = np.einsum("bft,bftk->bfk", G1, S)
+        dA[:, :, h0:h0 + 16] += R0
+        dA[:, 1:, h0:h0 + 16] += R1[:, :-1]
+        dA[:, -1, h0:h0 + 16] += R1[:, -1]
+    return dA * A

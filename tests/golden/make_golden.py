@@ -15,7 +15,7 @@ Fixtures (all float32 unless noted):
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
   mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
   sinesrc.npz       nsf_hifigan.models.SourceModuleHnNSF.forward with its two random draws injected  models.py:140-204
-  *_grad.npz        autograd of CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
+  *_grad.npz        autograd of Sins / CombSub / CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
                     for a random cotangent R: d(sum(signal * R)) / d ctrl
 """
 import os
@@ -251,6 +251,37 @@ def main():
             out["grad_" + k] = v.grad.numpy()
         return out
 
+    def run_grad_sins(B, Fr, seed, sizes=(48, 65, 33)):
+        torch.manual_seed(seed)
+        model = V.Sins(sr, hop, sizes[0], sizes[1], sizes[2], n_unit=64, n_spk=1).eval()
+        with torch.no_grad():
+            model.unit2ctrl.dense_out.weight_g.mul_(3.0)
+        g = torch.Generator().manual_seed(seed + 1)
+        units = torch.randn(B, Fr, 64, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=seed + 2))
+        f0f[0] = torch.clamp(f0f[0] * 2.2, 65, 800)
+        vol = torch.rand(B, Fr, 1, generator=g) * 0.1
+        u01 = torch.rand(B, Fr * hop, generator=g)
+        R = torch.randn(B, Fr * hop, generator=g)
+        cap = {}
+
+        def hook(mod, i, o):
+            for v in o[0].values():
+                v.retain_grad()
+            cap.update(ctrls=o[0])
+        hk = model.unit2ctrl.register_forward_hook(hook)
+        with mock.patch("torch.rand_like", side_effect=lambda t: u01.to(t)):
+            signal, _, _ = model(units, f0f, vol, infer=True)
+        hk.remove()
+        (signal * R).sum().backward()
+        out = dict(f0_frames=f0f.numpy(), noise=(u01 * 2 - 1).numpy(), cotangent=R.numpy(),
+                   signal=signal.detach().numpy(), sizes=np.array(sizes))
+        for k, v in cap["ctrls"].items():
+            out["ctrl_" + k] = v.detach().numpy()
+            out["grad_" + k] = v.grad.numpy()
+        return out
+
+    np.savez(os.path.join(HERE, "sins_grad.npz"), **run_grad_sins(2, 8, 54))
     np.savez(os.path.join(HERE, "combsub_grad.npz"), **run_grad_combsub(2, 8, 53))
     np.savez(os.path.join(HERE, "cssuper_grad.npz"), **run_grad("super", 2, 9, 51))
     np.savez(os.path.join(HERE, "csfast_grad.npz"), **run_grad("fast", 2, 8, 52))

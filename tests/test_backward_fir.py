@@ -138,10 +138,56 @@ def test_combsub_backward_golden(dev, golden_dir):
         assert rms(a.cpu().numpy() - ref) <= tol * rms(ref), (k, rms(a.cpu().numpy() - ref), rms(ref))
 
 
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("H,F", [(40, 6), (256, 5), (1, 3), (17, 1)])
+def test_sinusoid_bank_backward(dev, H, F):
+    """adjoint of the sinusoid bank w.r.t. the amplitude control: harmonic counts that are not a multiple of the
+    16-harmonic block, a single frame (the held last row takes both parts), masked harmonics above Nyquist"""
+    from ddsp_svc_amd import synth
+    B = 2
+    f0 = O.synth_f0(B, F, 44100, 512, seed=31 + H)
+    f0[0] *= 2.5
+    f0 = np.clip(f0, 65, 800).astype(np.float32)
+    (c_amp,) = O.synth_controls(B, F, [H], seed=5)
+    R = np.random.default_rng(H).standard_normal((B, F * 512)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = synth.phase(t(f0), 44100, 512)
+    c = t(c_amp).requires_grad_(True)
+    out = synth.SinusoidBankFunction.apply(t(f0), st, c, 44100, 512)
+    (out * t(R)).sum().backward()
+    x, _ = O.wrapped_phase(f0, 44100, 512)
+    want = O.sinusoid_bank_backward(R, x, f0, c_amp, 44100, 512)
+    # same documented deviation as the forward bank (no float32 rounding of k * phase) plus the rotation error
+    assert rms(c.grad.cpu().numpy() - want) <= 1e-5 * rms(want), (rms(c.grad.cpu().numpy() - want), rms(want))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_sins_backward_golden(dev, golden_dir):
+    """autograd through the Sins tail reproduces the reference's control gradients (fixture sins_grad.npz)"""
+    from ddsp_svc_amd import synth
+    g = np.load(os.path.join(golden_dir, "sins_grad.npz"))
+    keys = ("amplitudes", "group_delay", "noise_magnitude")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f0 = t(g["f0_frames"])
+    sizes = [int(v) for v in g["sizes"]]
+    packed = t(np.concatenate([g["ctrl_" + k] for k in keys], axis=-1)).requires_grad_(True)
+    views = torch.split(packed, sizes, dim=-1)
+    st = synth.phase(f0, 44100, 512)
+    sig, harm, nz = synth.sins_synth(f0, st, *views, t(g["noise"]), 44100, 512)
+    assert sig.requires_grad
+    assert rms(sig.detach().cpu().numpy() - g["signal"]) <= 1e-5 * rms(g["signal"])
+    (sig * t(g["cotangent"])).sum().backward()
+    grads = torch.split(packed.grad, sizes, dim=-1)
+    for a, k in zip(grads, keys):
+        ref = g["grad_" + k]
+        assert rms(a.cpu().numpy() - ref) <= 3e-5 * rms(ref), (k, rms(a.cpu().numpy() - ref), rms(ref))
+
+
 @pytest.mark.parametrize("dev", ["emu"], indirect=True)
-def test_combsub_module_training_step_matches_reference(dev):
-    """one backward pass through the drop-in CombSub (reference Unit2Control inside): parameter gradients equal the
-    reference module's (same weights, inputs, noise, cotangent)"""
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_combsub_module_training_step_matches_reference(dev, kind):
+    """one backward pass through the drop-in CombSub / Sins (reference Unit2Control inside): parameter gradients equal
+    the reference module's (same weights, inputs, noise, cotangent)"""
     from unittest import mock
     from unittest.mock import MagicMock
     ref_root = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
@@ -155,12 +201,13 @@ def test_combsub_module_training_step_matches_reference(dev):
         sys.modules.setdefault(name, MagicMock())
     import ddsp.vocoder as rvoc
     from ddsp_svc_amd import vocoder as V
-    ref_cls = getattr(rvoc, "_reference_CombSub", rvoc.CombSub)
+    name = "CombSub" if kind == "combsub" else "Sins"
+    ref_cls = getattr(rvoc, "_reference_" + name, getattr(rvoc, name))
     torch.manual_seed(3)
     B, F, n_unit = 2, 6, 16
-    args = (44100, 512, 65, 129, 65)
+    args = (44100, 512, 65, 129, 65) if kind == "combsub" else (44100, 512, 40, 65, 33)
     ref = ref_cls(*args, n_unit=n_unit, n_spk=1).train()
-    ours = V.CombSub(*args, n_unit=n_unit, n_spk=1).train()
+    ours = getattr(V, name)(*args, n_unit=n_unit, n_spk=1).train()
     ours.load_state_dict(ref.state_dict(), strict=True)
     for m in (ref, ours):
         for sub in m.modules():
