@@ -18,7 +18,8 @@
 // 512 - N/2, which moves the (circular, but alias-free: support <= 1023) result of block b to the output range
 // starting at (b-1) hop -- a multiple of the thread count -- so every thread only ever touches overlap-add
 // ring slots congruent to its id and the ring needs no barriers.  A run starts one pair early (discarded) so
-// the ring holds its predecessor's tail: no atomics, bit-reproducible for any run split.
+// the ring holds its predecessor's tail: no atomics, so a launch geometry is bit-reproducible (different run splits
+// agree to rounding: the first tap spectrum of a run comes out of a differently packed transform).
 #include "fft_r.h"
 #include "kernels.h"
 #include <stdlib.h>
