@@ -270,6 +270,12 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
+  size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
+  if (const char* e = getenv("DDSP_HIP_BLK_PADLDS")) pad = (size_t)atol(e);
+  if (pad > 0) {
+    hipLaunchKernelGGL(k_fir_blk<2>, dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    return 5;
+  }
   if (wps >= 4)
     hipLaunchKernelGGL(k_fir_blk<4>, dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
   else if (wps == 3)
