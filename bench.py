@@ -180,6 +180,97 @@ def bench_sinesrc(a, rank, world, device):
                      "algorithmic_bytes_per_launch": alg, "avg_ms": ms, "launches_per_step": 1}}))
 
 
+def bench_rssloss(a, rank, world, device):
+    """training loss (SURVEY.md 8-f #3): RSSLoss forward + backward w.r.t. the prediction for B x 10 s, the four
+    transform sizes fixed (a draw of torch.randint(256, 2048, (4,))); the eager composition of loss.py:22-31 on the
+    same device is timed beside it"""
+    import torch.distributed as dist
+    from ddsp_svc_amd import loss as L
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1
+    T = F * HOP
+    g = torch.Generator(device="cpu").manual_seed(99 + rank)
+    xt = (torch.randn(B, T, generator=g) * 0.1).to(device)
+    xp = (xt * 0.9 + 0.02 * torch.randn(B, T, generator=g).to(device)).requires_grad_(True)
+    sizes = [1153, 397, 2011, 768]
+    fs = [L.SSSLoss(n).to(device) for n in sizes]
+
+    def step():
+        value = 0.
+        for f in fs:
+            value = value + f(xt, xp)
+        loss = value / len(fs)
+        grad, = torch.autograd.grad(loss, xp)
+        return loss, grad
+
+    def eager():
+        value = 0.
+        for f in fs:
+            n, w = f.n_fft, f.spec.window
+            sp = lambda x: torch.stft(x, n, hop_length=n, win_length=n, window=w, center=False,
+                                      return_complex=True).abs() / w.pow(2).sum().sqrt() + 1e-7
+            St, Sp = sp(xt), sp(xp)
+            value = value + torch.mean(torch.linalg.norm(St - Sp, dim=(1, 2)) / torch.linalg.norm(St + Sp, dim=(1, 2))) \
+                + torch.nn.functional.l1_loss(St.log(), Sp.log())
+        loss = value / len(fs)
+        grad, = torch.autograd.grad(loss, xp)
+        return loss, grad
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        for _ in range(a.warmup):
+            out = fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        fence()
+        return time.perf_counter() - t0, out
+    elapsed, (loss, grad) = timed(step, a.steps)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(loss) and torch.isfinite(grad).all()
+    if rank != 0:
+        return
+    e_elapsed, (e_loss, e_grad) = timed(eager, max(2, a.steps // 4))
+    e_ms = e_elapsed / max(2, a.steps // 4) * 1e3
+    # the fused kernels' own traffic: 16 B per complex bin pair forward, 24 B backward
+    bins = sum((n // 2 + 1) * (1 + (T - n) // n) for n in sizes) * B
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    specs = [(f.spec(xt), f.spec(xp.detach())) for f in fs]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(10):
+        for f, (zt, zp) in zip(fs, specs):
+            L._SpectralLossFunction.apply(zt, zp, f.spec.inv_window_norm, f.eps, f.alpha)
+    ev[1].record()
+    torch.cuda.synchronize()
+    k_ms = ev[0].elapsed_time(ev[1]) / 10
+    ms = elapsed / a.steps * 1e3
+    print(json.dumps({
+        "metric": "audio samples/sec, RSSLoss forward+backward 44.1kHz 4 scales",
+        "value": B * world * T * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "RSSLoss(x_pred, x_true) + d/dx_pred for B=%d/GPU x %.0f s (T=%d), transform sizes %s "
+                               "(hop = size), STFT by torch.stft (rocFFT), everything behind it fused"
+                               % (B, a.seconds, T, sizes), "batch_per_gpu": B, "samples_per_utterance": T,
+                   "parallelism": "utterance-shard x%d" % world},
+        "roofline": {"kernel": "k_sss_partial + k_sss_final (4 scales)", "bound": "hbm",
+                     "achieved": 16.0 * bins / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": 16.0 * bins / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": 16.0 * bins, "avg_ms": k_ms, "launches_per_step": 1},
+        "eager_composition": {"ms_per_step": e_ms, "speedup": e_ms / ms,
+                              "loss_rel_diff": abs(float(loss) - float(e_loss)) / float(e_loss),
+                              "grad_rel_rms": float((grad - e_grad).pow(2).mean().sqrt() / e_grad.pow(2).mean().sqrt())}}))
+
+
 def bench_mel(a, rank, world, device):
     """waveform -> log-mel front-end of the cascade (SURVEY.md 8-f #2): one k_mel launch over B x 10 s of audio"""
     import multiprocessing as mp
@@ -313,7 +404,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc"])
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc", "rssloss"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -336,8 +427,8 @@ def main():
 
     from ddsp_svc_amd import _ffi, core, synth, sharding
 
-    if a.model == "sinesrc":
-        bench_sinesrc(a, rank, world, device)
+    if a.model in ("sinesrc", "rssloss"):
+        (bench_sinesrc if a.model == "sinesrc" else bench_rssloss)(a, rank, world, device)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

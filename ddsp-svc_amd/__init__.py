@@ -7,8 +7,9 @@ Sins/CombSub forward pass of yxlllc/DDSP-SVC).  Import name: ``ddsp_svc_amd`` (t
   vocoder   -- nn.Module drop-ins + patch_reference()
   mel       -- nsf_hifigan.nvSTFT.STFT.get_mel (the cascade's waveform -> log-mel front-end)
   nsf_source -- nsf_hifigan.models.SourceModuleHnNSF (SineGen + merge), the vocoder's harmonic source
+  loss      -- ddsp/loss.py SSSLoss / RSSLoss (torch.stft + fused loss kernels)
   sharding  -- utterance sharding across the GPUs of a node (+ optional RCCL gather)
 """
-from . import _ffi, build, core, mel, nsf_source, synth  # noqa: F401
+from . import _ffi, build, core, loss, mel, nsf_source, synth  # noqa: F401
 
 __version__ = "0.1.0"

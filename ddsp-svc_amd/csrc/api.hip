@@ -427,4 +427,33 @@ int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, cons
   return finish();
 }
 
+size_t ddsp_hip_spectral_loss_scratch_bytes(int B, long bins_per_utterance) {
+  if (B < 1 || bins_per_utterance < 1) return 0;
+  return sss_scratch_bytes(B, bins_per_utterance);
+}
+
+int ddsp_hip_spectral_loss(const float* spec_true, const float* spec_pred, int B, long bins_per_utterance,
+                           float inv_window_norm, float eps, float alpha, void* scratch, size_t scratch_bytes,
+                           float* norms, float* loss, void* stream) {
+  if (B < 0 || bins_per_utterance < 1 || !(inv_window_norm > 0.f)) return DDSP_HIP_EINVAL;
+  if (B == 0) return DDSP_HIP_EINVAL;                                      // a mean over nothing
+  if (!spec_true || !spec_pred || !scratch || !norms || !loss) return DDSP_HIP_EINVAL;
+  if (scratch_bytes < sss_scratch_bytes(B, bins_per_utterance)) return DDSP_HIP_EWS;
+  if (launch_sss_loss(spec_true, spec_pred, B, bins_per_utterance, inv_window_norm, eps, alpha, (double*)scratch, norms,
+                      loss, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_spectral_loss_backward(const float* spec_true, const float* spec_pred, int B, long bins_per_utterance,
+                                    const float* norms, float inv_window_norm, float eps, float alpha,
+                                    const float* grad_out, int wrt_true, float* d_spec, void* stream) {
+  if (B < 1 || bins_per_utterance < 1 || !(inv_window_norm > 0.f)) return DDSP_HIP_EINVAL;
+  if (!spec_true || !spec_pred || !norms || !grad_out || !d_spec) return DDSP_HIP_EINVAL;
+  if (launch_sss_loss_bwd(spec_true, spec_pred, B, bins_per_utterance, norms, inv_window_norm, eps, alpha, grad_out,
+                          wrt_true ? 1 : 0, d_spec, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 }  // extern "C"

@@ -59,4 +59,10 @@ int mel_frames(int T, int n_fft, int hop);
 int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
                        const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
                        float voiced_threshold, float* rad_acc, float* out, hipStream_t st);
+int sss_chunks(int B, long per_utt);
+size_t sss_scratch_bytes(int B, long per_utt);
+int launch_sss_loss(const float* xt, const float* xp, int B, long per_utt, float inv_wn, float eps, float alpha,
+                    double* scratch, float* norms, float* loss, hipStream_t st);
+int launch_sss_loss_bwd(const float* xt, const float* xp, int B, long per_utt, const float* norms, float inv_wn,
+                        float eps, float alpha, const float* grad_out, int wrt_true, float* dx, hipStream_t st);
 }  // namespace ddsp

@@ -1,0 +1,154 @@
+"""Drop-in for the training loss of the reference, ``ddsp/loss.py``: ``SSSLoss`` (:9-32) and ``RSSLoss`` (:34-54) --
+same constructors, same ``forward`` argument order (``SSSLoss(x_true, x_pred)``, ``RSSLoss(x_pred, x_true)``), same
+random draw of the transform sizes (``torch.randint``, :47).
+
+``RSSLoss`` draws arbitrary integer transform sizes, so the STFT itself stays with ``torch.stft`` (rocFFT; plumbing).
+Everything behind it -- magnitudes, the window normalisation and eps of ``Spectrogram(power=1, normalized=True)``, the
+two Frobenius norms per utterance, the log-L1 term, and in the backward pass the whole chain down to the gradient of
+the complex spectrum -- is one pass of csrc/loss.hip over the two spectra instead of ~10 eager kernels over
+``[B, bins, frames]`` temporaries."""
+import torch
+
+from . import _ffi
+from ._ffi import ptr
+
+
+def _dense_batch_major(z):
+    """True when ``z`` ([B, bins, frames] complex) occupies one dense block per utterance, utterances in order."""
+    if z.dim() != 3:
+        return False
+    per = z.shape[1] * z.shape[2]
+    inner = sorted(zip(z.stride()[1:], z.shape[1:]))
+    dense = inner[0][0] == 1 and inner[1][0] == inner[0][1]
+    return dense and (z.shape[0] == 1 or z.stride(0) == per)
+
+
+class _SpectralLossFunction(torch.autograd.Function):
+    """loss.py:22-31 behind the two STFTs."""
+
+    @staticmethod
+    def forward(ctx, spec_true, spec_pred, inv_window_norm, eps, alpha):
+        _ffi.check_device(spec_true, spec_pred)
+        if spec_true.shape != spec_pred.shape or spec_true.dim() != 3:
+            raise ValueError("the two spectrograms must have the same [B, bins, frames] shape")
+        st, sp = spec_true.detach(), spec_pred.detach()
+        if st.dtype != torch.complex64 or sp.dtype != torch.complex64:
+            st, sp = st.to(torch.complex64), sp.to(torch.complex64)
+        if not (_dense_batch_major(st) and st.stride() == sp.stride()):
+            st, sp = st.contiguous(), sp.contiguous()
+        B = st.shape[0]
+        per = st.shape[1] * st.shape[2]
+        lib = _ffi.lib()
+        dev = st.device
+        nbytes = lib.ddsp_hip_spectral_loss_scratch_bytes(B, per)
+        scratch = torch.empty(max(nbytes, 8) // 8, dtype=torch.float64, device=dev)
+        norms = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _ffi.check(lib.ddsp_hip_spectral_loss(ptr(st), ptr(sp), B, per, float(inv_window_norm), float(eps), float(alpha),
+                                              ptr(scratch), nbytes, ptr(norms), ptr(loss), _ffi.stream_of(st)))
+        ctx.save_for_backward(st, sp, norms)
+        ctx.cfg = (float(inv_window_norm), float(eps), float(alpha))
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        st, sp, norms = ctx.saved_tensors
+        inv_wn, eps, alpha = ctx.cfg
+        B = st.shape[0]
+        per = st.shape[1] * st.shape[2]
+        go = grad_out.detach().to(torch.float32).contiguous()
+        lib = _ffi.lib()
+        grads = [None, None]
+        for which in (0, 1):                                         # 0: true, 1: pred
+            if not ctx.needs_input_grad[which]:
+                continue
+            d = torch.empty_like(sp)                                 # same dense layout as the saved spectra
+            _ffi.check(lib.ddsp_hip_spectral_loss_backward(ptr(st), ptr(sp), B, per, ptr(norms), inv_wn, eps, alpha,
+                                                           ptr(go), 1 if which == 0 else 0, ptr(d),
+                                                           _ffi.stream_of(sp)))
+            grads[which] = d
+        return grads[0], grads[1], None, None, None
+
+
+class Spectrogram(torch.nn.Module):
+    """``torchaudio.transforms.Spectrogram(n_fft, hop_length=, power=None, center=False)`` as SSSLoss configures it
+    (loss.py:20), returning the COMPLEX spectrum: the ``power=1`` magnitude and the ``normalized=True`` division by
+    ``||window||_2`` are applied inside the fused loss kernel."""
+
+    def __init__(self, n_fft, hop_length):
+        super().__init__()
+        self.n_fft = int(n_fft)
+        self.hop_length = int(hop_length)
+        self.register_buffer("window", torch.hann_window(self.n_fft))      # periodic Hann, torchaudio's default
+
+    @property
+    def inv_window_norm(self):
+        return 1.0 / float(self.window.double().pow(2).sum().sqrt())
+
+    def forward(self, x):
+        shape = x.shape
+        z = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, hop_length=self.hop_length, win_length=self.n_fft,
+                       window=self.window, center=False, normalized=False, onesided=True, return_complex=True)
+        return z
+
+
+class SSSLoss(torch.nn.Module):
+    """Single-scale spectral loss, loss.py:9-32."""
+
+    def __init__(self, n_fft=111, alpha=1.0, overlap=0, eps=1e-7):
+        super().__init__()
+        self.n_fft = n_fft
+        self.alpha = alpha
+        self.eps = eps
+        self.hop_length = int(n_fft * (1 - overlap))                 # loss.py:19
+        self.spec = Spectrogram(self.n_fft, self.hop_length)
+
+    def forward(self, x_true, x_pred):
+        _ffi.check_device(x_true, x_pred)
+        if x_true.shape != x_pred.shape:
+            raise ValueError("x_true and x_pred must have the same shape")
+        x_true = x_true.reshape(-1, x_true.shape[-1]) if x_true.dim() != 2 else x_true
+        x_pred = x_pred.reshape(-1, x_pred.shape[-1]) if x_pred.dim() != 2 else x_pred
+        return _SpectralLossFunction.apply(self.spec(x_true.to(torch.float32)), self.spec(x_pred.to(torch.float32)),
+                                           self.spec.inv_window_norm, self.eps, self.alpha)
+
+
+class RSSLoss(torch.nn.Module):
+    """Random-scale spectral loss, loss.py:34-54.  The per-size modules are built on first use rather than all
+    ``fft_max - fft_min`` of them up front (loss.py:44-45 holds ~1800 window buffers); ``lossdict`` fills as sizes are
+    drawn."""
+
+    def __init__(self, fft_min, fft_max, n_scale, alpha=1.0, overlap=0, eps=1e-7, device="cuda"):
+        super().__init__()
+        self.fft_min = fft_min
+        self.fft_max = fft_max
+        self.n_scale = n_scale
+        self.alpha, self.overlap, self.eps, self.device = alpha, overlap, eps, device
+        self.lossdict = {}
+
+    def _scale(self, n_fft, device):
+        f = self.lossdict.get(n_fft)
+        if f is None:
+            f = self.lossdict[n_fft] = SSSLoss(n_fft, self.alpha, self.overlap, self.eps).to(device)
+        return f
+
+    def forward(self, x_pred, x_true):
+        value = 0.
+        n_ffts = torch.randint(self.fft_min, self.fft_max, (self.n_scale,))      # loss.py:47, CPU generator
+        for n_fft in n_ffts:
+            value = value + self._scale(int(n_fft), x_pred.device)(x_true, x_pred)
+        return value / self.n_scale
+
+
+def patch_reference_loss():
+    """Rebind ``SSSLoss`` / ``RSSLoss`` of an importable reference checkout (``ddsp.loss`` and the name ``train.py``
+    imported at :7) to the classes above."""
+    import sys
+    import ddsp.loss as dl
+    if not hasattr(dl, "_reference_RSSLoss"):
+        dl._reference_SSSLoss, dl._reference_RSSLoss = dl.SSSLoss, dl.RSSLoss
+    dl.SSSLoss, dl.RSSLoss = SSSLoss, RSSLoss
+    tr = sys.modules.get("train")
+    if tr is not None and hasattr(tr, "RSSLoss"):
+        tr.RSSLoss = RSSLoss
+    return dl

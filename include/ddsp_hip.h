@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 120          /* 0.1.2: + CombSubFast / CombSubSuperFast, hop-block FIR, log-mel front-end */
+#define DDSP_HIP_VERSION 130          /* 0.1.3: + adjoints, NSF source, spectral loss */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -228,6 +228,25 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
 int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini,
                          const float* noise, const float* weight, const float* bias, int dim, float sine_amp,
                          float noise_std, float voiced_threshold, float* rad_acc, float* out, void* stream);
+
+/* ---- spectral loss of the training loop (ddsp/loss.py:9-54) ---- */
+
+/* SSSLoss.forward behind the STFT (loss.py:22-31).  spec_true / spec_pred: the complex STFTs of the two signals
+ * (interleaved re, im; any dense layout with the utterance outermost, the SAME layout for both),
+ * bins_per_utterance complex values each; S = |X| inv_window_norm + eps (Spectrogram(power=1, normalized=True),
+ * loss.py:20); loss[0] = mean_b ||St - Sp||_F / ||St + Sp||_F + alpha mean |log St - log Sp|.  norms[B][2]
+ * receives the two Frobenius norms per utterance (input of the backward call); scratch of
+ * ddsp_hip_spectral_loss_scratch_bytes(B, bins_per_utterance) bytes.  RSSLoss (loss.py:34-54) calls this once per
+ * randomly drawn transform size. */
+size_t ddsp_hip_spectral_loss_scratch_bytes(int B, long bins_per_utterance);
+int ddsp_hip_spectral_loss(const float* spec_true, const float* spec_pred, int B, long bins_per_utterance,
+                           float inv_window_norm, float eps, float alpha, void* scratch, size_t scratch_bytes,
+                           float* norms, float* loss, void* stream);
+/* d loss / d spec (complex: dRe + i dIm, interleaved, same layout) of the predicted (wrt_true = 0) or the true
+ * (1) spectrum, times the upstream gradient grad_out[0] (device scalar). */
+int ddsp_hip_spectral_loss_backward(const float* spec_true, const float* spec_pred, int B, long bins_per_utterance,
+                                    const float* norms, float inv_window_norm, float eps, float alpha,
+                                    const float* grad_out, int wrt_true, float* d_spec, void* stream);
 
 #ifdef __cplusplus
 }

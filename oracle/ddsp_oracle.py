@@ -714,3 +714,56 @@ def sinusoid_bank_backward(grad_out, x, f0_frames, amp_ctrl, sr: float, hop: int
         dA[:, 1:, h0:h0 + 16] += R1[:, :-1]
         dA[:, -1, h0:h0 + 16] += R1[:, -1]
     return dA * A
+
+
+# --------------------------------------------------------------------------------------
+# spectral loss of the training loop: ddsp/loss.py:9-54
+# --------------------------------------------------------------------------------------
+def _sss_spectra(x, n_fft: int, hop: int):
+    """torchaudio.transforms.Spectrogram(n_fft, hop_length=hop, power=None, center=False) as loss.py:20 configures it
+    (torchaudio 0.x/2.x functional.spectrogram: periodic Hann window of n_fft, frames every hop from sample 0, no
+    padding, one-sided rfft).  torchaudio is absent from this container: its published semantics are restated here
+    (and in the stand-in tests/golden/make_golden.py installs to run the reference's SSSLoss) -- parity unpinned
+    for that one library call."""
+    x = np.asarray(x, F64)
+    B, T = x.shape
+    n_frames = 1 + (T - n_fft) // hop
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)
+    X = np.fft.rfft(x[:, idx] * window, axis=-1)                   # [B, frames, bins]
+    return X, window, idx
+
+
+def sss_loss(x_true, x_pred, n_fft: int, alpha: float = 1.0, overlap: float = 0.0, eps: float = 1e-7) -> float:
+    """SSSLoss.forward (loss.py:22-31)."""
+    hop = int(n_fft * (1 - overlap))                                # loss.py:19
+    Xt, window, _ = _sss_spectra(x_true, n_fft, hop)
+    Xp, _, _ = _sss_spectra(x_pred, n_fft, hop)
+    wn = np.sqrt((window ** 2).sum())                              # normalized=True -> "window" normalisation
+    St, Sp = np.abs(Xt) / wn + eps, np.abs(Xp) / wn + eps           # loss.py:23-24
+    conv = np.mean(np.sqrt(((St - Sp) ** 2).sum((1, 2))) / np.sqrt(((St + Sp) ** 2).sum((1, 2))))   # :26
+    log_term = np.mean(np.abs(np.log(St) - np.log(Sp)))             # :28
+    return float(conv + alpha * log_term)                           # :30
+
+
+def sss_loss_backward(x_true, x_pred, n_fft: int, alpha: float = 1.0, overlap: float = 0.0, eps: float = 1e-7):
+    """d SSSLoss / d x_pred, analytically (what autograd returns for loss.py:22-31)."""
+    hop = int(n_fft * (1 - overlap))
+    Xt, window, idx = _sss_spectra(x_true, n_fft, hop)
+    Xp, _, _ = _sss_spectra(x_pred, n_fft, hop)
+    wn = np.sqrt((window ** 2).sum())
+    At, Ap = np.abs(Xt), np.abs(Xp)
+    St, Sp = At / wn + eps, Ap / wn + eps
+    B = St.shape[0]
+    d, s = St - Sp, St + Sp
+    nd = np.sqrt((d ** 2).sum((1, 2)))[:, None, None]
+    ns = np.sqrt((s ** 2).sum((1, 2)))[:, None, None]
+    g = (-d / (nd * ns) - nd * s / ns ** 3) / B - alpha * np.sign(np.log(St) - np.log(Sp)) / (Sp * St.size)
+    G = np.where(Ap > 0, g / wn * Xp / np.where(Ap > 0, Ap, 1.0), 0.0)          # dRe + i dIm
+    full = np.zeros(G.shape[:-1] + (n_fft,), np.complex128)
+    full[..., :G.shape[-1]] = G
+    dframes = (np.fft.ifft(full, axis=-1) * n_fft).real * window   # x_n enters X_k through exp(-i 2 pi k n / n_fft)
+    dx = np.zeros(np.asarray(x_pred).shape, F64)
+    for b in range(B):
+        np.add.at(dx[b], idx, dframes[b])
+    return dx

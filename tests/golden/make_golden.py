@@ -15,6 +15,8 @@ Fixtures (all float32 unless noted):
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
   mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
   sinesrc.npz       nsf_hifigan.models.SourceModuleHnNSF.forward with its two random draws injected  models.py:140-204
+  sssloss.npz       ddsp.loss.SSSLoss / RSSLoss forward + autograd w.r.t. x_pred, with a torch.stft stand-in for the absent
+                    torchaudio.transforms.Spectrogram (documented semantics restated)                  loss.py:9-54
   *_grad.npz        autograd of Sins / CombSub / CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
                     for a random cotangent R: d(sum(signal * R)) / d ctrl
 """
@@ -42,8 +44,63 @@ def import_reference():
     return core, vocoder
 
 
+class SpectrogramStandIn(torch.nn.Module):
+    """torchaudio.transforms.Spectrogram as ddsp/loss.py:20 uses it (torchaudio is not installed here): periodic Hann
+    window of n_fft, torch.stft without centring or padding, one-sided, ``normalized=True`` = division by the
+    window's L2 norm, ``power=1`` = magnitude  (torchaudio/functional/functional.py, spectrogram())."""
+
+    def __init__(self, n_fft, hop_length, power, normalized, center):
+        super().__init__()
+        assert power == 1 and normalized is True and center is False
+        self.n_fft, self.hop_length = n_fft, hop_length
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, x):
+        z = torch.stft(x, self.n_fft, hop_length=self.hop_length, win_length=self.n_fft, window=self.window,
+                       center=False, normalized=False, onesided=True, return_complex=True)
+        return (z / self.window.pow(2.).sum().sqrt()).abs()
+
+
+def loss_fixture():
+    """ddsp/loss.py run as is, on top of the Spectrogram stand-in."""
+    import_reference()
+    sys.modules["torchaudio"].transforms.Spectrogram = SpectrogramStandIn
+    sys.modules.pop("ddsp.loss", None)
+    import ddsp.loss as L
+    g = torch.Generator().manual_seed(71)
+    t = torch.arange(6000) / 44100.0
+    tone = sum(0.2 / k * torch.sin(2 * np.pi * 196.0 * k * t + 0.7 * k) for k in range(1, 20))
+    x_true = torch.stack([tone + 0.02 * torch.randn(6000, generator=g), 0.1 * torch.randn(6000, generator=g),
+                          torch.roll(tone, 37) * 0.5])
+    x_pred = x_true * 0.8 + 0.05 * torch.randn(3, 6000, generator=g)
+    x_pred[2, 1000:1400] = 0.0
+    out = {"x_true": x_true.numpy(), "x_pred": x_pred.numpy()}
+    cases = [(111, 1.0, 0.0), (256, 1.0, 0.75), (777, 0.5, 0.0), (2047, 1.0, 0.0), (1024, 1.0, 0.5)]
+    out["cases"] = np.array(cases, np.float64)
+    for i, (n_fft, alpha, overlap) in enumerate(cases):
+        f = L.SSSLoss(int(n_fft), alpha, overlap)
+        xp = x_pred.clone().requires_grad_(True)
+        loss = f(x_true, xp)
+        loss.backward()
+        out[f"loss{i}"] = loss.detach().numpy()
+        out[f"grad{i}"] = xp.grad.numpy()
+    torch.manual_seed(72)
+    rss = L.RSSLoss(256, 300, 4, device="cpu")
+    drawn = torch.randint(256, 300, (4,), generator=torch.Generator().manual_seed(73))
+    with mock.patch("torch.randint", side_effect=lambda *a, **k: drawn):
+        xp = x_pred.clone().requires_grad_(True)
+        loss = rss(xp, x_true)
+        loss.backward()
+    out["rss_sizes"] = drawn.numpy()
+    out["rss_loss"] = loss.detach().numpy()
+    out["rss_grad"] = xp.grad.numpy()
+    np.savez(os.path.join(HERE, "sssloss.npz"), **out)
+
+
 def main():
     from oracle import ddsp_oracle as O
+    if "--only-loss" in sys.argv:
+        return loss_fixture()
     core, V = import_reference()
     torch.manual_seed(0)
     sr, hop = 44100, 512
@@ -320,6 +377,8 @@ def main():
             mel = stft.get_mel(y)
             np.savez(os.path.join(HERE, f"mel_{tag}.npz"), audio=y.numpy(), mel=mel.numpy(),
                      basis=basis if tag == "a" else np.zeros(0, np.float32))
+
+    loss_fixture()
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
