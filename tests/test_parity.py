@@ -170,6 +170,41 @@ def test_impulse_response_odd_sizes(dev, n_mag, rows):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("n_mag,rows,per", [(256, 1, 0), (256, 65, 0), (244, 130, 3), (248, 200, 2), (241, 70, 0), (256, 64 * 5, 4),
+                                             (256, 191, 1)])
+def test_impulse_response_tile_runs(dev, n_mag, rows, per, monkeypatch):
+    """the pipelined tile-run kernel of the 256-bin tables (k_ir_gemm_p): partial row tiles, runs of 1..4 tiles per
+    workgroup incl. an odd count (column halves of a row tile split across workgroups), all window modes, real
+    (with the exp activation fused) and complex responses"""
+    from ddsp_svc_amd import _ffi, core
+    if per:
+        monkeypatch.setenv("DDSP_HIP_GEMM_PER", str(per))
+    rng = np.random.default_rng(n_mag + rows)
+    re = rng.standard_normal((1, rows, n_mag)).astype(np.float32)
+    im = rng.standard_normal((1, rows, n_mag)).astype(np.float32)
+    hw = (rng.random((1, rows)) * 300 + 20).astype(np.float32)
+    z = torch.complex(T_(re, dev), T_(im, dev))
+    mag = T_(np.exp(re), dev)
+    hwt = T_(hw, dev).unsqueeze(-1)
+    for mode, kw in ((O.MODE_ROLL, dict(hann_window=False)), (O.MODE_HANN, dict()),
+                     (O.MODE_DYNAMIC, dict(half_width_frames=hwt))):
+        ref = O.impulse_response(re, im, mode, hw)
+        assert rms(N_(core.frequency_impulse_response(z, **kw)) - ref) <= 2e-6 * max(rms(ref), 1e-3), mode
+        ref = O.impulse_response(np.exp(re.astype(np.float64)), None, mode, hw)
+        assert rms(N_(core.frequency_impulse_response(mag, **kw)) - ref) <= 2e-6 * max(rms(ref), 1e-3), mode
+    # raw control with the activation fused into the operand staging (what the synthesiser calls)
+    N = 2 * (n_mag - 1)
+    ctrl = T_(re[0], dev)
+    taps = torch.empty(rows, N, dtype=torch.float32, device=ctrl.device)
+    tab = core.ir_table(n_mag, ctrl.device)
+    _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ctrl.data_ptr(), n_mag, None, 0, _ffi.ACT_EXP, 1.0 / 128, _ffi.MODE_HANN,
+                                                    None, rows, n_mag, tab.data_ptr(), taps.data_ptr(),
+                                                    _ffi.stream_of(ctrl)))
+    ref = O.impulse_response(np.exp(re.astype(np.float64)) / 128, None, O.MODE_HANN)[0]
+    assert rms(N_(taps) - ref) <= 2e-6 * max(rms(ref), 1e-3)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_allpass_response(dev):
     from ddsp_svc_amd import _ffi
     rng = np.random.default_rng(8)
