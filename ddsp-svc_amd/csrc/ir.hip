@@ -9,8 +9,6 @@
 // and the roll + window + mirror (real responses give symmetric taps, so only m = 0..N/2 is
 // contracted) fused into the epilogue.
 #include "ddsp_common.h"
-#include <stdlib.h>
-#include <type_traits>
 
 namespace ddsp {
 
@@ -347,261 +345,6 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same contraction for 241 <= n_mag <= 256 (KP = NP = 256: the shipped models), as a PIPELINED run of tiles.
-// In k_ir_gemm every workgroup of the launch is resident at once, so all of them contract at the same time (the
-// MFMA pipe is contended, HBM idle) and then all of them store at the same time (HBM write-bound, the MFMA pipe
-// idle).  Here a workgroup walks `per` consecutive 64 x 128 tiles (the two column halves of a row tile are
-// neighbours, so the second pass finds its control rows in L2) and the finished accumulators of tile i are
-// stored WHILE tile i+1 is contracted: one accumulator register -- 8 (mirrored) stores per lane -- after the
-// global loads of each chunk group, so the loads never queue behind the stores they share a counter with.
-// Waves: 2 x 2, each 32 rows x 64 columns = 2 accumulators of 32x32.  Only the last tile of a workgroup stores in
-// the open.
-// ------------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DDSP_OPAQUE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#else
-#define DDSP_OPAQUE4(a, b, c, d) ((void)0)
-#endif
-constexpr int PM = 64, PN = 128;
-constexpr int P_LDB = PN + 4;
-constexpr int P_STAGE = PM * LDA + KC * P_LDB;
-
-template <int ACT, bool HAS_IM, int MODE>
-__global__ void __launch_bounds__(256, 2) k_ir_gemm_p(const float* __restrict__ a_re, long ld_re,
-                                                   const float* __restrict__ a_im, long ld_im, float scale,
-                                                   const float* __restrict__ table,
-                                                   const float* __restrict__ half_width, long rows, int n,
-                                                   float* __restrict__ taps, int tiles, int per) {
-  __shared__ __attribute__((aligned(16))) float stage[2 * P_STAGE];
-  constexpr int NCH = 16;                                       // k chunks per plane (KP = 256)
-  constexpr int TOT = HAS_IM ? 2 * NCH : NCH;                   // chunks per tile
-  constexpr int CPG = TOT / 16;                                 // chunks per store group
-  constexpr long NP = 256, PLANE = 256 * NP;
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wcg = wave & 1;                     // row block / 64-column group of the wave
-  const int l = tid & 63;
-  const int li = l & 31, h = l >> 5;
-  const int N = 2 * (n - 1);
-  const int half = N / 2;
-  const float* hann = table + 2 * PLANE;
-  const int t_first = blockIdx.x * per;
-  int t_last = t_first + per;
-  if (t_last > tiles) t_last = tiles;
-  if (t_first >= t_last) return;
-
-  const int a_row = tid >> 2, a_kq = (tid & 3) * 4;
-  const int b_k = tid >> 5, b_c4 = (tid & 31) * 4;
-  struct Chunk { float4 a, b0, b1; };
-
-  // branch-free: rows past the end are read from the last row and zeroed when parked (n is a multiple of 4 and the
-  // operands are 16-byte aligned -- the launcher's condition for this kernel -- so a quad of k is all in or all out).
-  // Addresses are a workgroup-uniform base plus a 32-bit lane offset, so none of them occupies a register pair.
-  const unsigned b_lane = (unsigned)(b_k * (int)NP + b_c4);           // unsigned: uniform base + 32-bit lane offset addressing
-  auto fetch = [&](int t, int cc) -> Chunk {
-    const long row0 = (long)(t >> 1) * PM;
-    const int col0 = (t & 1) * PN;
-    const int part = (HAS_IM && cc >= NCH) ? 1 : 0;
-    const int k0 = (cc - part * NCH) * KC;
-    const float* A = (part ? a_im : a_re) + row0 * (part ? ld_im : ld_re);
-    const int ld = (int)(part ? ld_im : ld_re);
-    long left = rows - 1 - row0;                          // last valid row of the tile, relative
-    const int rr = a_row < left ? a_row : (int)left;
-    int k = k0 + a_kq;
-    if (k + 3 >= n) k = n - 4;
-    Chunk c;
-    c.a = *reinterpret_cast<const float4*>(A + (unsigned)(rr * ld + k));
-    const float* Tb = table + ((part ? PLANE : 0) + (long)k0 * NP + col0);
-    c.b0 = *reinterpret_cast<const float4*>(Tb + b_lane);
-    c.b1 = *reinterpret_cast<const float4*>(Tb + (b_lane + 8u * (unsigned)NP));
-    return c;
-  };
-  auto park = [&](int buf, int t, int cc, const Chunk& c) {
-    float* As = stage + buf * P_STAGE;
-    float* Bs = As + PM * LDA;
-    const int part = (HAS_IM && cc >= NCH) ? 1 : 0;
-    const int k = (cc - part * NCH) * KC + a_kq;
-    const bool live = (long)(t >> 1) * PM + a_row < rows;
-    float4 v;
-    v.x = (live && k < n) ? ir_activate<ACT>(c.a.x, scale) : 0.f;
-    v.y = (live && k + 1 < n) ? ir_activate<ACT>(c.a.y, scale) : 0.f;
-    v.z = (live && k + 2 < n) ? ir_activate<ACT>(c.a.z, scale) : 0.f;
-    v.w = (live && k + 3 < n) ? ir_activate<ACT>(c.a.w, scale) : 0.f;
-    *reinterpret_cast<float4*>(As + a_row * LDA + a_kq) = v;
-    *reinterpret_cast<float4*>(Bs + b_k * P_LDB + b_c4) = c.b0;
-    *reinterpret_cast<float4*>(Bs + (b_k + 8) * P_LDB + b_c4) = c.b1;
-  };
-  auto contract = [&](int buf, f32x16 (&acc)[2]) {
-    const float* As = stage + buf * P_STAGE;
-    const float* Bs = As + PM * LDA;
-    const float4 lo = *reinterpret_cast<const float4*>(As + (wr * 32 + li) * LDA + 8 * h);
-    const float4 hi = *reinterpret_cast<const float4*>(As + (wr * 32 + li) * LDA + 8 * h + 4);
-    const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const float* bp = Bs + (8 * h) * P_LDB + wcg * 64 + li;
-    float bv[8][2];
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) {
-      bv[sidx][0] = bp[sidx * P_LDB];
-      bv[sidx][1] = bp[sidx * P_LDB + 32];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx][1], acc[1], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);                  // the activation of the next chunk stays behind the MFMAs:
-                                                        // hoisted, it would wait for its load -- and every store -- at once
-  };
-
-  // The parked tile: a finished FULL tile whose stores ride along with the next one's contraction.  Its stores are
-  // unconditional straight-line code between the chunk's global loads and its MFMAs -- a store behind a per-lane
-  // or per-tile branch makes the wait for the loads conservative (the counter is shared), i.e. a wait for the stores.
-  f32x16 pE[2], pO[2];
-  long p_row0 = 0;
-  int p_jcol[2][2];
-  bool p_flip[2][2];
-  float p_wcol[2][2];
-  bool p_valid = false;
-  auto tile_row = [&](long row0, int reg) -> long { return row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h; };
-  auto load_hw = [&](long row0, int reg) -> float {
-    if (MODE != IR_MODE_DYNAMIC) return 1.f;
-    long r = tile_row(row0, reg);
-    if (r >= rows) r = rows - 1;
-    return half_width[r];
-  };
-  auto window = [&](int j, float wc_, float hw) -> float {
-    if (MODE != IR_MODE_DYNAMIC) return wc_;
-    float u = (float)(j - half) / hw;                   // core.py:244
-    if (u > 1.0f) u = 0.0f;                             // core.py:245
-    return (1.0f + cos_turns(kPiF * u)) / 2.0f;         // core.py:246
-  };
-  // column rules of a tile (same as the epilogue of k_ir_gemm): output column of either mirror side, -1 = nothing
-  // to store; on full tiles the two columns without a partner store their one value twice instead
-  auto column_rules = [&](int col0, bool full, int (&jcol)[2][2], bool (&flip)[2][2], float (&wcol)[2][2]) {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int m = col0 + wcg * 64 + cb * 32 + li;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const bool ok = m <= half && (side == 0 ? m < half : m >= 1);
-        int j = side == 0 ? half + m : half - m;
-        flip[cb][side] = false;
-        if (!ok) {
-          if (full) { j = side == 0 ? half - m : half + m; flip[cb][side] = true; }
-          else j = -1;
-        }
-        jcol[cb][side] = j;
-        wcol[cb][side] = (MODE == IR_MODE_HANN && j >= 0) ? hann[j] : 1.f;
-      }
-    }
-  };
-  // one accumulator register of the parked tile: 4 stores per lane, no conditions; uniform row base + lane offset
-  auto emit_parked = [&](int reg, float hw) {
-    float* dst = taps + (p_row0 + (reg & 3) + 8 * (reg >> 2)) * (long)N;
-    const int lane_row = (wr * 32 + 4 * h) * N;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const float E = pE[cb][reg], O = HAS_IM ? pO[cb][reg] : 0.f;
-        const bool minus = (side == 1) != p_flip[cb][side];
-        const int j = p_jcol[cb][side];
-        dst[(unsigned)(lane_row + j)] = (minus ? E - O : E + O) * window(j, p_wcol[cb][side], hw);
-      }
-  };
-
-  f32x16 accE[2], accO[2];
-  // K loop of tile t; EMIT: the parked tile's stores ride along, one accumulator register per chunk group
-  auto run_tile = [&](int t, auto emit_tag) {
-    constexpr bool EMIT = decltype(emit_tag)::value;
-    Chunk nx;
-    float hw_cur = EMIT ? load_hw(p_row0, 0) : 1.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      float hw_nxt = 1.f;
-#pragma unroll
-      for (int c = 0; c < CPG; ++c) {
-        const int cc = g * CPG + c;
-        const bool last = cc == TOT - 1;
-        const bool more = !last || t + 1 < t_last;
-        if (more) nx = last ? fetch(t + 1, 0) : fetch(t, cc + 1);
-        if (EMIT && c == 0) {
-          if (g < 15) hw_nxt = load_hw(p_row0, g + 1);
-          __builtin_amdgcn_sched_barrier(0);            // loads first: they must not queue behind the stores
-          emit_parked(g, hw_cur);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (HAS_IM && cc >= NCH) contract(cc & 1, accO);
-        else contract(cc & 1, accE);
-        // the control values become visible to the compiler only here, behind the MFMAs: their activation,
-        // hoisted to the load, would wait for it -- and for every store issued before it -- on the spot
-        DDSP_OPAQUE4(nx.a.x, nx.a.y, nx.a.z, nx.a.w);
-        if (more) park((cc + 1) & 1, last ? t + 1 : t, last ? 0 : cc + 1, nx);
-        __syncthreads();
-      }
-      hw_cur = hw_nxt;
-    }
-  };
-
-  {
-    const Chunk first = fetch(t_first, 0);
-    park(0, t_first, 0, first);
-  }
-  __syncthreads();
-  for (int t = t_first; t < t_last; ++t) {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { accE[cb][i] = 0.f; accO[cb][i] = 0.f; }
-    if (p_valid) run_tile(t, std::true_type{});
-    else run_tile(t, std::false_type{});
-    const long row0 = (long)(t >> 1) * PM;
-    const int col0 = (t & 1) * PN;
-    const bool full = row0 + PM <= rows && col0 + PN - 1 <= half;            // workgroup-uniform
-    if (full) {
-      // park it: accumulators, row origin, column rules
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) { pE[cb] = accE[cb]; pO[cb] = accO[cb]; }
-      p_row0 = row0;
-      p_valid = true;
-      column_rules(col0, true, p_jcol, p_flip, p_wcol);
-    } else {
-      // a partial tile (the last rows) stores in the open, masked
-      p_valid = false;
-      int jcol[2][2];
-      bool flip[2][2];
-      float wcol[2][2];
-      column_rules(col0, false, jcol, flip, wcol);
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const long r = tile_row(row0, reg);
-        if (r >= rows) continue;
-        const float hw = load_hw(row0, reg);
-        float* dst = taps + r * (long)N;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const int j = jcol[cb][side];
-            if (j < 0) continue;
-            const float E = accE[cb][reg], O = HAS_IM ? accO[cb][reg] : 0.f;
-            dst[j] = (side == 1 ? E - O : E + O) * window(j, wcol[cb][side], hw);
-          }
-      }
-    }
-  }
-  // the last full tile of the run stores in the open
-  if (p_valid) {
-    float hws[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) hws[reg] = load_hw(p_row0, reg);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) emit_parked(reg, hws[reg]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Adjoint of the tap synthesis: d_taps [rows, N] -> gradient of the one-sided response (or of the raw control
 // through the exp activation).  With dE[m] = w+ dt[N/2 + m] + w- dt[N/2 - m] and dO[m] = w+ dt[N/2 + m] - w- dt[N/2 - m]
 // (window factors of the two taps a bin pair feeds; m = 0 and m = N/2 have one tap only)
@@ -830,35 +573,6 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
   dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)(ir_np(n) / GN)), block(256);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int vec = (al16(a_re) && (ld_re & 3) == 0 && (!a_im || (al16(a_im) && (ld_im & 3) == 0))) ? 1 : 0;
-  // pipelined tile runs for the 256-bin tables (k_ir_gemm_p): at most two resident workgroups per CU, each with an
-  // even number of consecutive tiles once there is more than one tile per workgroup
-  static const int use_v1 = getenv("DDSP_HIP_GEMM_V1") ? 1 : 0;
-  if (!use_v1 && vec && (n & 3) == 0 && ir_kp(n) == 256 && ir_np(n) == 256 && rows < (1L << 24) &&
-      !(a_im && act == IR_ACT_EXP)) {
-    const int tiles = (int)((rows + PM - 1) / PM) * 2;
-    int per = (tiles + 511) / 512;
-    if (per > 1) per += per & 1;
-    if (const char* e = getenv("DDSP_HIP_GEMM_PER")) { int v = atoi(e); if (v >= 1) per = v; }
-    const dim3 pgrid((unsigned)((tiles + per - 1) / per));
-#define DDSP_IRP_LAUNCH(ACT_, IM_, MODE_)                                                                          \
-  hipLaunchKernelGGL((k_ir_gemm_p<ACT_, IM_, MODE_>), pgrid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, \
-                     half_width, rows, n, taps, tiles, per)
-#define DDSP_IRP_MODES(ACT_, IM_)                                              \
-  do {                                                                         \
-    if (mode == IR_MODE_HANN) DDSP_IRP_LAUNCH(ACT_, IM_, IR_MODE_HANN);        \
-    else if (mode == IR_MODE_DYNAMIC) DDSP_IRP_LAUNCH(ACT_, IM_, IR_MODE_DYNAMIC); \
-    else DDSP_IRP_LAUNCH(ACT_, IM_, IR_MODE_ROLL);                             \
-  } while (0)
-    if (a_im) {
-      DDSP_IRP_MODES(IR_ACT_NONE, true);
-    } else {
-      if (act == IR_ACT_EXP) DDSP_IRP_MODES(IR_ACT_EXP, false);
-      else DDSP_IRP_MODES(IR_ACT_NONE, false);
-    }
-#undef DDSP_IRP_MODES
-#undef DDSP_IRP_LAUNCH
-    return;
-  }
 #define DDSP_IR_LAUNCH(ACT_, IM_, MODE_)                                                                          \
   hipLaunchKernelGGL((k_ir_gemm<ACT_, IM_, MODE_>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, \
                      half_width, rows, n, taps, vec)

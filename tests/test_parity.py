@@ -170,15 +170,11 @@ def test_impulse_response_odd_sizes(dev, n_mag, rows):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("n_mag,rows,per", [(256, 1, 0), (256, 65, 0), (244, 130, 3), (248, 200, 2), (241, 70, 0), (256, 64 * 5, 4),
-                                             (256, 191, 1)])
-def test_impulse_response_tile_runs(dev, n_mag, rows, per, monkeypatch):
-    """the pipelined tile-run kernel of the 256-bin tables (k_ir_gemm_p): partial row tiles, runs of 1..4 tiles per
-    workgroup incl. an odd count (column halves of a row tile split across workgroups), all window modes, real
-    (with the exp activation fused) and complex responses"""
+@pytest.mark.parametrize("n_mag,rows", [(256, 1), (256, 65), (244, 130), (248, 200), (241, 70), (256, 64 * 5), (256, 191)])
+def test_impulse_response_row_tiles(dev, n_mag, rows):
+    """the 256-column table: partial and multiple row tiles, all window modes, real (with the exp activation fused)
+    and complex responses"""
     from ddsp_svc_amd import _ffi, core
-    if per:
-        monkeypatch.setenv("DDSP_HIP_GEMM_PER", str(per))
     rng = np.random.default_rng(n_mag + rows)
     re = rng.standard_normal((1, rows, n_mag)).astype(np.float32)
     im = rng.standard_normal((1, rows, n_mag)).astype(np.float32)

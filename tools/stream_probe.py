@@ -83,6 +83,26 @@ def timeit(fn, reps=30):
     return round(e0.elapsed_time(e1) / reps, 4)
 
 
+def fused_order(bufs):
+    """the kernel order of ddsp_hip_combsub_synth on one stream, with the given buffer assignment"""
+    s = main.cuda_stream
+    re_, im_, ta, tb, tc, cmb, hh, sig = bufs
+    ck(L.ddsp_hip_allpass_response(p(c_gd), ld, rows, n, p(re_), p(im_), s))
+    ck(L.ddsp_hip_impulse_response(p(re_), n, p(im_), n, 0, 1.0, 0, None, rows, n, p(tab), p(ta), s))
+    ck(L.ddsp_hip_combtooth(p(f0), None, p(state.phase0), B, F, HOP, float(SR), 1, p(cmb), s))
+    ck(L.ddsp_hip_fft_convolve(p(cmb), 0, p(ta), None, p(hh), None, B, F, HOP, N, 0, s))
+    ck(L.ddsp_hip_impulse_response(p(c_h), ld, None, 0, 1, 1.0, 2, p(hw), rows, n, p(tab), p(tb), s))
+    hm = cmb if bufs_alias_harm[0] else h2
+    ck(L.ddsp_hip_fft_convolve(p(hh), 0, p(tb), None, p(hm), None, B, F, HOP, N, 0, s))
+    ck(L.ddsp_hip_impulse_response(p(c_nz), ld, None, 0, 1, 1.0 / 128, 1, None, rows, n, p(tab), p(tc), s))
+    ck(L.ddsp_hip_fft_convolve(p(noise), 0, p(tc), p(hm), p(sig), None, B, F, HOP, N, 0, s))
+
+
+h2 = torch.empty(B, T, device=dev)
+bufs_alias_harm = [False]
+ws = torch.empty(2 * B * T + rows * N + rows + 64, device=dev)          # carve_synth's layout
+w_buf0, w_buf1 = ws[:B * T], ws[B * T:2 * B * T]
+w_taps = ws[2 * B * T:2 * B * T + rows * N]
 res = {}
 try:
     ref = fused().clone()
@@ -96,6 +116,15 @@ for rnd in range(2):
     s1 = signal.clone()
     res["forked_noise_harmtaps_ms_%d" % rnd] = timeit(lambda: forked(True))
     s2 = signal.clone()
+for rnd in range(2):
+    bufs_alias_harm[0] = False
+    res["fusedorder_separate_ms_%d" % rnd] = timeit(lambda: fused_order((re, im, t1, t2, t3, comb, h1, signal)))
+    res["fusedorder_sharedtaps_ms_%d" % rnd] = timeit(lambda: fused_order((re, im, t1, t1, t1, comb, h1, signal)))
+    bufs_alias_harm[0] = True
+    res["fusedorder_sharedtaps_harmalias_ms_%d" % rnd] = timeit(lambda: fused_order((re, im, t1, t1, t1, comb, h1, signal)))
+    res["fusedorder_carved_ms_%d" % rnd] = timeit(lambda: fused_order(
+        (w_buf0[:rows * n], w_buf0[rows * n:2 * rows * n], w_taps, w_taps, w_taps, w_buf0, w_buf1, signal)))
+    res["fused_ms_again_%d" % rnd] = timeit(fused)
 res["forked_equal_serial"] = bool((s0 == s1).all() and (s0 == s2).all())
 if ref is not None:
     res["serial_vs_fused_maxdiff"] = float((s0 - ref).abs().max())
