@@ -32,10 +32,10 @@ SIGNATURES = {
     "ddsp_hip_fft_convolve_backward": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "ddsp_hip_sins_synth": (c_int, [P, P, P, P, c_long, P, c_long, P, c_long, P, c_int,
                                     c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_int,
-                                    P, P, P, P, P, P, c_size_t, c_int, P]),
+                                    P, P, P, P, P, P, c_size_t, c_int, P, P]),
     "ddsp_hip_combsub_synth": (c_int, [P, P, P, P, c_long, P, c_long, P, c_long, P, c_int,
                                        c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_int,
-                                       P, P, P, P, P, P, P, c_size_t, c_int, P]),
+                                       P, P, P, P, P, P, P, c_size_t, c_int, P, P]),
     "ddsp_hip_synth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddsp_hip_combtooth": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_int, P, P]),
     "ddsp_hip_sinusoid_bank": (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_double, c_int, P, P]),
@@ -101,6 +101,20 @@ def check_device(*tensors):
 
 def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+_AUX = {}
+
+
+def aux_stream_of(t, rows):
+    """Second stream for the noise branch of the synthesiser tails (include/ddsp_hip.h, ``aux_stream``): one per
+    device, used once the launch is large enough for the overlap to matter.  ``DDSP_HIP_ONE_STREAM=1`` disables it."""
+    if not t.is_cuda or rows < 4096 or os.environ.get("DDSP_HIP_ONE_STREAM"):
+        return None
+    s = _AUX.get(t.device)
+    if s is None:
+        s = _AUX[t.device] = torch.cuda.Stream(device=t.device)
+    return s.cuda_stream
 
 
 def ptr(t):

@@ -33,6 +33,48 @@ struct Carver {
 
 struct SynthWs {
   float *buf0, *buf1, *taps, *re, *im, *hw, *harm;
+  float *taps_nz, *nzbuf;      // the noise branch's own taps and output when it runs on a second stream
+};
+
+// Fork / join of the independent noise branch onto a caller-provided second stream.  The two events are created once
+// per host thread and device (the only thing this library ever creates) and re-used: a wait captures the record that
+// precedes it, so re-recording an event for the next call does not disturb waits already enqueued.
+struct BranchEvents {
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+struct Branch {
+  hipStream_t main, aux;
+  BranchEvents* ev = nullptr;
+  bool forked = false;
+  Branch(hipStream_t m, void* aux_stream) : main(m), aux(m) {
+    if (!aux_stream || S(aux_stream) == m) return;
+    static thread_local BranchEvents per_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    BranchEvents& e = per_device[dev];
+    if (!e.fork) {
+      if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) { e.fork = nullptr; return; }
+      if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipEventDestroy(e.fork);
+        e.fork = e.join = nullptr;
+        return;
+      }
+    }
+    // everything enqueued on the main stream so far (the inputs' producers) precedes the branch
+    if (hipEventRecord(e.fork, m) != hipSuccess) return;
+    if (hipStreamWaitEvent(S(aux_stream), e.fork, 0) != hipSuccess) return;
+    ev = &e;
+    aux = S(aux_stream);
+    forked = true;
+  }
+  // the main stream continues only after everything the branch enqueued
+  void join() {
+    if (!forked) return;
+    (void)hipEventRecord(ev->join, aux);
+    (void)hipStreamWaitEvent(main, ev->join, 0);
+    forked = false;
+  }
 };
 
 size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
@@ -53,6 +95,8 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
     w.im = c.take<float>(R * n_max);
   }
   w.harm = w.buf0;
+  w.taps_nz = c.take<float>(R * N);
+  w.nzbuf = c.take<float>(BT);
   return align_up(c.used, 256);
 }
 
@@ -221,7 +265,8 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
                         long ld_amp, const float* c_gd, long ld_gd, const float* c_nz, long ld_nz, const float* noise,
                         int noise_is_u01, int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,
                         const float* table_ap, const float* table_nz, float* signal, float* harmonic_or_null,
-                        float* noise_out_or_null, void* ws, size_t ws_bytes, int fir_impl, void* stream) {
+                        float* noise_out_or_null, void* ws, size_t ws_bytes, int fir_impl, void* stream,
+                        void* aux_stream) {
   if (B < 0 || F <= 0 || hop <= 0 || H <= 0 || n_ap < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
   if (ld_amp < H || ld_gd < n_ap || ld_nz < n_nz) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
@@ -234,6 +279,26 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
+  Branch br(st, aux_stream);
+  if (br.forked) {
+    // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+    launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                   n_nz, w.taps_nz, br.aux);
+    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                              br.aux);
+    launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
+    launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                   w.taps, st);
+    const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
+    br.join();                                           // always joined, also on the error paths below
+    if (r == -1) return DDSP_HIP_EHOP;
+    if (r == -2 || rn < 0) return DDSP_HIP_ESHAPE;
+    // harmonic = all-pass(sinusoids) (vocoder.py:597-600); signal = harmonic + noise (:609)
+    if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
   // all-pass taps first (their response lives in buf0 until the exciter overwrites it)
   launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
   launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
@@ -260,7 +325,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
                            const float* noise, int noise_is_u01, int B, int F, int hop, double sr, int infer, int n_ap,
                            int n_harm, int n_nz, const float* table_ap, const float* table_harm, const float* table_nz,
                            float* signal, float* harmonic_or_null, float* noise_out_or_null, void* ws, size_t ws_bytes,
-                           int fir_impl, void* stream) {
+                           int fir_impl, void* stream, void* aux_stream) {
   if (B < 0 || F <= 0 || hop <= 0 || n_ap < 2 || n_harm < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
   if (ld_gd < n_ap || ld_harm < n_harm || ld_nz < n_nz) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
@@ -274,6 +339,33 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
+  Branch br(st, aux_stream);
+  if (br.forked) {
+    // noise branch (vocoder.py:854-858) on the second stream, beside the harmonic chain
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+    launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                   n_nz, w.taps_nz, br.aux);
+    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                              br.aux);
+    launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
+    launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                   w.taps, st);
+    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
+    int r1 = 0;
+    if (rc == 0) {
+      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
+      launch_half_width(f0_frames, R, (float)sr, w.hw, st);
+      launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, w.hw, R,
+                     n_harm, w.taps, st);
+    }
+    br.join();                                           // always joined, also on the error paths below
+    if (rc != 0) return DDSP_HIP_EHOP;
+    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
+    // signal = harmonic + noise (vocoder.py:860): the second harmonic filter adds the branch's result
+    if (launch_fir(w.buf1, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
   float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
   // all-pass taps first (vocoder.py:843-846; their response lives in buf0 until the exciter overwrites it)
   launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);

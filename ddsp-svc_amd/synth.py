@@ -133,7 +133,7 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
         ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(ca), lda, ptr(cg), ldg, ptr(cn), ldn,
         ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), H, n_ap, n_nz,
         ptr(ir_table(n_ap, dev)), ptr(ir_table(n_nz, dev)), ptr(signal), ptr(harm), ptr(nzo),
-        ptr(ws), need, int(fir_impl), _ffi.stream_of(f0)))
+        ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F)))
     return signal, harm, nzo
 
 
@@ -297,7 +297,7 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
         ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(cg), ldg, ptr(ch), ldh, ptr(cn), ldn,
         ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), n_ap, n_h, n_nz,
         ptr(ir_table(n_ap, dev)), ptr(ir_table(n_h, dev)), ptr(ir_table(n_nz, dev)),
-        ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0)))
+        ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F)))
     return signal, harm, nzo
 
 

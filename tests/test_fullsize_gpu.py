@@ -119,6 +119,26 @@ def test_tail_rows_match_oracle_and_batching(cuda, batch, kind):
         assert rms(one - sig[sl]) <= 1e-6 * rms(one)
 
 
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_tail_second_stream_full_size(cuda, batch, kind, monkeypatch):
+    """the full batch takes the two-stream order by default (rows >= 4096): bit-identical to the one-stream order,
+    call after call (workspace, events and the second stream are re-used), also with work queued behind it"""
+    from ddsp_svc_amd import _ffi, synth
+    f0, (c0, c1, c2), noise = batch
+    fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+    st = synth.phase(f0, SR, HOP)
+    assert _ffi.aux_stream_of(f0, B * F) is not None
+    with monkeypatch.context() as m:
+        m.setattr(_ffi, "aux_stream_of", lambda t, rows: None)
+        one = fn(f0, st, c0, c1, c2, noise, SR, HOP, want_components=False)[0].clone()
+    outs = []
+    for i in range(6):
+        outs.append(fn(f0, st, c0, c1, c2, noise, SR, HOP, want_components=False)[0])
+        outs[-1].mul_(1.0)                          # a consumer on the main stream right behind the call
+    for o in outs:
+        assert torch.equal(o, one)
+
+
 def test_phase_checksum_and_restart(cuda, batch):
     """phase_frames of the batch against the oracle for every utterance (cheap), and the additivity of the scan:
     synthesising the second half with initial_phase = phase reached at the split equals the tail of the full run"""
