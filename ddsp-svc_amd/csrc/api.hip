@@ -32,7 +32,7 @@ struct Carver {
 };
 
 struct SynthWs {
-  float *buf0, *buf1, *taps, *re, *im, *hw, *harm;
+  float *buf0, *buf1, *taps, *re, *im, *harm;
   float *taps_nz, *nzbuf;      // the noise branch's own taps and output when it runs on a second stream
 };
 
@@ -82,7 +82,6 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   w.buf0 = c.take<float>(BT);
   w.buf1 = c.take<float>(BT);
   w.taps = c.take<float>(R * N);
-  w.hw = c.take<float>(R);
   // The all-pass response (re, im) is dead once its taps are synthesised, before the exciter is written: when it
   // fits (2 n <= hop) it lives in buf0, and the harmonic signal re-uses buf0 after the first filter has consumed
   // the exciter -- the step then cycles through three [B,T]-sized buffers instead of six (less of it falls out of
@@ -354,9 +353,9 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
     int r1 = 0;
     if (rc == 0) {
       r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
-      launch_half_width(f0_frames, R, (float)sr, w.hw, st);
-      launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, w.hw, R,
-                     n_harm, w.taps, st);
+      // half_width_frames = 1.5 sr / (f0 + 1e-3) (vocoder.py:851) is formed in the kernel's epilogue
+      launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
+                     n_harm, w.taps, st, (float)sr);
     }
     br.join();                                           // always joined, also on the error paths below
     if (rc != 0) return DDSP_HIP_EHOP;
@@ -376,9 +375,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851)
-  launch_half_width(f0_frames, R, (float)sr, w.hw, st);
-  launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, w.hw, R, n_harm,
-                 w.taps, st);
+  launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
+                 w.taps, st, (float)sr);
   if (launch_fir(w.buf1, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // noise branch + mix (vocoder.py:854-860)

@@ -199,16 +199,17 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
   const float* f0_row = f0_frames + b * F;
   const float nyq = cfg.sr_f / 2.0f;
   const int f1 = f + 1 < F ? f + 1 : F - 1;           // last frame held (core.py:68)
-  for (int i = tid; i < 2 * HP; i += 256) {
-    const int k = i >> 1, side = i & 1;
-    float v = 0.f;
+  for (int k = tid; k < HP; k += 256) {
+    float a0 = 0.f, a1 = 0.f;
     if (k < H) {
-      const int ff = side ? f1 : f;
-      const float a = expf(c_amp[(b * F + ff) * ld_amp + k]) / 128.0f;      // vocoder.py:580
-      const float p = f0_row[ff] * (float)(k + 1);
-      v = a * ((p < nyq ? 1.0f : 0.0f) + 1e-7f);                          // core.py:75-76
+      const float e0 = expf(c_amp[(b * F + f) * ld_amp + k]) / 128.0f;       // vocoder.py:580
+      const float e1 = expf(c_amp[(b * F + f1) * ld_amp + k]) / 128.0f;
+      const float kk = (float)(k + 1);
+      a0 = e0 * ((f0_row[f] * kk < nyq ? 1.0f : 0.0f) + 1e-7f);             // core.py:75-76
+      a1 = e1 * ((f0_row[f1] * kk < nyq ? 1.0f : 0.0f) + 1e-7f);
     }
-    amp[i] = v;
+    amp[2 * k] = a0;
+    amp[2 * k + 1] = a1 - a0;                       // the frame-to-frame step: upsample(A)[t] = A[f] + lambda (A[f+1] - A[f])
   }
   // wrapped phase of this thread's two samples (vocoder.py:564-572): float64 terms, block-wide exclusive scan
   const Upsampler::Row3 rows = up.load3(f0_row, f);
@@ -238,7 +239,20 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
       ts[j] = __builtin_elementwise_fma(ts[j - 1], tc[0], tc[j - 1] * ts[0]);
     }
   }
-  f32x2 S0 = {0.f, 0.f}, S1 = {0.f, 0.f};            // sum_k sin(k theta) A[f][k] and ... A[f+1][k], per sample
+  // interpolation weight of the thread's two samples (core.py:66-70: lambda = j / hop towards frame f + 1)
+  f32x2 lam;
+  {
+    int i0, i1;
+    float w0, w1;
+    up.locate(t0, i0, i1, w0, w1);
+    lam.x = w1;
+    up.locate(t0 + 1, i0, i1, w0, w1);
+    lam.y = w1;
+  }
+  // sum_k sin(k theta) A_k(t) block by block:  sin((16 b + j) theta) = Cb sin(j theta) + Sb cos(j theta), so a block
+  // contributes Cb P + Sb Q with P = sum_j sin(j theta) A_j(t), Q = sum_j cos(j theta) A_j(t): three packed
+  // multiply-adds per harmonic and sample pair (amplitude interpolation, P, Q)
+  f32x2 S = {0.f, 0.f};
   f32x2 Cb = {1.f, 1.f}, Sb = {0.f, 0.f};            // cis(16 b theta)
   const int nblk = HP >> 4;
   for (int blk = 0; blk < nblk; ++blk) {
@@ -256,23 +270,18 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
       }
     }
     const float* ap = amp + 32 * blk;
+    f32x2 P = {0.f, 0.f}, Q = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float a0 = ap[2 * j], a1 = ap[2 * j + 1];
-      const f32x2 sv = __builtin_elementwise_fma(Cb, ts[j], Sb * tc[j]);  // sin((16 blk + j + 1) theta), both samples
-      S0 = __builtin_elementwise_fma(sv, f32x2{a0, a0}, S0);
-      S1 = __builtin_elementwise_fma(sv, f32x2{a1, a1}, S1);
+      const float a0 = ap[2 * j], da = ap[2 * j + 1];
+      const f32x2 a = __builtin_elementwise_fma(lam, f32x2{da, da}, f32x2{a0, a0});
+      P = __builtin_elementwise_fma(ts[j], a, P);
+      Q = __builtin_elementwise_fma(tc[j], a, Q);
     }
+    S = __builtin_elementwise_fma(Cb, P, S);
+    S = __builtin_elementwise_fma(Sb, Q, S);
   }
-  // upsample(A)[t] = w0 A[f] + w1 A[f+1] (core.py:66-70) applied to the two partial sums
-  float r[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int i0, i1;
-    float w0, w1;
-    up.locate(t0 + q, i0, i1, w0, w1);
-    r[q] = fmaf(w0, S0[q], w1 * S1[q]);
-  }
+  const float r[2] = {S.x, S.y};
   float* dst = out + b * (long)F * HOP + t0;
   if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
   else { dst[0] = r[0]; dst[1] = r[1]; }

@@ -110,13 +110,6 @@ __global__ void __launch_bounds__(256) k_allpass_response(const float* __restric
   }
 }
 
-// vocoder.py:851  half_width_frames = 1.5 * sr / (f0_frames + 1e-3)
-__global__ void __launch_bounds__(256) k_half_width(const float* __restrict__ f0_frames, long rows, float sr,
-                                                    float* __restrict__ hw) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < rows) hw[i] = (1.5f * sr) / (f0_frames[i] + 1e-3f);
-}
-
 // ------------------------------------------------------------------------------------------------
 // taps = window( roll( X * T ) ).  Workgroup tile = 64 frames x 256 taps-columns (all of m = 0..N/2 for
 // n_mag <= 256, so every control row is read from HBM exactly once), 4 waves of 64x64 = 2x2 MFMA
@@ -152,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
                                                  const float* __restrict__ a_im, long ld_im, float scale,
                                                  const float* __restrict__ table,
                                                  const float* __restrict__ half_width, long rows, int n,
-                                                 float* __restrict__ taps, int a_vec_ok) {
+                                                 float* __restrict__ taps, int a_vec_ok, float hw_sr) {
   __shared__ __attribute__((aligned(16))) float stage[2 * IR_STAGE];
   const int tid = threadIdx.x;
   const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = 64-column group
@@ -316,7 +309,10 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const long r = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      hwr[reg] = (MODE == IR_MODE_DYNAMIC && r < rows) ? half_width[r] : 1.f;
+      float hv = (MODE == IR_MODE_DYNAMIC && r < rows) ? half_width[r] : 1.f;
+      // hw_sr > 0: `half_width` holds f0 and the width is formed here, vocoder.py:851 (same float32 operations as a separate pass would do)
+      if (MODE == IR_MODE_DYNAMIC && hw_sr > 0.f) hv = (1.5f * hw_sr) / (hv + 1e-3f);
+      hwr[reg] = hv;
     }
     if (full) {
 #pragma unroll
@@ -561,21 +557,16 @@ void launch_allpass_response(const float* c, long ld, long rows, int n, float* r
   hipLaunchKernelGGL(k_allpass_response, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, c, ld, rows, n, re, im, vec4);
 }
 
-void launch_half_width(const float* f0_frames, long rows, float sr, float* hw, hipStream_t st) {
-  if (rows == 0) return;
-  hipLaunchKernelGGL(k_half_width, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, f0_frames, rows, sr, hw);
-}
-
 void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale,
                     const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                    hipStream_t st) {
+                    hipStream_t st, float hw_from_f0_sr) {
   if (rows == 0) return;
   dim3 grid((unsigned)((rows + GM - 1) / GM), (unsigned)(ir_np(n) / GN)), block(256);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int vec = (al16(a_re) && (ld_re & 3) == 0 && (!a_im || (al16(a_im) && (ld_im & 3) == 0))) ? 1 : 0;
 #define DDSP_IR_LAUNCH(ACT_, IM_, MODE_)                                                                          \
   hipLaunchKernelGGL((k_ir_gemm<ACT_, IM_, MODE_>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, table, \
-                     half_width, rows, n, taps, vec)
+                     half_width, rows, n, taps, vec, hw_from_f0_sr)
 #define DDSP_IR_MODES(ACT_, IM_)                                              \
   do {                                                                        \
     if (mode == IR_MODE_HANN) DDSP_IR_LAUNCH(ACT_, IM_, IR_MODE_HANN);        \

@@ -21,10 +21,9 @@ int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, con
 size_t ir_table_floats(int n);
 void launch_ir_table(int n, float* table, hipStream_t st);
 void launch_allpass_response(const float* c, long ld, long rows, int n, float* re, float* im, hipStream_t st);
-void launch_half_width(const float* f0_frames, long rows, float sr, float* hw, hipStream_t st);
 void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale,
                     const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                    hipStream_t st);
+                    hipStream_t st, float hw_from_f0_sr = 0.f);   // > 0: half_width[] holds f0, width = 1.5 sr / (f0 + 1e-3)
 void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                         int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                         hipStream_t st);

@@ -46,25 +46,31 @@ __global__ void __launch_bounds__(256) k_remove_above_fmax(const float* __restri
 // ------------------------------------------------------------------------------------------------
 // level 1+2: per-frame totals of f0[t]/sr.  One wave per frame, lane owns SPL consecutive samples.
 // ------------------------------------------------------------------------------------------------
+constexpr int PH_FRAMES_PER_WAVE = 4;                // consecutive frames a wave walks: amortises the launch of tiny workgroups
+
 template <int SPL>
 __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restrict__ f0_frames, long n_frames, int F,
                                                           int hop, Upsampler up, PhaseCfg cfg,
                                                           double* __restrict__ sums) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  long fr = (long)blockIdx.x * 4 + wave;
-  if (fr >= n_frames) return;                       // wave-uniform
-  long b = fr / F;
-  int f = (int)(fr % F);
-  const float* row = f0_frames + b * F;
-  const Upsampler::Row3 rows = up.load3(row, f);
-  double acc = 0.0;
+  const long fr0 = ((long)blockIdx.x * 4 + wave) * PH_FRAMES_PER_WAVE;
 #pragma unroll
-  for (int r = 0; r < SPL; ++r) {
-    int j = lane * SPL + r;
-    if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
+  for (int q = 0; q < PH_FRAMES_PER_WAVE; ++q) {
+    const long fr = fr0 + q;
+    if (fr >= n_frames) return;                     // wave-uniform
+    const long b = fr / F;
+    const int f = (int)(fr % F);
+    const float* row = f0_frames + b * F;
+    const Upsampler::Row3 rows = up.load3(row, f);
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < SPL; ++r) {
+      int j = lane * SPL + r;
+      if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sums[fr] = acc;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) sums[fr] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,12 +201,13 @@ int launch_phase(const float* f0_frames, const float* initial_phase, int B, int 
   Upsampler up = make_upsampler(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
+  const dim3 sgrid((unsigned)((n_frames + 4 * PH_FRAMES_PER_WAVE - 1) / (4 * PH_FRAMES_PER_WAVE)));
   if (spl == 8)
-    hipLaunchKernelGGL(k_phase_frame_sums<8>, grid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    hipLaunchKernelGGL(k_phase_frame_sums<8>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   else if (spl == 16)
-    hipLaunchKernelGGL(k_phase_frame_sums<16>, grid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    hipLaunchKernelGGL(k_phase_frame_sums<16>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   else
-    hipLaunchKernelGGL(k_phase_frame_sums<32>, grid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    hipLaunchKernelGGL(k_phase_frame_sums<32>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   hipLaunchKernelGGL(k_phase_frame_scan, dim3((unsigned)B), dim3(256), 0, st, f0_frames, initial_phase, F, hop, up, cfg,
                      (const double*)frame_sums, phase0, phase_frames);
   if (x_or_null) {
