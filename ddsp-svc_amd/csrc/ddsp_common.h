@@ -21,7 +21,19 @@ constexpr double kPiD = 3.14159265358979323846;
 struct Upsampler {
   float scale;
   int F;
+  // > 0 when hop = 2^shift and F hop <= 2^24: scale = 2^-shift, (float)t and scale * t are exact, so the float
+  // recipe below reduces to integer shifts -- bit-identical, about a third of the instructions
+  int shift;
   __device__ __forceinline__ void locate(long t, int& i0, int& i1, float& l0, float& l1) const {
+    if (shift > 0) {
+      const int ti = (int)t;
+      const int k = ti >> shift;
+      l1 = (float)(ti - (k << shift)) * scale;
+      l0 = 1.0f - l1;
+      i0 = k < F - 1 ? k : F - 1;
+      i1 = k + 1 < F - 1 ? k + 1 : F - 1;
+      return;
+    }
     float src = scale * (float)t;
     int k = (int)src;
     if (k > F) k = F;

@@ -153,6 +153,10 @@ static inline Upsampler make_upsampler(int F, int hop) {
   Upsampler u;
   u.F = F;
   u.scale = (float)F / (float)((long)F * hop);
+  u.shift = 0;
+  if (hop > 1 && (hop & (hop - 1)) == 0 && (long)F * hop <= (1L << 24)) {
+    while ((1 << u.shift) < hop) ++u.shift;
+  }
   return u;
 }
 
