@@ -234,6 +234,8 @@ static inline double __fma_rn(double a, double b, double c) { return fma(a, b, c
 static inline float __builtin_amdgcn_sinf(float turns) { return (float)sin(2.0 * M_PI * (double)turns); }   // v_sin_f32
 static inline float __builtin_amdgcn_cosf(float turns) { return (float)cos(2.0 * M_PI * (double)turns); }   // v_cos_f32
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }                                            // v_rcp_f32
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }                                         // v_log_f32
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }                                        // v_sqrt_f32
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }                                         // v_exp_f32
 static inline float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }                                    // v_fract_f32
 #define __sinf(x) sinf(x)
