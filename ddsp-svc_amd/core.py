@@ -79,27 +79,63 @@ def crop_and_compensate_delay(audio, audio_size, ir_size, padding="same", delay_
     return audio[:, start:-end]
 
 
+def _impulse_response_forward(re, im, mode, hw):
+    B, F, n = re.shape
+    taps = torch.empty(B, F, 2 * (n - 1), dtype=torch.float32, device=re.device)
+    _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(re), n, ptr(im), n, _ffi.ACT_NONE, 1.0, mode, ptr(hw),
+                                                    B * F, n, ptr(ir_table(n, re.device)), ptr(taps),
+                                                    _ffi.stream_of(re)))
+    return taps
+
+
+class FrequencyImpulseResponseFunction(torch.autograd.Function):
+    """core.py:254-270 with the gradient back to the one-sided response: the adjoint of irfft + roll + window
+    (``ddsp_hip_impulse_response_backward``).  A complex response is differentiable without a window
+    (``hann_window=False``, the all-pass case); the window itself (half widths) is a constant."""
+
+    @staticmethod
+    def forward(ctx, magnitudes, mode, hw):
+        if magnitudes.is_complex():
+            re, im = _f32c(magnitudes.real.detach()), _f32c(magnitudes.imag.detach())
+        else:
+            re, im = _f32c(magnitudes.detach()), None
+        ctx.cfg = (int(mode), im is not None, tuple(re.shape))
+        ctx.save_for_backward(hw if hw is not None else re.new_empty(0))
+        return _impulse_response_forward(re, im, mode, hw)
+
+    @staticmethod
+    def backward(ctx, d_taps):
+        (hw,) = ctx.saved_tensors
+        mode, is_complex, (B, F, n) = ctx.cfg
+        if is_complex and mode != _ffi.MODE_ROLL:
+            raise NotImplementedError("gradient of a windowed impulse response w.r.t. a complex response")
+        g = _f32c(d_taps)
+        d_re = torch.empty(B, F, n, dtype=torch.float32, device=g.device)
+        d_im = torch.empty_like(d_re) if is_complex else None
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(
+            ptr(g), None, 0, _ffi.ACT_NONE, 1.0, mode, ptr(hw) if hw.numel() else None, B * F, n,
+            ptr(ir_table(n, g.device)), ptr(d_re), ptr(d_im), _ffi.stream_of(g)))
+        return (torch.complex(d_re, d_im) if is_complex else d_re), None, None
+
+
 def frequency_impulse_response(magnitudes, hann_window=True, half_width_frames=None):
     """core.py:254-270: one-sided response ``[B,F,n]`` (complex or real) -> taps ``[B,F,2(n-1)]``
-    in causal form, windowed as the flags select."""
+    in causal form, windowed as the flags select.  Differentiable w.r.t. ``magnitudes``."""
     _ffi.check_device(magnitudes, half_width_frames)
-    if magnitudes.is_complex():
-        re, im = _f32c(magnitudes.real), _f32c(magnitudes.imag)
-    else:
-        re, im = _f32c(magnitudes), None
-    B, F, n = re.shape
-    N = 2 * (n - 1)
+    B, F, n = magnitudes.shape
     if not hann_window:
         mode, hw = _ffi.MODE_ROLL, None
     elif half_width_frames is None:
         mode, hw = _ffi.MODE_HANN, None
     else:
-        mode, hw = _ffi.MODE_DYNAMIC, _f32c(half_width_frames.expand(B, F, 1))
-    taps = torch.empty(B, F, N, dtype=torch.float32, device=re.device)
-    tab = ir_table(n, re.device)
-    _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(re), n, ptr(im), n, _ffi.ACT_NONE, 1.0, mode, ptr(hw),
-                                                    B * F, n, ptr(tab), ptr(taps), _ffi.stream_of(re)))
-    return taps
+        mode, hw = _ffi.MODE_DYNAMIC, _f32c(half_width_frames.detach().expand(B, F, 1))
+    if torch.is_grad_enabled() and magnitudes.requires_grad:
+        return FrequencyImpulseResponseFunction.apply(magnitudes, mode, hw)
+    if magnitudes.is_complex():
+        re, im = _f32c(magnitudes.real), _f32c(magnitudes.imag)
+    else:
+        re, im = _f32c(magnitudes), None
+    return _impulse_response_forward(re, im, mode, hw)
 
 
 def _fft_convolve_forward(x, ir, impl):
@@ -163,5 +199,31 @@ def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
 
 
 def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None):
-    """core.py:273-280."""
-    return fft_convolve(audio, frequency_impulse_response(magnitudes, hann_window, half_width_frames))
+    """core.py:273-280.  Without gradients: one C call (tap synthesis + time-varying FIR, the taps in a scratch
+    tensor); with gradients: the differentiable composition."""
+    needs_grad = torch.is_grad_enabled() and (audio.requires_grad or magnitudes.requires_grad)
+    if needs_grad or audio.dim() != 2 or magnitudes.dim() != 3:
+        return fft_convolve(audio, frequency_impulse_response(magnitudes, hann_window, half_width_frames))
+    _ffi.check_device(audio, magnitudes, half_width_frames)
+    B, T = audio.shape
+    F, n = magnitudes.shape[1], magnitudes.shape[2]
+    if magnitudes.shape[0] != B:
+        raise ValueError("Batch size of audio ({}) and impulse response ({}) must be the same.".format(
+            B, magnitudes.shape[0]))                                           # core.py:151-153
+    if F < 1 or T % F != 0 or n < 2:
+        return fft_convolve(audio, frequency_impulse_response(magnitudes, hann_window, half_width_frames))
+    hop = T // F
+    if magnitudes.is_complex():
+        re, im = _f32c(magnitudes.real), _f32c(magnitudes.imag)
+    else:
+        re, im = _f32c(magnitudes), None
+    mode = _ffi.MODE_ROLL if not hann_window else (_ffi.MODE_HANN if half_width_frames is None else _ffi.MODE_DYNAMIC)
+    hw = None if mode != _ffi.MODE_DYNAMIC else _f32c(half_width_frames.expand(B, F, 1))
+    x = _f32c(audio)
+    lib = _ffi.lib()
+    nbytes = lib.ddsp_hip_frequency_filter_workspace_bytes(B, F, n)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, T, dtype=torch.float32, device=x.device)
+    _ffi.check(lib.ddsp_hip_frequency_filter(ptr(x), ptr(re), n, ptr(im), n, mode, ptr(hw), B, F, hop, n,
+                                             ptr(ir_table(n, x.device)), ptr(out), ptr(ws), nbytes, _ffi.stream_of(x)))
+    return out

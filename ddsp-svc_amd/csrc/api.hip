@@ -205,6 +205,29 @@ int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, c
   return finish();
 }
 
+size_t ddsp_hip_frequency_filter_workspace_bytes(int B, int F, int n_mag) {
+  if (B <= 0 || F <= 0 || n_mag < 2) return 0;
+  return align_up((size_t)B * F * 2 * (size_t)(n_mag - 1) * sizeof(float), 256);
+}
+
+int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_re, const float* resp_im, long ld_im,
+                              int mode, const float* half_width, int B, int F, int hop, int n_mag, const float* table,
+                              float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (B < 0 || F <= 0 || hop <= 0 || n_mag < 2 || ld_re < n_mag || (resp_im && ld_im < n_mag)) return DDSP_HIP_EINVAL;
+  if (mode < 0 || mode > 2) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!audio || !resp_re || !table || !out || !ws) return DDSP_HIP_EINVAL;
+  if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
+  if (ws_bytes < ddsp_hip_frequency_filter_workspace_bytes(B, F, n_mag)) return DDSP_HIP_EWS;
+  float* taps = static_cast<float*>(ws);
+  const long R = (long)B * F;
+  launch_ir_gemm(resp_re, ld_re, resp_im, ld_im, DDSP_HIP_ACT_NONE, 1.0f, table, mode, half_width, R, n_mag, taps,
+                 S(stream));
+  if (launch_fir(audio, 0, taps, nullptr, out, nullptr, B, F, hop, 2 * (n_mag - 1), DDSP_HIP_FIR_AUTO, S(stream)) < 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float* taps, const float* grad_out,
                                    float* d_audio, float* d_taps, int B, int F, int hop, int N, void* stream) {
   if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;

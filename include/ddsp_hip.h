@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 131          /* 0.1.3: + adjoints, NSF source, spectral loss */
+#define DDSP_HIP_VERSION 132          /* 0.1.3: + adjoints, NSF source, spectral loss */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -100,6 +100,15 @@ int ddsp_hip_allpass_backward(const float* c, long ld, long rows, int n_mag, con
  * receives the un-added result. */
 int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, const float* addend,
                           float* out, float* out_plain, int B, int F, int hop, int N, int impl, void* stream);
+
+/* ddsp/core.py:273-280  frequency_filter(audio[B,T], magnitudes[B,F,n_mag] (complex: resp_re + i resp_im, resp_im
+ * may be NULL), hann_window, half_width_frames) = fft_convolve(audio, frequency_impulse_response(...)) in one call.
+ * mode / half_width[B*F] as ddsp_hip_impulse_response; ws holds the taps
+ * (ddsp_hip_frequency_filter_workspace_bytes(B, F, n_mag) bytes); out[B,T]. */
+size_t ddsp_hip_frequency_filter_workspace_bytes(int B, int F, int n_mag);
+int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_re, const float* resp_im, long ld_im,
+                              int mode, const float* half_width, int B, int F, int hop, int n_mag,
+                              const float* table, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* What autograd returns for ddsp_hip_fft_convolve given grad_out[B,T] = dL/dout: d_taps[B,F,N] and, if
  * d_audio is not NULL, d_audio[B,T] (the adjoints of core.py:120-182; training back-propagates through them,

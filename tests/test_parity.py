@@ -230,6 +230,44 @@ def test_fft_convolve_golden(dev, golden_dir, impl, n_mag):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("n_mag", [65, 129, 256])
+def test_frequency_filter_golden(dev, golden_dir, n_mag):
+    """core.frequency_filter (core.py:273-280) through its one-call C entry point, the three window modes, against the
+    reference's outputs; and the differentiable composition it falls back to under autograd gives the same values"""
+    from ddsp_svc_amd import core
+    g = np.load(os.path.join(golden_dir, f"filter_n{n_mag}.npz"))
+    audio = T_(g["audio"], dev)
+    ap = torch.complex(T_(g["resp_re"], dev), T_(g["resp_im"], dev))
+    mag = T_(g["mag"], dev)
+    hw = T_(g["half_width"], dev).unsqueeze(-1)
+    for key, kw, m in (("y_roll", dict(hann_window=False), ap), ("y_hann", dict(), mag),
+                       ("y_dyn", dict(half_width_frames=hw), mag)):
+        y = core.frequency_filter(audio, m, **kw)
+        assert rms(N_(y) - g[key]) <= 2e-6 * rms(g[key]), key
+        # under autograd: the differentiable composition gives the same values, and its gradient w.r.t. the response
+        # is the chain of the oracle's two adjoints (FIR -> taps, taps -> response)
+        if audio.shape[1] // mag.shape[1] != 512:
+            continue                                  # the FIR adjoint covers hop 512 (fixture n_mag = 129 has hop 256)
+        mg = m.clone().requires_grad_(True)
+        y2 = core.frequency_filter(audio, mg, **kw)
+        assert y2.requires_grad and rms(N_(y2.detach()) - N_(y)) <= 1e-6 * rms(g[key])
+        R = torch.from_numpy(np.random.default_rng(n_mag).standard_normal(g[key].shape).astype(np.float32)).to(y2.device)
+        (y2 * R).sum().backward()
+        mode = O.MODE_ROLL if key == "y_roll" else (O.MODE_HANN if key == "y_hann" else O.MODE_DYNAMIC)
+        ir = O.impulse_response(g["resp_re"] if m.is_complex() else g["mag"],
+                                g["resp_im"] if m.is_complex() else None, mode, g["half_width"])
+        _, d_taps = O.ltv_fir_backward(N_(R), g["audio"], ir)
+        d_re, d_im = O.impulse_response_backward(d_taps, mode, g["half_width"])
+        got = mg.grad
+        if m.is_complex():
+            assert rms(N_(got.real) - d_re) <= 2e-5 * rms(d_re) and rms(N_(got.imag) - d_im) <= 2e-5 * rms(d_im)
+        else:
+            assert rms(N_(got) - d_re) <= 2e-5 * rms(d_re), key
+    with pytest.raises(ValueError):
+        core.frequency_filter(audio[:1], mag)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("B,F,hop,N", [(1, 1, 512, 510), (2, 3, 512, 30), (1, 5, 200, 64), (1, 4, 512, 1022),
                                        (1, 9, 256, 510)])
 def test_fft_convolve_shapes(dev, B, F, hop, N):
