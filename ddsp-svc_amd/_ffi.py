@@ -114,6 +114,8 @@ def aux_stream_of(t, rows):
     device, used once the launch is large enough for the overlap to matter.  ``DDSP_HIP_ONE_STREAM=1`` disables it."""
     if not t.is_cuda or rows < 4096 or os.environ.get("DDSP_HIP_ONE_STREAM"):
         return None
+    if torch.cuda.current_device() != t.device.index:      # the library's fork / join events belong to the current device
+        return None
     s = _AUX.get(t.device)
     if s is None:
         s = _AUX[t.device] = torch.cuda.Stream(device=t.device)
