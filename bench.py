@@ -100,7 +100,10 @@ def hbm_traffic(kernel):
     FETCH_SIZE / WRITE_SIZE passes over this same workload, gfx950 read correction applied), or None."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+    def version(name):                                   # r01_v10_... after r01_v9_...: numeric, not lexicographic
+        import re
+        return [int(x) for x in re.findall(r"\d+", name)]
+    for name in sorted(os.listdir(pdir), key=version) if os.path.isdir(pdir) else []:
         if name.endswith("_hbm_traffic.json"):
             try:
                 d = json.load(open(os.path.join(pdir, name)))
