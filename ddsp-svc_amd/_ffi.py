@@ -88,9 +88,11 @@ def lib():
     if _LIB is None:
         with _LOCK:
             if _LIB is None:
-                path = _build.LIB
-                if not os.path.exists(path):
-                    path = _build.build()
+                path = os.environ.get("DDSP_HIP_LIB")          # A/B measurements against another build of the library
+                if not path:
+                    path = _build.LIB
+                    if not os.path.exists(path):
+                        path = _build.build()
                 _LIB = bind(ctypes.CDLL(path))
     return _LIB
 

@@ -99,6 +99,88 @@ struct Plan {
       for (int m = 0; m < 8; ++m) v[m] = t[m];
     }
   }
+
+  // ---- the pair without the last exchange (R = 2) -------------------------------------------------------------
+  // forward_s stops after pass 3 and takes the final DFT_2 over n4 -- the low lane bit -- across lane pairs (DPP), so
+  // the spectrum stays in the "scrambled" layout S
+  //     thread tid = k4 + 2 k1 + 16 k2, slot k3  <->  Z[k1 + 8 k2 + 64 k3 + 512 k4],
+  // two LDS exchanges instead of three.  Pointwise spectral work does not care about the layout; a mirrored bin
+  // Z[-k] is reached through s_index().  transposed() runs the same factorisation backwards (the DFT matrix is
+  // symmetric, so the transposed algorithm is the DFT itself): it takes layout S and returns natural order
+  // v[m] = X[P m + tid], again with two exchanges and with the same twiddle registers.
+  static __device__ __forceinline__ int s_index(int tid, int slot) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    return ((tid >> 1) & 7) + 8 * (tid >> 4) + 64 * slot + 512 * (tid & 1);
+  }
+  // DFT_2 over the low lane bit: even lane a0 + a1, odd lane a0 - a1
+  static __device__ __forceinline__ void lane_pair_dft2(f32x2 (&v)[8], int tid) {
+    const float sgn = (tid & 1) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float px = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k].x), 0xB1, 0xF, 0xF, false));
+      const float py = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k].y), 0xB1, 0xF, 0xF, false));
+      v[k] = f32x2{fmaf(sgn, v[k].x, px), fmaf(sgn, v[k].y, py)};        // quad_perm [1,0,3,2]: the neighbour's value
+    }
+  }
+  // v[n1] = z[P n1 + tid] -> v[k3] = Z[s_index(tid, k3)].  X must be free of readers on entry; on return X is free
+  // and Y may still be read by slower waves.
+  static __device__ __forceinline__ void forward_s(f32x2 (&v)[8], const Tw& tw, f32x2* X, f32x2* Y, int tid) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) X[k * P + tid] = v[k];
+    __syncthreads();
+    {
+      const int k1 = tid / C, c = tid & (C - 1);
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) v[n2] = X[k1 * P + n2 * C + c];
+      dft8(v);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      const int n3 = c / R, n4 = c & (R - 1);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) Y[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) v[n3] = Y[n3 * P + (tid ^ (n3 * R))];
+    dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
+    lane_pair_dft2(v, tid);
+  }
+  // v[k3] = Z[s_index(tid, k3)] -> v[m] = sum_k Z[k] W_N^(k (P m + tid)).  Y must be free of readers on entry; X
+  // becomes free at the first barrier (its last readers are whoever used it before this call); on return Y is
+  // free and X may still be read by slower waves.
+  static __device__ __forceinline__ void transposed(f32x2 (&v)[8], const Tw& tw, f32x2* Y, f32x2* X, int tid) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    lane_pair_dft2(v, tid);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
+    dft8(v);
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) Y[n3 * P + (tid ^ (n3 * R))] = v[n3];
+    __syncthreads();
+    {
+      const int k1 = tid / C, c = tid & (C - 1);
+      const int n3 = c / R, n4 = c & (R - 1);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) v[k2] = Y[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      dft8(v);
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) X[k1 * P + n2 * C + c] = v[n2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = X[k * P + tid];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+    dft8(v);
+  }
 };
 
 }  // namespace fft

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   tw.init(tid);
 #pragma unroll
   for (int m = 0; m < S; ++m) ring[P * m + tid] = 0.f;
-  int cur = 0;                                                 // ex[cur] plays "A"; swapped after every inverse transform
+  int cur = 0;                                                 // ex[cur]: the exchange buffer no wave is reading any more
 
   // Global loads are issued unconditionally from clamped addresses and masked when they are USED: a load whose
   // result feeds a select or the 2u-1 map right away would be waited for on the spot instead of staying in flight
@@ -94,16 +94,20 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     for (int m = 0; m < 4; ++m) r.v[m] = src[P * m];
     return r;
   };
-  // FFT of two tap rows packed as real + i imaginary; returns with z in natural "slot m, lane tid" layout and
-  // the same values in LDS (buffer Bx) for the mirrored read
+  // FFT of a packed pair (real + i imaginary) into the scrambled layout S of fft_r.h (two LDS exchanges; every
+  // spectral array of this kernel lives in S), then the same values parked in LDS at their natural bin index for the
+  // mirrored read Z[-k].  ex[cur] is the buffer no wave reads any more; the mirror copy goes there as well (its
+  // readers of the first pass are behind the second barrier), so afterwards the OTHER buffer is the free one.
+  const int kS0 = PL::s_index(tid, 0);                          // bin of slot 0; slot m holds bin kS0 + 64 m
   auto transform = [&](f32x2 (&z)[S]) -> f32x2* {
-    f32x2* A = ex[cur];
-    f32x2* Bx = ex[cur ^ 1];
-    PL::forward(z, tw, A, Bx, tid);
+    f32x2* X = ex[cur];
+    f32x2* Y = ex[cur ^ 1];
+    PL::forward_s(z, tw, X, Y, tid);
 #pragma unroll
-    for (int m = 0; m < S; ++m) Bx[P * m + tid] = z[m];
-    __syncthreads();                                            // A's pass-4 readers are through: the next transform
-    return Bx;                                                  // may write A at once, and Bx after its first barrier
+    for (int m = 0; m < S; ++m) X[kS0 + 64 * m] = z[m];
+    __syncthreads();
+    cur ^= 1;
+    return X;
   };
   const float ch = 0.25f / (float)NF;                          // the 1/2 of both splits and the 1/N of the inverse
   // Ga = ch * H_j, Gb = ch * H_j+1 from Z = FFT(h_j + i h_j+1):  H_j = (Z[k] + conj Z[-k]) / 2,
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     const f32x2* Zn = transform(z);
 #pragma unroll
     for (int m = 0; m < S; ++m) {
-      const int k = P * m + tid;
+      const int k = kS0 + 64 * m;
       const f32x2 zneg = Zn[(NF - k) & (NF - 1)];
       const f32x2 p = fft::add_conj(z[m], zneg);                // 2 H_j
       const f32x2 d = fft::sub_conj(z[m], zneg);                // 2i H_j+1
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
       const f32x2* Zn = transform(z);
 #pragma unroll
       for (int m = 0; m < S; ++m) {
-        const int k = P * m + tid;
+        const int k = kS0 + 64 * m;
         const f32x2 zneg = Zn[(NF - k) & (NF - 1)];
         const f32x2 p = fft::add_conj(z[m], zneg);              // 2 X1
         const f32x2 d = fft::sub_conj(z[m], zneg);              // 2i X2
@@ -194,14 +198,10 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
         add[i] = addend[ob + t];
       }
     }
-    {
-      f32x2* A = ex[cur];
-      f32x2* Bx = ex[cur ^ 1];
-      PL::forward(V, tw, A, Bx, tid);
-      // no barrier follows (the overlap-add ring is thread-private): slower waves may still read A in their last
-      // pass, so the next transform takes Bx as its first write target
-      cur ^= 1;
-    }
+    // back to time order: the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid.
+    // No barrier follows (the overlap-add ring is thread-private): its second buffer may still be read by the slower
+    // wave, its first -- ex[cur] -- is free again, which is what the next transform expects
+    PL::transposed(V, tw, ex[cur], ex[cur ^ 1], tid);
     // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb-1) hop + n.
     const bool last = q == g.pairs - 1;
     const bool interior = own && !last && (b0 - 1) * FB_HOP + 256 >= 0 && (b0 + 1) * FB_HOP + 256 <= g.T;   // uniform
