@@ -542,13 +542,15 @@ def main():
         for _ in range(3):
             once()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        # one event pair per launch (all enqueued back to back, no synchronisation in between): the average of the
+        # pairs is the launch duration without the gap between dependent launches, which is what a kernel trace reports
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
             once()
-        e1.record()
+            e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
 
     used_impl = a.fir_impl if a.fir_impl else (5 if N <= 512 else 3)
     fir_ms = time_fir(used_impl)
