@@ -64,6 +64,15 @@ struct Upsampler {
     const float b = i1 < r.f ? r.a : (i1 == r.f ? r.b : r.c);
     return fmaf(l0, a, l1 * b);
   }
+  // sample j of frame r.f (t = r.f * hop + j, 0 <= j < hop): in the shift form the frame index of every such sample is
+  // r.f itself, so the two rows are fixed and only the weight varies
+  __device__ __forceinline__ float at3_in_frame(const Row3& r, int j, int hop) const {
+    if (shift > 0) {
+      const float l1 = (float)j * scale;
+      return fmaf(1.0f - l1, r.b, l1 * r.c);
+    }
+    return at3(r, (long)r.f * hop + j);
+  }
   __device__ __forceinline__ float at(const float* __restrict__ row, long stride, long t) const {
     int i0, i1;
     float l0, l1;

@@ -30,7 +30,7 @@ __device__ __forceinline__ void frame_phase(const float* __restrict__ f0_row, in
     int j = lane * SPL + r;
     float v = 0.f;
     if (j < hop) {
-      v = up.at3(rows, (long)f * hop + j);
+      v = up.at3_in_frame(rows, j, hop);
       acc += cfg.term(v);
     }
     o.f0u[r] = v;
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
   const Upsampler::Row3 rows = up.load3(f0_row, f);
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   const long t0 = (long)f * HOP + 2 * tid;
-  const double q0 = cfg.term(up.at3(rows, t0));
-  const double q1 = cfg.term(up.at3(rows, t0 + 1));
+  const double q0 = cfg.term(up.at3_in_frame(rows, 2 * tid, HOP));
+  const double q1 = cfg.term(up.at3_in_frame(rows, 2 * tid + 1, HOP));
   const double mine = q0 + q1;
   const double excl = wave_excl_scan(mine, lane);
   if (lane == 63) wsum[wave] = excl + mine;
@@ -318,8 +318,8 @@ __global__ void __launch_bounds__(256) k_sins_bank2_bwd(const float* __restrict_
   const Upsampler::Row3 rows = up.load3(f0_row, f);
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   const long t0 = (long)f * HOP + 2 * tid;
-  const double q0 = cfg.term(up.at3(rows, t0));
-  const double q1 = cfg.term(up.at3(rows, t0 + 1));
+  const double q0 = cfg.term(up.at3_in_frame(rows, 2 * tid, HOP));
+  const double q1 = cfg.term(up.at3_in_frame(rows, 2 * tid + 1, HOP));
   const double mine = q0 + q1;
   const double excl = wave_excl_scan(mine, lane);
   if (lane == 63) wsum[wave] = excl + mine;

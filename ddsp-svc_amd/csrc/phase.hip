@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
 #pragma unroll
     for (int r = 0; r < SPL; ++r) {
       int j = lane * SPL + r;
-      if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
+      if (j < hop) acc += cfg.term(up.at3_in_frame(rows, j, hop));
     }
     acc = wave_sum(acc);
     if (lane == 0) sums[fr] = acc;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_phase_expand(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < SPL; ++r) {
     int j = lane * SPL + r;
-    if (j < hop) acc += cfg.term(up.at3(rows, (long)f * hop + j));
+    if (j < hop) acc += cfg.term(up.at3_in_frame(rows, j, hop));
     pre[r] = acc;
   }
   double base = phase0[fr] + wave_excl_scan(acc, lane);
