@@ -60,36 +60,39 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
 
   typename PL::Tw tw;
   tw.init(tid);
-  f32x2* A = ex[0];
-  f32x2* Bx = ex[1];
-
-  // forward transform, natural-order copy in Bx, one barrier (see fir_blk.hip): the next transform may follow at once
+  // Transforms as in fir_blk.hip: forward into the scrambled bin layout S of fft_r.h (all spectra of this kernel live
+  // in S; the products are pointwise), the transposed factorisation back to time order, two LDS exchanges each.
+  // ex[cur] is the buffer no wave reads any more.
+  int cur = 0;
+  const int kS0 = PL::s_index(tid, 0);                          // slot m holds bin kS0 + 64 m
+  const f32x2* mir = ex[0];                                     // where the last transform parked its bins by index
   auto transform = [&](f32x2 (&z)[S]) {
-    PL::forward(z, tw, A, Bx, tid);
+    f32x2* X = ex[cur];
+    PL::forward_s(z, tw, X, ex[cur ^ 1], tid);
 #pragma unroll
-    for (int m = 0; m < S; ++m) Bx[P * m + tid] = z[m];
+    for (int m = 0; m < S; ++m) X[kS0 + 64 * m] = z[m];
     __syncthreads();
+    mir = X;
+    cur ^= 1;
   };
   // p = Z[k] + conj Z[-k], d = Z[k] - conj Z[-k] for the thread's 8 bins
   auto split = [&](const f32x2 (&z)[S], f32x2 (&p)[S], f32x2 (&d)[S]) {
 #pragma unroll
     for (int m = 0; m < S; ++m) {
-      const int k = P * m + tid;
-      const f32x2 zneg = Bx[(NF - k) & (NF - 1)];
+      const int k = kS0 + 64 * m;
+      const f32x2 zneg = mir[(NF - k) & (NF - 1)];
       p[m] = fft::add_conj(z[m], zneg);
       d[m] = fft::sub_conj(z[m], zneg);
     }
   };
-  // inverse of V = Va + i Vb (both Hermitian) by conj / forward / conj: re -> ra, im -> rb
+  // inverse of V = Va + i Vb (both Hermitian) by conj / transform / conj: re -> ra, im -> rb, in time order
   auto inverse_pair = [&](const f32x2 (&Va)[S], const f32x2 (&Vb)[S], float (&ra)[S], float (&rb)[S]) {
     f32x2 v[S];
 #pragma unroll
     for (int m = 0; m < S; ++m) v[m] = fft::conj_minus_i_conj(Va[m], Vb[m]);
-    PL::forward(v, tw, A, Bx, tid);
+    PL::transposed(v, tw, ex[cur], ex[cur ^ 1], tid);           // leaves ex[cur] free again
 #pragma unroll
     for (int m = 0; m < S; ++m) { ra[m] = v[m].x; rb[m] = -v[m].y; }
-    // the caller's next transform writes A: swap the roles so it starts in the buffer nobody reads any more
-    f32x2* t = A; A = Bx; Bx = t;
   };
   // (x1, x2) of block bi packed in one transform -> p = 2 X1, d = 2i X2
   auto block_spectra = [&](int bi, f32x2 (&p)[S], f32x2 (&d)[S]) {
