@@ -111,9 +111,9 @@ def stream_of(t):
 _AUX = {}
 
 
-def aux_stream_of(t, rows):
-    """Second stream for the noise branch of the synthesiser tails (include/ddsp_hip.h, ``aux_stream``): one per
-    device, used once the launch is large enough for the overlap to matter.  ``DDSP_HIP_ONE_STREAM=1`` disables it."""
+def aux_torch_stream(t, rows):
+    """The cached second ``torch.cuda.Stream`` of ``t``'s device, or None (small launches, CPU tensors under the
+    emulator, ``DDSP_HIP_ONE_STREAM=1``, or a device other than the current one)."""
     if not t.is_cuda or rows < 4096 or os.environ.get("DDSP_HIP_ONE_STREAM"):
         return None
     if torch.cuda.current_device() != t.device.index:      # the library's fork / join events belong to the current device
@@ -121,7 +121,30 @@ def aux_stream_of(t, rows):
     s = _AUX.get(t.device)
     if s is None:
         s = _AUX[t.device] = torch.cuda.Stream(device=t.device)
-    return s.cuda_stream
+    return s
+
+
+def aux_stream_of(t, rows):
+    """Second stream for the noise branch of the synthesiser tails (include/ddsp_hip.h, ``aux_stream``): one per
+    device, used once the launch is large enough for the overlap to matter.  ``DDSP_HIP_ONE_STREAM=1`` disables it."""
+    s = aux_torch_stream(t, rows)
+    return None if s is None else s.cuda_stream
+
+
+def on_aux_stream(fn, ref, rows):
+    """Run ``fn()`` (a branch that is independent of what the caller's stream does next) on the second stream, forked
+    behind the caller's stream and joined back into it; autograd runs the branch's backward on the same stream.
+    Returns ``fn``'s tensor."""
+    aux = aux_torch_stream(ref, rows)
+    if aux is None:
+        return fn()
+    main = torch.cuda.current_stream(ref.device)
+    aux.wait_stream(main)
+    with torch.cuda.stream(aux):
+        out = fn()
+    main.wait_stream(aux)
+    out.record_stream(main)                                # allocated under the second stream, consumed on the first
+    return out
 
 
 def ptr(t):

@@ -248,14 +248,16 @@ def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, nois
     from .core import fft_convolve
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
     B, F = f0.shape
+    nz = _f32c(noise.reshape(B, -1))
+    if noise_is_u01:
+        nz = nz * 2 - 1                                                                        # :854
+    # the noise branch does not meet the harmonic chain before the final sum: second stream (forward and backward)
+    noise_f = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
+        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), f0, B * F)                      # :855-858
     comb = combtooth(f0_frames, state, sampling_rate, block_size)                             # vocoder.py:839-840
     h1 = fft_convolve(comb, AllpassTapsFunction.apply(group_delay))                           # :843-846
     hw = (1.5 * float(sampling_rate)) / (f0 + 1e-3)                                           # :851
     harmonic = fft_convolve(h1, MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw))   # :847-851
-    nz = _f32c(noise.reshape(B, -1))
-    if noise_is_u01:
-        nz = nz * 2 - 1                                                                        # :854
-    noise_f = fft_convolve(nz, MagnitudeTapsFunction.apply(noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None))   # :855-858
     return harmonic + noise_f, harmonic, noise_f
 
 
@@ -264,12 +266,13 @@ def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude
     """Sins DSP tail as a composition of differentiable primitives (training).  Returns (signal, harmonic, noise)."""
     from .core import fft_convolve
     B = f0_frames.shape[0]
-    sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)       # vocoder.py:585-594
-    harmonic = fft_convolve(sinus, AllpassTapsFunction.apply(group_delay))                            # :597-600
     nz = _f32c(noise.reshape(B, -1))
     if noise_is_u01:
         nz = nz * 2 - 1                                                                                # :603
-    noise_f = fft_convolve(nz, MagnitudeTapsFunction.apply(noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None))   # :604-607
+    noise_f = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
+        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), nz, B * group_delay.shape[1])         # :604-607
+    sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)       # vocoder.py:585-594
+    harmonic = fft_convolve(sinus, AllpassTapsFunction.apply(group_delay))                            # :597-600
     return harmonic + noise_f, harmonic, noise_f
 
 

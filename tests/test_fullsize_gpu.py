@@ -139,6 +139,33 @@ def test_tail_second_stream_full_size(cuda, batch, kind, monkeypatch):
         assert torch.equal(o, one)
 
 
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_training_second_stream_full_size(cuda, batch, kind, monkeypatch):
+    """forward + backward of the differentiable compositions with the noise branch on the second stream (the
+    default at this size): signal and control gradients bit-identical to the one-stream order, step after step"""
+    from ddsp_svc_amd import _ffi, synth
+    f0, ctrls, noise = batch
+    fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+    st = synth.phase(f0, SR, HOP)
+    R = torch.randn(B, T, generator=torch.Generator().manual_seed(3)).to(cuda)
+
+    def step():
+        c = [x.detach().clone().requires_grad_(True) for x in ctrls]
+        sig = fn(f0, st, c[0], c[1], c[2], noise, SR, HOP)[0]
+        (sig * R).sum().backward()
+        return sig.detach(), [x.grad for x in c]
+
+    assert _ffi.aux_torch_stream(f0, B * F) is not None
+    with monkeypatch.context() as m:
+        m.setattr(_ffi, "aux_torch_stream", lambda t, rows: None)
+        sig1, g1 = step()
+    for _ in range(3):
+        sig2, g2 = step()
+        assert torch.equal(sig1, sig2)
+        for a, b2 in zip(g1, g2):
+            assert torch.isfinite(a).all() and torch.equal(a, b2)
+
+
 def test_phase_checksum_and_restart(cuda, batch):
     """phase_frames of the batch against the oracle for every utterance (cheap), and the additivity of the scan:
     synthesising the second half with initial_phase = phase reached at the split equals the tail of the full run"""
