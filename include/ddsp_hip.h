@@ -136,7 +136,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
                            float* signal, float* harmonic_or_null, float* noise_out_or_null,
                            void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream);
 
-/* aux_stream (both calls above): NULL, or a second stream of the same device.  The noise branch (its taps and its
+/* aux_stream (both calls above): NULL, or a second stream of the same device, which must be the calling thread's
+ * current device (hipSetDevice) -- the fork / join events are created there.  The noise branch (its taps and its
  * filter: independent of the harmonic chain until the final sum) is then enqueued there -- forked after everything
  * already on `stream`, joined back before the last kernel on `stream`, so for the caller the call still behaves as
  * one operation on `stream` -- and fills the machine where the chain's kernels leave it idle (tails, store phases):
