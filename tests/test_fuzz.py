@@ -1,0 +1,78 @@
+"""Seeded random shapes through the fused tails (batch, frame count incl. 1 and odd counts, bin counts on and off the
+256-column table, harmonic counts, run splits of the hop-block FIR / the spectral filter) against the oracle: the
+edge cases nobody thought of.  Tolerance: 2e-5 relative RMS per output (the tails sit at 1e-6 ... 5e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddsp_oracle as O
+from tests.backends import BACKENDS, dev  # noqa: F401
+
+SR, HOP = 44100, 512
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("seed", range(8))
+def test_random_harmonic_plus_noise_tails(dev, seed, monkeypatch):
+    from ddsp_svc_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for _ in range(3):
+        B, F = int(rng.integers(1, 4)), int(rng.integers(1, 45))
+        n = int(rng.choice([256, 256, 129, 65, 33, 252, 200]))
+        kind = rng.choice(["combsub", "sins"])
+        run = int(rng.choice([0, 1, 2, 3, 5]))
+        if run:
+            monkeypatch.setenv("DDSP_HIP_BLK_RUN", str(run))
+        else:
+            monkeypatch.delenv("DDSP_HIP_BLK_RUN", raising=False)
+        H = int(rng.choice([256, 128, 40, 17])) if kind == "sins" else n
+        f0 = O.synth_f0(B, F, SR, HOP, seed=int(rng.integers(1 << 30)))
+        ctrls = [rng.standard_normal((B, F, s)).astype(np.float32) * 0.7 for s in (H, n, n)]
+        noise = rng.random((B, F * HOP)).astype(np.float32) * 2 - 1
+        st = synth.phase(t(f0), SR, HOP)
+        fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+        ofn = O.combsub_dsp if kind == "combsub" else O.sins_dsp
+        out = fn(t(f0), st, t(ctrls[0]), t(ctrls[1]), t(ctrls[2]), t(noise), SR, HOP)
+        ref = ofn(f0, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP)
+        for got, key in zip(out, ("signal", "harmonic", "noise")):
+            e, r = _rms(got.cpu().numpy() - ref[key]), _rms(ref[key])
+            assert np.isfinite(e) and e <= 2e-5 * max(r, 1e-9), (kind, B, F, n, H, run, key, e, r)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("seed", range(4))
+def test_random_spectral_tails(dev, seed, monkeypatch):
+    from ddsp_svc_amd import synth
+    rng = np.random.default_rng(2000 + seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for _ in range(2):
+        B, F = int(rng.integers(1, 3)), int(rng.integers(1, 30))
+        kind = rng.choice(["fast", "super"])
+        run = int(rng.choice([0, 1, 2, 3]))
+        if run:
+            monkeypatch.setenv("DDSP_HIP_STFT_RUN", str(run))
+        else:
+            monkeypatch.delenv("DDSP_HIP_STFT_RUN", raising=False)
+        f0 = O.synth_f0(B, F, SR, HOP, seed=int(rng.integers(1 << 30)))
+        if kind == "fast":
+            c = [rng.standard_normal((B, F, 513)).astype(np.float32) * 0.5 for _ in range(3)]
+            noise = rng.random((B, F * HOP)).astype(np.float32) * 2 - 1
+            w = torch.sqrt(torch.hann_window(1024)).to(dev)
+            st = synth.phase(t(f0), SR, HOP)
+            got = synth.combsubfast_synth(t(f0), st, t(c[0]), t(c[1]), t(c[2]), t(noise), w, SR, HOP)
+            ref = O.combsubfast_dsp(f0, c[0], c[1], c[2], noise, SR, HOP)
+        else:
+            c = [rng.standard_normal((B, F, 1025)).astype(np.float32) * 0.5 for _ in range(4)]
+            noise = rng.standard_normal((B, F * HOP)).astype(np.float32)
+            w = torch.hann_window(2048).to(dev)
+            st = synth.fast_source(t(f0), SR, HOP)
+            got = synth.combsubsuperfast_synth(t(f0), st, t(c[0]), t(c[1]), t(c[2]), t(c[3]), t(noise), w, SR, HOP)
+            ref = O.combsubsuperfast_dsp(f0, c[0], c[1], c[2], c[3], noise, SR, HOP)
+        ref = ref["signal"] if isinstance(ref, dict) else ref
+        e, r = _rms(got.cpu().numpy() - ref), _rms(ref)
+        assert np.isfinite(e) and e <= 2e-5 * max(r, 1e-9), (kind, B, F, run, e, r)
