@@ -270,14 +270,17 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
         Cb = cn;
       }
     }
-    const float* ap = amp + 32 * blk;
+    const float4* ap = reinterpret_cast<const float4*>(amp + 32 * blk);   // (A, dA) of two harmonics per 16-byte read
     f32x2 P = {0.f, 0.f}, Q = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float a0 = ap[2 * j], da = ap[2 * j + 1];
-      const f32x2 a = __builtin_elementwise_fma(lam, f32x2{da, da}, f32x2{a0, a0});
-      P = __builtin_elementwise_fma(ts[j], a, P);
-      Q = __builtin_elementwise_fma(tc[j], a, Q);
+    for (int jj = 0; jj < 8; ++jj) {
+      const float4 q = ap[jj];
+      const f32x2 a = __builtin_elementwise_fma(lam, f32x2{q.y, q.y}, f32x2{q.x, q.x});
+      const f32x2 b = __builtin_elementwise_fma(lam, f32x2{q.w, q.w}, f32x2{q.z, q.z});
+      P = __builtin_elementwise_fma(ts[2 * jj], a, P);
+      Q = __builtin_elementwise_fma(tc[2 * jj], a, Q);
+      P = __builtin_elementwise_fma(ts[2 * jj + 1], b, P);
+      Q = __builtin_elementwise_fma(tc[2 * jj + 1], b, Q);
     }
     S = __builtin_elementwise_fma(Cb, P, S);
     S = __builtin_elementwise_fma(Sb, Q, S);
