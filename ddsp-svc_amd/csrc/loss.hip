@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(SL_THREADS) k_sss_grad(const float2* __restric
 }
 
 int sss_chunks(int B, long per_utt) {
-  long c = (per_utt + 4095) / 4096;
-  const long want = (4096 + (B > 0 ? B : 1) - 1) / (B > 0 ? B : 1);      // ~4 k workgroups on the chip
+  long c = (per_utt + 8191) / 8192;
+  const long want = (2048 + (B > 0 ? B : 1) - 1) / (B > 0 ? B : 1);      // ~2 k workgroups on the chip, >= 8 k bins each
   if (c > want) c = want;
   if (c < 1) c = 1;
   return (int)c;
