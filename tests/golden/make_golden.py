@@ -17,6 +17,10 @@ Fixtures (all float32 unless noted):
   sinesrc.npz       nsf_hifigan.models.SourceModuleHnNSF.forward with its two random draws injected  models.py:140-204
   sssloss.npz       ddsp.loss.SSSLoss / RSSLoss forward + autograd w.r.t. x_pred, with a torch.stft stand-in for the absent
                     torchaudio.transforms.Spectrogram (documented semantics restated)                  loss.py:9-54
+  cfg1_*.npz        BASELINE cfg 1 exactly (B=1, 5 s, F=431): CombSub 256/128/256, Sins 128/256/256, infer True/False; inputs from
+                    seeds, outputs decimated                                                  vocoder.py:556-611, :811-862
+  phase_10s.npz     the 10 s (F=862, 441 344-term) phase scan, infer True/False                        vocoder.py:564-575
+  filter_n{128,257,512}.npz, combsub_mixed.npz, sins_mixed.npz   tap synthesis, filters and tails at the larger bin counts
   *_grad.npz        autograd of Sins / CombSub / CombSubFast / CombSubSuperFast.forward w.r.t. the controls Unit2Control produced,
                     for a random cotangent R: d(sum(signal * R)) / d ctrl
 """
@@ -97,10 +101,159 @@ def loss_fixture():
     np.savez(os.path.join(HERE, "sssloss.npz"), **out)
 
 
+DECIM = 97          # prime: the decimated samples walk through every position inside a hop block
+
+
+def input_checks(a):
+    """A few numbers that identify a regenerated input array (sum, sum of squares, first / last values): the BASELINE-
+    shape fixtures keep their large inputs as seeds, and the tests refuse to compare if the regenerated array differs."""
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a.sum(), np.square(a).sum(), a[0], a[1], a[a.size // 2], a[-1]], np.float64)
+
+
+def summarise(y, hop=512, windows=((0, 1536), (100 * 512 - 300, 100 * 512 + 900))):
+    """Small-on-disk view of a [B,T] waveform: every DECIM-th sample, the per-frame RMS, two contiguous stretches (the
+    start with its zero-state transient, one interior stretch across frame boundaries)."""
+    y = np.asarray(y)
+    B, T = y.shape
+    out = {"dec": y[:, ::DECIM].copy(), "frame_rms": np.sqrt(np.mean(np.square(y.astype(np.float64)).reshape(B, T // hop, hop), -1)).astype(np.float32)}
+    for i, (a, b) in enumerate(windows):
+        a, b = max(0, min(a, T)), max(0, min(b, T))
+        out[f"win{i}"] = y[:, a:b].copy()
+        out[f"win{i}_range"] = np.array([a, b], np.int64)
+    return out
+
+
+class FixedControls(torch.nn.Module):
+    """stands in for Unit2Control inside the UNMODIFIED reference module: returns the drawn controls (the DSP tail is
+    what is being pinned; ddsp/unit2control.py:107-109 returns ``(controls dict, hidden)``)"""
+
+    def __init__(self, ctrls):
+        super().__init__()
+        self.ctrls = ctrls
+
+    def forward(self, units, f0, phase, volume, spk_id=None, spk_mix_dict=None):
+        self.phase_frames = phase
+        return self.ctrls, torch.zeros(units.shape[0], units.shape[1], 1)
+
+
+def baseline_shape_fixtures():
+    """Reference-pinned fixtures at the BASELINE.json shapes that round 1 covered only transitively (missing #2
+    and #7): cfg 1 exactly (B = 1, 5 s, F = 431: CombSub 256/128/256 and Sins 128/256/256 = configs/sins.yaml:20-22), the
+    10 s phase scan (F = 862, vocoder.py:564-575, infer True / False), and the tap synthesis + tails at n_mag 128 / 257 /
+    512.  Large inputs are regenerated from seeds (oracle.synth_*: numpy PCG64 streams) and identified by input_checks;
+    large outputs are stored decimated."""
+    from oracle import ddsp_oracle as O
+    core, V = import_reference()
+    sr, hop = 44100, 512
+
+    # ---- cfg 1: B = 1, 5 s ------------------------------------------------------------------------------------------
+    F1 = 5 * sr // hop + 1                                    # vocoder.py:222 frame rule -> 431
+    assert F1 == 431
+    for kind, sizes, seed in (("combsub", (256, 128, 256), 910), ("sins", (128, 256, 256), 920)):
+        for infer in (True, False):
+            f0 = O.synth_f0(1, F1, sr, hop, seed=seed)
+            if kind == "combsub":
+                f0 = np.clip(f0 * np.float32(1.7), 65, 800).astype(np.float32)     # crosses 259 Hz: dynamic-window clamp quirk
+            ctrls = O.synth_controls(1, F1, sizes, seed=seed + 1, scale=0.7)
+            noise = O.synth_noise(1, F1 * hop, seed=seed + 2)
+            if kind == "sins":
+                model = V.Sins(sr, hop, *sizes, n_unit=8, n_spk=1).eval()
+                names = ("amplitudes", "group_delay", "noise_magnitude")
+            else:
+                model = V.CombSub(sr, hop, *sizes, n_unit=8, n_spk=1).eval()
+                names = ("group_delay", "harmonic_magnitude", "noise_magnitude")
+            model.unit2ctrl = FixedControls({k: torch.from_numpy(c) for k, c in zip(names, ctrls)})
+            u01 = torch.from_numpy((noise + np.float32(1)) / np.float32(2))            # exact inverse of 2u-1 on this grid
+            assert np.array_equal((u01 * 2 - 1).numpy(), noise)
+            with torch.no_grad(), mock.patch("torch.rand_like", side_effect=lambda t: u01.to(t)):
+                signal, _, (harm, nz) = model(torch.zeros(1, F1, 8), torch.from_numpy(f0), torch.zeros(1, F1, 1), infer=infer)
+            out = dict(f0_frames=f0, sizes=np.array(sizes), seeds=np.array([seed + 1, seed + 2]), ctrl_scale=np.float64(0.7),
+                       decim=np.int64(DECIM), phase_frames=model.unit2ctrl.phase_frames.numpy()[..., 0],
+                       noise_check=input_checks(noise))
+            for k, c in zip(names, ctrls):
+                out["check_" + k] = input_checks(c)
+            for key, y in (("signal", signal), ("harmonic", harm), ("noise_out", nz)):
+                for kk, vv in summarise(y.numpy()).items():
+                    out[f"{key}_{kk}"] = vv
+            np.savez_compressed(os.path.join(HERE, f"cfg1_{kind}_infer{int(infer)}.npz"), **out)
+
+    # ---- 10 s phase scan: F = 862, 441 344-term cumsum ---------------------------------------------------------------
+    F2 = 10 * sr // hop + 1
+    assert F2 == 862
+    f0 = O.synth_f0(3, F2, sr, hop, seed=930)
+    f0[1] = 800.0                                             # largest accumulated phase: 8 000 cycles
+    f0[2] = np.clip(f0[2] * np.float32(0.4), 65, 800)
+    f0t = torch.from_numpy(f0)
+    out = {"f0_frames": f0, "decim": np.int64(DECIM)}
+    for infer in (True, False):
+        f0u = core.upsample(f0t, hop)
+        x = torch.cumsum(f0u.double() / sr, axis=1) if infer else torch.cumsum(f0u / torch.tensor(sr), axis=1)
+        x = x - torch.round(x)
+        x = x.to(f0u)
+        phase = 2 * np.pi * x
+        out[f"x_dec_infer{int(infer)}"] = x[:, ::DECIM, 0].numpy()
+        out[f"x_tail_infer{int(infer)}"] = x[:, -2048:, 0].numpy()
+        out[f"phase_frames_infer{int(infer)}"] = phase[:, ::hop, 0].numpy()
+    np.savez_compressed(os.path.join(HERE, "phase_10s.npz"), **out)
+
+    # ---- tap synthesis + filters at n_mag 128 / 257 / 512 ------------------------------------------------------------
+    for n_mag, Fr in ((128, 7), (257, 6), (512, 5)):
+        g = torch.Generator().manual_seed(300 + n_mag)
+        B = 2
+        T = Fr * hop
+        audio = torch.rand(B, T, generator=g) * 2 - 1
+        c = torch.randn(B, Fr, n_mag, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=n_mag))
+        f0f[1] = f0f[1] * 0 + 640.0
+        gd = np.pi * torch.tanh(c)
+        ap = torch.exp(1.j * torch.cumsum(gd, axis=-1))
+        mag = torch.exp(c)
+        zmag = torch.complex(mag, torch.zeros_like(mag))
+        hw = 1.5 * sr / (f0f + 1e-3)
+        np.savez_compressed(os.path.join(HERE, f"filter_n{n_mag}.npz"),
+                            audio=audio.numpy(), ctrl=c.numpy(), f0_frames=f0f.numpy(), half_width=hw.numpy()[..., 0],
+                            y_roll=core.frequency_filter(audio, ap, hann_window=False).numpy(),
+                            y_hann=core.frequency_filter(audio, zmag, hann_window=True).numpy(),
+                            y_dyn=core.frequency_filter(audio, zmag, hann_window=True, half_width_frames=hw).numpy(),
+                            ir_roll=core.frequency_impulse_response(ap, hann_window=False).numpy(),
+                            ir_hann=core.frequency_impulse_response(zmag).numpy(),
+                            ir_dyn=core.frequency_impulse_response(zmag, half_width_frames=hw).numpy())
+
+    # ---- module tails with mixed bin counts, through the real Unit2Control (captured controls) ------------------------
+    def run_module(kind, sizes, B, Fr, seed):
+        torch.manual_seed(seed)
+        model = (V.Sins if kind == "sins" else V.CombSub)(sr, hop, sizes[0], sizes[1], sizes[2], n_unit=64, n_spk=1).eval()
+        with torch.no_grad():
+            model.unit2ctrl.dense_out.weight_g.mul_(4.0)
+        g = torch.Generator().manual_seed(seed + 1)
+        units = torch.randn(B, Fr, 64, generator=g)
+        f0f = torch.from_numpy(O.synth_f0(B, Fr, sr, hop, seed=seed + 2))
+        f0f[0] = torch.clamp(f0f[0] * 2.2, 65, 800)
+        vol = torch.rand(B, Fr, 1, generator=g) * 0.1
+        u01 = torch.rand(B, Fr * hop, generator=g)
+        cap = {}
+        hk = model.unit2ctrl.register_forward_hook(lambda mod, i, o: cap.update(ctrls=o[0]))
+        with torch.no_grad(), mock.patch("torch.rand_like", side_effect=lambda t: u01.to(t)):
+            signal, hidden, (harm, nz) = model(units, f0f, vol, infer=True)
+        hk.remove()
+        return dict(f0_frames=f0f.numpy(), noise=(u01 * 2 - 1).numpy(), signal=signal.numpy(), harmonic=harm.numpy(),
+                    noise_out=nz.numpy(), sizes=np.array(sizes),
+                    **{"ctrl_" + k: v.detach().numpy() for k, v in cap["ctrls"].items()})
+
+    np.savez_compressed(os.path.join(HERE, "combsub_mixed.npz"), **run_module("combsub", (257, 128, 512), 2, 9, 940))
+    np.savez_compressed(os.path.join(HERE, "sins_mixed.npz"), **run_module("sins", (64, 512, 128), 1, 9, 950))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz") and (f.startswith(("cfg1_", "phase_10s", "combsub_mixed", "sins_mixed")) or f[8:-4] in ("128", "257", "512")):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
 def main():
     from oracle import ddsp_oracle as O
     if "--only-loss" in sys.argv:
         return loss_fixture()
+    if "--baseline-shapes" in sys.argv:
+        return baseline_shape_fixtures()
     core, V = import_reference()
     torch.manual_seed(0)
     sr, hop = 44100, 512
@@ -379,6 +532,7 @@ def main():
                      basis=basis if tag == "a" else np.zeros(0, np.float32))
 
     loss_fixture()
+    baseline_shape_fixtures()
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
