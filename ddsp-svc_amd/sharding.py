@@ -27,35 +27,69 @@ def take_shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[lo:hi]
 
 
-def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0, group=None) -> Optional[torch.Tensor]:
+def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0, group=None, async_op: bool = False):
     """Collect the per-rank ``[b_local, T]`` waveforms into ``[n_total, T]``.
 
-    ``dst=None`` -> all-gather (every rank gets the batch); otherwise only ``dst`` receives it and the
-    others return ``None``.  Equal shards go through one ``all_gather_into_tensor`` / ``gather``;
-    ragged shards are padded to the largest shard (at most one utterance of padding per rank).
-    On an 8-GPU MI355X node each peer's shard travels over its own xGMI link, so the gather is
-    link-parallel; no ring is forced."""
+    ``dst=None`` -> all-gather (every rank gets the batch); otherwise only the rank whose rank INSIDE ``group`` is
+    ``dst`` receives it and the others return ``None``.  Equal shards go through one ``all_gather_into_tensor`` /
+    ``gather`` whose receive buffers are slices of the result tensor (no second copy on the root); ragged shards are
+    padded to the largest shard (at most one utterance of padding per rank).  On an 8-GPU MI355X node each peer's shard
+    travels over its own xGMI link, so the gather is link-parallel; no ring is forced.
+
+    ``async_op=True`` returns ``(finish, work)`` instead: the collective is enqueued and ``finish()`` waits for it and
+    returns the tensor (or None) -- a caller that synthesises in chunks can enqueue the gather of chunk i and start
+    chunk i+1 before waiting."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)                                  # rank inside ``group``: shards are numbered in group order
     counts = shard_counts(n_total, world)
+    if local.dim() != 2:
+        raise ValueError("local must be [b_local, T]")
     if local.shape[0] != counts[rank]:
         raise ValueError("local shard has %d utterances, expected %d" % (local.shape[0], counts[rank]))
+    if dst is not None and not (0 <= dst < world):
+        raise ValueError("dst must be a rank inside the group")
     T = local.shape[1]
     mx = max(counts)
     send = local.contiguous()
     if send.shape[0] < mx:
         pad = torch.zeros(mx - send.shape[0], T, dtype=send.dtype, device=send.device)
         send = torch.cat([send, pad], 0)
+    receiver = dst is None or rank == dst
+    out = torch.empty(world * mx, T, dtype=send.dtype, device=send.device) if receiver else None
     if dst is None:
-        out = torch.empty(world * mx, T, dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(out, send, group=group)
-        parts = out.view(world, mx, T)
+        work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
     else:
-        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, bufs, dst=dst, group=group)
-        if rank != dst:
+        bufs = [out[r * mx:(r + 1) * mx] for r in range(world)] if receiver else None
+        # torch.distributed addresses the destination by GLOBAL rank; translate the group-local one
+        gdst = dist.get_global_rank(group, dst) if group is not None else dst
+        work = dist.gather(send, bufs, dst=gdst, group=group, async_op=async_op)
+
+    def finish():
+        if async_op and work is not None:
+            work.wait()
+        if not receiver:
             return None
-        parts = torch.stack(bufs, 0)
-    if all(c == mx for c in counts):
-        return parts.reshape(world * mx, T)
-    return torch.cat([parts[r, :counts[r]] for r in range(world)], 0)
+        if all(c == mx for c in counts):
+            return out
+        parts = out.view(world, mx, T)
+        return torch.cat([parts[r, :counts[r]] for r in range(world)], 0)
+
+    if async_op:
+        return finish, work
+    return finish()
+
+
+def synth_sharded(fn, n_total: int, rank: int, world: int, *batched, logical_shards: int = 1):
+    """Run ``fn(*slices) -> [b, T]`` on this rank's contiguous slice of every ``[n_total, ...]`` tensor in ``batched``
+    (utterances are independent: no collective on the data path).  ``logical_shards > 1`` further splits the rank's
+    slice into that many contiguous pieces run back to back -- what a 1-GPU box uses to exercise the partition
+    arithmetic of a G-GPU job -- and concatenates the results."""
+    lo, hi = shard_bounds(n_total, rank, world)
+    outs = []
+    for g in range(logical_shards):
+        a, b = shard_bounds(hi - lo, g, logical_shards)
+        if b > a:
+            outs.append(fn(*(t[lo + a:lo + b] for t in batched)))
+    if not outs:
+        return None
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)

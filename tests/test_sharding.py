@@ -1,4 +1,7 @@
-"""Multi-GPU layer on CPU: partition arithmetic and the optional gather over a world_size-2 gloo group."""
+"""Multi-GPU layer: partition arithmetic, the optional gather over world_size-2 / -3 gloo groups on CPU (ranks shard the
+REAL synthesiser output -- the HIP sources under the CPU emulator -- and the gathered batch must equal the unsharded one),
+a sub-group that does not start at global rank 0, and on the MI355X a 1-rank RCCL communicator with G logical shards
+(what a 1-GPU box can exercise of the G-GPU job)."""
 import os
 
 import pytest
@@ -50,3 +53,131 @@ def test_gather_world2_gloo(n_total, dst):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _emu_backend():
+    """what tests/backends.py's ``emu`` fixture does, for a spawned worker process"""
+    import ctypes
+    from ddsp_svc_amd import _ffi
+    from tests.hipemu import build as emu_build
+    _ffi._LIB = _ffi.bind(ctypes.CDLL(emu_build.build()))
+    _ffi.check_device = lambda *t: None
+
+
+def _synth_inputs(n_total, F, device):
+    from oracle import ddsp_oracle as O
+    f0 = torch.from_numpy(O.synth_f0(n_total, F, seed=77)).to(device)
+    f0[0] = torch.clamp(f0[0] * 2.2, 65, 800)
+    cg, ch, cn = (torch.from_numpy(c).to(device) for c in O.synth_controls(n_total, F, [33, 65, 17], seed=78))
+    noise = torch.from_numpy(O.synth_noise(n_total, F * 512, seed=79)).to(device)
+    return f0, cg, ch, cn, noise
+
+
+def _combsub(f0, cg, ch, cn, noise):
+    from ddsp_svc_amd import synth
+    st = synth.phase(f0, 44100, 512)
+    return synth.combsub_synth(f0, st, cg, ch, cn, noise, 44100, 512, want_components=False)[0]
+
+
+def _synth_worker(rank, world, port, n_total, dst, use_async, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _emu_backend()
+        from ddsp_svc_amd.sharding import gather_utterances, synth_sharded
+        inputs = _synth_inputs(n_total, 5, "cpu")
+        local = synth_sharded(_combsub, n_total, rank, world, *inputs)
+        if use_async:
+            finish, _ = gather_utterances(local, n_total, dst=dst, async_op=True)
+            got = finish()
+        else:
+            got = gather_utterances(local, n_total, dst=dst)
+        ok = True
+        if dst is None or rank == dst:
+            full = _combsub(*inputs)                                  # the unsharded batch, same kernels
+            ok = got is not None and got.shape == full.shape and torch.equal(got, full) and bool(full.abs().max() > 1e-3)
+        else:
+            ok = got is None
+        q.put((rank, ok))
+    except Exception as e:                                            # surface the reason instead of a queue timeout
+        q.put((rank, repr(e)))
+    dist.destroy_process_group()
+
+
+def _run(target, world, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() * 7 + hash(args) % 997) % 2000
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+@pytest.mark.parametrize("n_total,dst,use_async", [(4, 0, False), (3, 1, False), (3, None, True)])
+def test_sharded_synth_world2_gloo(n_total, dst, use_async):
+    """every rank synthesises its slice with the real kernels (emulated); gathered == unsharded, bit for bit"""
+    res = _run(_synth_worker, 2, (n_total, dst, use_async))
+    assert all(ok is True for _, ok in res), res
+
+
+def _subgroup_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ddsp_svc_amd.sharding import gather_utterances, take_shard
+        grp = dist.new_group([1, 2])                                  # does not contain global rank 0
+        ok = True
+        if rank in (1, 2):
+            full = torch.arange(n_total * 4, dtype=torch.float32).reshape(n_total, 4)
+            local = take_shard(full, rank - 1, 2)
+            got = gather_utterances(local, n_total, dst=1, group=grp)  # group-local destination 1 = global rank 2
+            ok = (got is not None and torch.equal(got, full)) if rank == 2 else got is None
+        q.put((rank, ok))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    dist.destroy_process_group()
+
+
+def test_gather_subgroup_world3_gloo():
+    res = _run(_subgroup_worker, 3, (5,))
+    assert all(ok is True for _, ok in res), res
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_logical_shards_gpu():
+    """1-GPU box: a 1-rank RCCL communicator (backend nccl) + G = 4 logical shards of the real CombSub synthesis, gathered
+    through the same call the 8-GPU job uses -> equal to the unsharded batch"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ddsp_svc_amd.sharding import gather_utterances, synth_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 1000)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        probe = torch.ones(4, device=dev)
+        dist.all_reduce(probe)                                         # the communicator works
+        assert float(probe.sum()) == 4.0
+        def same(a, b):          # the filter's workgroup run length may depend on the batch size: equal up to rounding
+            return a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        inputs = _synth_inputs(8, 40, dev)
+        full = _combsub(*inputs)
+        local = synth_sharded(_combsub, 8, 0, 1, *inputs, logical_shards=4)
+        for dst in (0, None):
+            got = gather_utterances(local, 8, dst=dst)
+            assert same(got, full)
+        finish, _ = gather_utterances(local, 8, dst=0, async_op=True)
+        assert same(finish(), full)
+        # shard g of a G-GPU job == rows of the unsharded batch (what rank g of the 8-GPU run computes)
+        for g in range(4):
+            part = synth_sharded(_combsub, 8, g, 4, *inputs)
+            assert same(part, full[2 * g:2 * g + 2])
+    finally:
+        dist.destroy_process_group()
