@@ -8,10 +8,18 @@ noise) are already in HBM; only ``signal`` is written (the (harmonic, noise) tup
 caller discards is not materialised).  Multi-GPU: one process per GPU, utterances sharded, no
 data-path collective ("weak" scaling: B per GPU fixed).
 
+``--gpus N`` with N > 1 and no RANK in the environment re-executes itself under ``torch.distributed.run`` with N ranks
+(one per GPU, backend nccl = RCCL); under an external launcher it checks WORLD_SIZE == N.  It never falls back to fewer
+ranks: fewer than N visible devices is an error.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      the dominant kernel (the time-varying FIR, k_fir_blk) timed alone with events on the launch stream
-  cpu_baseline  the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
-                on this host's cores over a bounded sample of the same workload (N=1 only)
+  roofline               the dominant kernel (the time-varying FIR, k_fir_blk) timed alone with events on the launch stream
+  roofline_step_traffic  PMC HBM bytes of one whole step (committed profiles/*_hbm_traffic.json) over its algorithmic bytes
+  ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
+  cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
+                         on this host's cores over a bounded sample of the same workload (N=1 only)
+  cpu_baseline_aten_chain  the reference's op chain walked with torch CPU operators (oracle/aten_chain.py), all cores
+  value_module_mode      the drop-in module with a stand-in Unit2Control producing the controls on the GPU (control mode (i))
 """
 import argparse
 import json
@@ -56,9 +64,21 @@ def model_sizes(kind, bins):
     return (bins,) * 3
 
 
+def synthetic_f0(B, F, seed):
+    """vibrato + random-walk drift curves clamped to [65, 800] Hz, strictly positive, some utterances above
+    259 Hz (the dynamic-window clamp of core.py:245 is exercised); ``[B,F,1]`` float32"""
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(100.0, 400.0, size=(B, 1))
+    depth = rng.uniform(0.0, 1.0, size=(B, 1))
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=(B, 1))
+    drift = np.cumsum(rng.normal(0.0, 0.05, size=(B, F)), axis=1)
+    t = np.arange(F)[None, :] * HOP / SR
+    semitones = depth * np.sin(2.0 * np.pi * 5.5 * t + phi) + 0.5 * drift
+    return np.clip(base * 2.0 ** (semitones / 12.0), 65.0, 800.0).astype(np.float32)[:, :, None]
+
+
 def make_inputs(kind, B, F, sizes, device, seed):
-    from oracle import ddsp_oracle as O            # only the synthetic-input generators
-    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=seed)).to(device)
+    f0 = torch.from_numpy(synthetic_f0(B, F, seed)).to(device)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     ctrl = torch.randn(B, F, sum(sizes), generator=g).to(device)      # one tensor, split into strided views
     ctrls = torch.split(ctrl, list(sizes), dim=-1)
@@ -146,16 +166,161 @@ def _cpu_mel_worker(args):
     return float(O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)).max())
 
 
+def step_traffic(model):
+    """PMC HBM bytes of ONE whole step of ``model`` from the newest committed profiles/*_hbm_traffic.json that carries a
+    ``__step__`` entry (tools/gpu_traffic.sh over ``bench.py --only-steps``: every kernel's bytes x its launches / steps)."""
+    pdir = os.path.join(ROOT, "profiles")
+    import re
+    best = None
+    for name in sorted(os.listdir(pdir), key=lambda n: [int(x) for x in re.findall(r"\d+", n)]) if os.path.isdir(pdir) else []:
+        if name.endswith("_hbm_traffic.json"):
+            try:
+                d = json.load(open(os.path.join(pdir, name))).get("__step__")
+            except Exception:
+                continue
+            if d and d.get("model") == model:
+                best = dict(d, source="profiles/" + name)
+    return best
+
+
+def cpu_baseline_aten_chain(kind, F, sizes, budget_s=10.0, batch=32):
+    """The reference's op chain (F.interpolate, float64 cumsum, rfft / irfft at 2 hop + N - 1 points, fold) walked with
+    torch CPU operators on every core of this host (oracle/aten_chain.py, pinned to the reference's fixtures): what the
+    reference's DSP tail costs here, without the reference checkout.  One warm-up on a short batch, then whole batches
+    of ``batch`` utterances until ~budget."""
+    from oracle import aten_chain as A
+    cores = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        def run(B, seed):
+            g = torch.Generator().manual_seed(seed)
+            f0 = torch.from_numpy(synthetic_f0(B, F, seed))
+            c = [torch.randn(B, F, n, generator=g) for n in sizes]
+            nz = torch.rand(B, F * HOP, generator=g) * 2 - 1
+            fn = A.sins_tail if kind == "sins" else A.combsub_tail
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out = fn(f0, c[0], c[1], c[2], nz, SR, HOP, True)[0]
+            dt = time.perf_counter() - t0
+            assert torch.isfinite(out).all()
+            return dt
+        run(2, 1)
+        times = []
+        while sum(times) < budget_s and len(times) < 16:
+            times.append(run(batch, 100 + len(times)))
+        med = sorted(times)[len(times) // 2]
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": batch * F * HOP / med, "unit": "samples/s", "cores": cores, "kind": "aten-chain",
+            "threads": cores, "sample": "%d runs of B=%d x %d frames (%.1f s audio each) through the reference's op chain "
+            "with torch %s CPU operators, median %.2f s per run" % (len(times), batch, F, F * HOP / SR, torch.__version__, med)}
+
+
+def module_mode(kind, B, F, n, device, steps, warmup):
+    """Control mode (i) of SURVEY.md 8-d: the drop-in module end to end -- HOT-1, a Unit2Control producing the controls on
+    the GPU, torch.rand noise, HOT-2 -- with a stand-in of the reference's Unit2Control shape (tools/standins.py: the
+    reference's own module cannot travel to the GPU box)."""
+    from ddsp_svc_amd import vocoder as V
+    from tools.standins import StandInUnit2Control
+    torch.manual_seed(0)
+    if kind == "sins":
+        m = V.Sins(SR, HOP, n, n, n, n_unit=768, n_spk=1, unit2ctrl_factory=StandInUnit2Control)
+    else:
+        m = V.CombSub(SR, HOP, n, n, n, n_unit=768, n_spk=1, unit2ctrl_factory=StandInUnit2Control)
+    m = m.to(device).eval()
+    m.return_components = False
+    g = torch.Generator().manual_seed(5)
+    units = torch.randn(B, F, 768, generator=g).to(device)
+    vol = (torch.rand(B, F, 1, generator=g) * 0.1).to(device)
+    f0 = torch.from_numpy(synthetic_f0(B, F, 1234)).to(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = m(units, f0, vol)[0]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(steps):
+            out = m(units, f0, vol)[0]
+        ev[1].record()
+        ph = torch.zeros(B, F, 1, device=device)
+        ev[2].record()
+        for _ in range(steps):
+            m.unit2ctrl(units, f0, ph, vol)
+        ev[3].record()
+        torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    return {"value": B * F * HOP / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms,
+            "unit2ctrl_ms": ev[2].elapsed_time(ev[3]) / steps,
+            "note": "drop-in %s module forward (HOT-1 + stand-in Unit2Control of %.1f M parameters + torch.rand + HOT-2), "
+                    "signal only; the stand-in is not the reference's network" %
+                    (type(m).__name__, sum(p.numel() for p in m.unit2ctrl.parameters()) / 1e6)}
+
+
+def launch_ranks(n):
+    """``--gpus N`` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d needs %d devices, this host shows %d" % (n, n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def setup_ranks(a):
+    """(rank, world, device, info): reads the launcher's environment, refuses a world size that is not ``--gpus``, opens
+    the RCCL communicator and proves it with one all-reduce."""
+    import torch.distributed as dist
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(a.gpus)                              # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: refusing to report a different GPU count"
+                         % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py --gpus %d needs %d devices, this host shows %d" % (a.gpus, a.gpus, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    info = {}
+    if world > 1 or a.gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        info["rccl_ranks"] = int(probe.item())
+        if info["rccl_ranks"] != world:
+            raise SystemExit("RCCL all-reduce saw %d ranks, expected %d" % (info["rccl_ranks"], world))
+    return rank, world, device, info
+
+
+def finish_ranks():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_sinesrc(a, rank, world, device):
     """harmonic source of NSF-HiFiGAN (SURVEY.md 8-f #4): SineGen + merge for B x 10 s, 9 harmonics, noise resident"""
     import torch.distributed as dist
     from ddsp_svc_amd import nsf_source as S
-    from oracle import ddsp_oracle as O
     B = a.batch_per_gpu
     F = int(a.seconds * SR) // HOP + 1
     T = F * HOP
     g = torch.Generator(device="cpu").manual_seed(777 + rank)
-    f0 = torch.from_numpy(O.synth_f0(B, F, SR, HOP, seed=55 + rank)[..., 0]).to(device)
+    f0 = torch.from_numpy(synthetic_f0(B, F, 55 + rank)[..., 0]).to(device)
     w = (torch.randn(9, generator=g) * 0.3).to(device)
     b = torch.zeros(1, device=device)
     ri = torch.rand(9, generator=g).to(device)
@@ -421,12 +586,94 @@ def report_fast(a, rank, world, B, F, T, sizes, elapsed, gather_ms, f0, ctrls, n
     print(json.dumps(res))
 
 
+def bench_cascade_seam(a, rank, world, device):
+    """BASELINE cfg 5's seam on one MI355X (main_diff.py:356-359,378): drop-in CombSubSuperFast -> log-mel -> denoiser ->
+    NSF harmonic source + generator body, B utterances of 10 s on one stream.  The neural parts are stand-ins
+    (tools/standins.py: the reference's networks and checkpoints cannot travel to the GPU box); the DSP parts are the
+    product's kernels.  Reported: the whole chain, and the part of it the HIP kernels account for."""
+    import torch.distributed as dist
+    from tools.standins import CascadeSeam
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1
+    T = F * HOP
+    torch.manual_seed(0)
+    seam = CascadeSeam(SR, HOP).to(device).eval()
+    g = torch.Generator().manual_seed(31 + rank)
+    units = torch.randn(B, F, 768, generator=g).to(device)
+    vol = (torch.rand(B, F, 1, generator=g) * 0.1).to(device)
+    f0 = torch.from_numpy(synthetic_f0(B, F, 1234 + rank)).to(device)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    steps, warm = max(3, a.steps // 10), max(2, a.warmup // 5)
+    for _ in range(warm):
+        out = seam(units, f0, vol)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = seam(units, f0, vol)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    wav, ddsp_wav, ddsp_mel = out
+    assert wav.shape == (B, T) and ddsp_mel.shape == (B, F, 128)
+    assert torch.isfinite(wav).all() and torch.isfinite(ddsp_wav).all() and torch.isfinite(ddsp_mel).all()
+    # the DSP pieces alone (the product's share of the chain), each on resident inputs
+    from ddsp_svc_amd import synth
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    with torch.no_grad():
+        st = synth.fast_source(f0, SR, HOP)
+        ctrls, _ = seam.ddsp.unit2ctrl(units, f0, st.phase_frames, vol)
+        gauss = torch.randn(B, T, device=device)
+        ri = torch.zeros(9, device=device)
+        nz = torch.randn(B, T, 9, device=device)
+        from ddsp_svc_amd import nsf_source
+
+        def dsp():
+            s2 = synth.fast_source(f0, SR, HOP)
+            w = synth.combsubsuperfast_synth(f0, s2, ctrls["harmonic_magnitude"], ctrls["harmonic_phase"],
+                                             ctrls["noise_magnitude"], ctrls["noise_phase"], gauss, seam.ddsp.window, SR, HOP)
+            m = seam.stft.get_mel(w).transpose(1, 2)
+            e = nsf_source.sine_source(f0[..., 0], HOP, SR, seam.source.l_linear.weight, seam.source.l_linear.bias, ri, nz)
+            return m, e
+        for _ in range(3):
+            dsp()
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(10):
+            dsp()
+        ev[1].record()
+        torch.cuda.synchronize()
+    dsp_ms = ev[0].elapsed_time(ev[1]) / 10
+    if rank != 0:
+        return
+    ms = elapsed / steps * 1e3
+    print(json.dumps({
+        "metric": "audio samples/sec, cascade seam (DDSP synth -> log-mel -> denoiser -> NSF source), stand-in networks",
+        "value": B * world * T * steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "main_diff.py seam for B=%d/GPU x %.0f s (F=%d, T=%d): drop-in CombSubSuperFast(win 2048) with a "
+                               "stand-in Unit2Control, k_mel, stand-in denoiser, k_sinegen + stand-in generator body; one "
+                               "stream" % (B, a.seconds, F, T), "batch_per_gpu": B, "samples_per_utterance": T,
+                   "parallelism": "utterance-shard x%d" % world},
+        "dsp_kernels_ms": dsp_ms, "dsp_share_of_step": dsp_ms / ms,
+        "note": "integration measurement: the stand-in networks are not the reference's (their cost is not the subject); "
+                "dsp_kernels_ms is the product's part -- fast_source + stft filter + log-mel + NSF source"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc", "rssloss"])
+    ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc", "rssloss",
+                                                         "cascade_seam"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -435,34 +682,28 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed clock ramp-up before the warm-up steps (0 disables)")
     ap.add_argument("--gather", action="store_true", help="also time the optional gather of the waveforms to rank 0")
+    ap.add_argument("--only-steps", action="store_true",
+                    help="run exactly warmup + steps of the step and nothing else (no clock ramp-up, no separately timed "
+                         "kernels, no baselines): what tools/gpu_traffic.sh and the kernel-trace profiles wrap")
+    ap.add_argument("--no-module-mode", action="store_true", help="skip the control-mode (i) timing")
     a = ap.parse_args()
+    if a.only_steps:
+        a.prewarm_seconds = 0.0
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    rank, world, device, comm = setup_ranks(a)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
 
     from ddsp_svc_amd import _ffi, core, synth, sharding
 
     if a.model in ("sinesrc", "rssloss"):
         (bench_sinesrc if a.model == "sinesrc" else bench_rssloss)(a, rank, world, device)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish_ranks()
     if a.model == "mel":
         bench_mel(a, rank, world, device)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish_ranks()
+    if a.model == "cascade_seam":
+        bench_cascade_seam(a, rank, world, device)
+        return finish_ranks()
 
     B = a.batch_per_gpu
     F = int(a.seconds * SR) // HOP + 1              # the reference's frame-count rule (vocoder.py:222)
@@ -497,32 +738,40 @@ def main():
     for _ in range(a.warmup):
         out = step()
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()                                     # the same K steps on the device clock (launch stream)
     for _ in range(a.steps):
         out = step()
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    events_ms = ev0.elapsed_time(ev1) / a.steps
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed, events_ms], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, events_ms = float(tt[0].item()), float(tt[1].item())
     assert torch.isfinite(out).all()
 
     gather_ms = None
-    if a.gather and world > 1:
+    if a.gather:                                     # world 1: a 1-rank RCCL communicator, the same call path
+        for _ in range(2):
+            sharding.gather_utterances(out, B * world, dst=0)
         fence()
         t1 = time.perf_counter()
         full = sharding.gather_utterances(out, B * world, dst=0)
         fence()
         gather_ms = (time.perf_counter() - t1) * 1e3
         del full
+    if a.only_steps:
+        if rank == 0:
+            print(json.dumps({"only_steps": True, "model": a.model, "steps": a.steps, "warmup": a.warmup, "n_gpus": world,
+                              "ms_per_step": elapsed / a.steps * 1e3, "ms_per_step_events": events_ms}))
+        return finish_ranks()
 
     if a.model in FAST_MODELS:
         report_fast(a, rank, world, B, F, T, sizes, elapsed, gather_ms, f0, ctrls, noise, window, win)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish_ranks()
 
     # ---- dominant kernel alone: the time-varying FIR (N = 2(n-1) taps), events on the launch stream.  Two forms ship:
     # the FFT-domain block convolution (k_fir_fft, what the step uses for hop 512 / N <= 512) and the direct form on
@@ -578,7 +827,7 @@ def main():
             "metric": "audio samples/sec, CombSub 44.1kHz 256-harm hop512" if a.model == "combsub"
                       else "audio samples/sec, Sins 44.1kHz 256-harm hop512",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_s": a.prewarm_seconds,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "ms_per_step_events": events_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s B=%d/GPU x %.0f s utterances (F=%d, T=%d), n_mag %d/%d/%d, sr 44100, hop 512, "
                                    "DSP path (HOT-1 + HOT-2) from resident f0 / raw controls ~N(0,1) / uniform noise, "
@@ -612,15 +861,23 @@ def main():
                                   "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},
         }
+        res.update(comm)
+        tr = step_traffic(a.model) if (B, F, n) == (32, 862, 256) else None
+        res["roofline_step_traffic"] = None if tr is None else {
+            "pmc_bytes_per_step": tr["hbm_bytes"], "algorithmic_bytes_per_step": alg_bytes,
+            "ratio": tr["hbm_bytes"] / alg_bytes, "launches_per_step": tr.get("launches_per_step"), "source": tr["source"]}
         if gather_ms is not None:
             res["gather_ms"] = gather_ms
+            res["gather_bytes_per_rank"] = 4.0 * B * T
+        if world == 1 and not a.no_module_mode:
+            res["value_module_mode"] = module_mode(a.model, B, F, n, device, max(5, a.steps // 5), 3)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, F, sizes)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            res["cpu_baseline_aten_chain"] = cpu_baseline_aten_chain(a.model, F, sizes)
+            res["cpu_baseline_aten_chain"]["gpu_over_cpu"] = value / res["cpu_baseline_aten_chain"]["value"]
         print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish_ranks()
 
 
 if __name__ == "__main__":

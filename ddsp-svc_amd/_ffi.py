@@ -19,6 +19,9 @@ P = ctypes.c_void_p
 SIGNATURES = {
     "ddsp_hip_version": (c_int, []),
     "ddsp_hip_error_string": (ctypes.c_char_p, [c_int]),
+    "ddsp_hip_set_tuning": (c_int, [ctypes.c_char_p, c_long]),
+    "ddsp_hip_get_tuning": (c_long, [ctypes.c_char_p]),
+    "ddsp_hip_window_impulse_response": (c_int, [P, c_int, P, c_long, c_int, P, P]),
     "ddsp_hip_upsample": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "ddsp_hip_remove_above_fmax": (c_int, [P, P, c_long, c_int, c_float, c_int, P, P]),
     "ddsp_hip_phase": (c_int, [P, P, c_int, c_int, c_int, c_double, c_int, P, P, P, P, P]),
@@ -109,18 +112,29 @@ def stream_of(t):
 
 
 _AUX = {}
+_ONE_STREAM = bool(os.environ.get("DDSP_HIP_ONE_STREAM"))      # read once, at import: never hand the tails a second stream
+
+
+def set_tuning(name, value):
+    """Measurement / test hook: ``ddsp_hip_set_tuning`` (include/ddsp_hip.h); ``value = 0`` restores the default."""
+    check(lib().ddsp_hip_set_tuning(name.encode(), int(value)))
 
 
 def aux_torch_stream(t, rows):
-    """The cached second ``torch.cuda.Stream`` of ``t``'s device, or None (small launches, CPU tensors under the
-    emulator, ``DDSP_HIP_ONE_STREAM=1``, or a device other than the current one)."""
-    if not t.is_cuda or rows < 4096 or os.environ.get("DDSP_HIP_ONE_STREAM"):
+    """The cached second ``torch.cuda.Stream`` that belongs to the caller's current stream on ``t``'s device (one per
+    (device, main stream): callers on different streams -- other host threads -- do not share a branch stream), or None
+    (small launches, CPU tensors under the emulator, ``DDSP_HIP_ONE_STREAM=1``, or a device other than the current one)."""
+    if not t.is_cuda or rows < 4096 or _ONE_STREAM:
         return None
     if torch.cuda.current_device() != t.device.index:      # the library's fork / join events belong to the current device
         return None
-    s = _AUX.get(t.device)
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    s = _AUX.get(key)
     if s is None:
-        s = _AUX[t.device] = torch.cuda.Stream(device=t.device)
+        with _LOCK:
+            s = _AUX.get(key)
+            if s is None:
+                s = _AUX[key] = torch.cuda.Stream(device=t.device)
     return s
 
 

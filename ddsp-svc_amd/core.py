@@ -40,28 +40,78 @@ def get_fft_size(frame_size, ir_size, power_of_2=True):
     return int(2 ** math.ceil(math.log2(convolved))) if power_of_2 else convolved
 
 
-def upsample(signal, factor):
-    """core.py:66-70: ``[B,F,C] -> [B,F*factor,C]`` linear interpolation, last frame held."""
-    _ffi.check_device(signal)
-    sig = _f32c(signal)
+def _upsample_forward(sig, factor):
     B, F, C = sig.shape
-    factor = int(factor)
     out = torch.empty(B, F * factor, C, dtype=torch.float32, device=sig.device)
     _ffi.check(_ffi.lib().ddsp_hip_upsample(ptr(sig), B, F, C, factor, ptr(out), _ffi.stream_of(sig)))
     return out
 
 
-def remove_above_fmax(amplitudes, pitch, fmax, level_start=1):
-    """core.py:73-77: ``amplitudes * ((pitch*k < fmax) + 1e-7)``."""
-    _ffi.check_device(amplitudes, pitch)
-    a = _f32c(amplitudes)
+class UpsampleFunction(torch.autograd.Function):
+    """``upsample`` under autograd (the reference's ``F.interpolate`` is differentiable: amplitudes train through it).
+    The adjoint of the interpolation -- frame f collects ``(1 - j/hop)`` of its own block and ``j/hop`` of the previous
+    one, the held last frame both halves of the last block -- is two small reductions, left to torch."""
+
+    @staticmethod
+    def forward(ctx, signal, factor):
+        ctx.factor = factor
+        return _upsample_forward(_f32c(signal.detach()), factor)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        hop = ctx.factor
+        B, T, C = grad_out.shape
+        g = grad_out.reshape(B, T // hop, hop, C)
+        lam = (torch.arange(hop, device=g.device, dtype=g.dtype) / hop).view(1, 1, hop, 1)
+        own, nxt = (g * (1 - lam)).sum(2), (g * lam).sum(2)
+        d = own.clone()
+        d[:, 1:] += nxt[:, :-1]
+        d[:, -1] += nxt[:, -1]                                     # core.py:68: the last frame is repeated
+        return d, None
+
+
+def upsample(signal, factor):
+    """core.py:66-70: ``[B,F,C] -> [B,F*factor,C]`` linear interpolation, last frame held.  Differentiable."""
+    _ffi.check_device(signal)
+    factor = int(factor)
+    if torch.is_grad_enabled() and signal.requires_grad:
+        return UpsampleFunction.apply(signal, factor)
+    return _upsample_forward(_f32c(signal), factor)
+
+
+def _remove_above_fmax_forward(a, p, fmax, level_start):
     H = a.shape[-1]
-    rows = a.numel() // H
-    p = _f32c(pitch.expand(*a.shape[:-1], 1))
     out = torch.empty_like(a)
-    _ffi.check(_ffi.lib().ddsp_hip_remove_above_fmax(ptr(a), ptr(p), rows, H, float(fmax), int(level_start),
+    _ffi.check(_ffi.lib().ddsp_hip_remove_above_fmax(ptr(a), ptr(p), a.numel() // H, H, float(fmax), int(level_start),
                                                      ptr(out), _ffi.stream_of(a)))
     return out
+
+
+class RemoveAboveFmaxFunction(torch.autograd.Function):
+    """``remove_above_fmax`` under autograd: linear in the amplitudes (the mask, piecewise constant in the pitch, carries
+    no gradient -- as in the reference, where it goes through ``.float()`` of a comparison)."""
+
+    @staticmethod
+    def forward(ctx, amplitudes, pitch, fmax, level_start):
+        a = _f32c(amplitudes.detach())
+        p = _f32c(pitch.detach().expand(*a.shape[:-1], 1))
+        ctx.save_for_backward(p)
+        ctx.cfg = (float(fmax), int(level_start))
+        return _remove_above_fmax_forward(a, p, fmax, level_start)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (p,) = ctx.saved_tensors
+        return _remove_above_fmax_forward(_f32c(grad_out), p, *ctx.cfg), None, None, None
+
+
+def remove_above_fmax(amplitudes, pitch, fmax, level_start=1):
+    """core.py:73-77: ``amplitudes * ((pitch*k < fmax) + 1e-7)``.  Differentiable w.r.t. the amplitudes."""
+    _ffi.check_device(amplitudes, pitch)
+    if torch.is_grad_enabled() and amplitudes.requires_grad:
+        return RemoveAboveFmaxFunction.apply(amplitudes, pitch, fmax, level_start)
+    a = _f32c(amplitudes)
+    return _remove_above_fmax_forward(a, _f32c(pitch.expand(*a.shape[:-1], 1)), fmax, level_start)
 
 
 def crop_and_compensate_delay(audio, audio_size, ir_size, padding="same", delay_compensation=-1):
@@ -79,6 +129,45 @@ def crop_and_compensate_delay(audio, audio_size, ir_size, padding="same", delay_
     return audio[:, start:-end]
 
 
+def _window_taps(ir, mode, hw):
+    """zero-phase taps [..., N] -> windowed causal taps (one elementwise kernel)"""
+    x = _f32c(ir)
+    N = x.shape[-1]
+    rows = x.numel() // N
+    out = torch.empty_like(x)
+    _ffi.check(_ffi.lib().ddsp_hip_window_impulse_response(ptr(x), int(mode), ptr(hw), rows, N, ptr(out), _ffi.stream_of(x)))
+    return out
+
+
+def _windowed(impulse_response, mode, hw):
+    _ffi.check_device(impulse_response, hw)
+    if torch.is_grad_enabled() and impulse_response.requires_grad:
+        # differentiable composition: the kernel, applied to ones, IS the window in causal order
+        w = _window_taps(torch.ones_like(impulse_response, dtype=torch.float32), mode, hw)
+        return impulse_response.roll(impulse_response.size(-1) // 2, -1) * w
+    return _window_taps(impulse_response, mode, hw)
+
+
+def apply_window_to_impulse_response(impulse_response, window_size: int = 0, causal: bool = False):
+    """core.py:185-237: periodic Hann window on zero-phase taps ``[B,F,N]``, result in causal form.  Every caller of the
+    reference uses the defaults (window = the full tap length).  ``causal=True`` fails in the reference itself (it calls
+    the non-existent ``torch.fftshift``, core.py:203-204) and a shorter ``window_size`` is a branch no caller reaches;
+    both are refused here rather than guessed."""
+    if causal:
+        raise AttributeError("module 'torch' has no attribute 'fftshift'")          # what the reference raises, core.py:204
+    N = int(impulse_response.size(-1))
+    if 0 < window_size < N:
+        raise NotImplementedError("apply_window_to_impulse_response: window_size < ir_size is not on the synthesis path")
+    return _windowed(impulse_response, _ffi.MODE_HANN, None)
+
+
+def apply_dynamic_window_to_impulse_response(impulse_response, half_width_frames):
+    """core.py:240-251: f0-dependent raised-cosine window (``half_width_frames [B,F,1]``; only ``w > 1`` is clamped,
+    core.py:245) on zero-phase taps ``[B,F,N]``, result in causal form."""
+    hw = _f32c(half_width_frames.detach().expand(*impulse_response.shape[:-1], 1))
+    return _windowed(impulse_response, _ffi.MODE_DYNAMIC, hw)
+
+
 def _impulse_response_forward(re, im, mode, hw):
     B, F, n = re.shape
     taps = torch.empty(B, F, 2 * (n - 1), dtype=torch.float32, device=re.device)
@@ -90,8 +179,9 @@ def _impulse_response_forward(re, im, mode, hw):
 
 class FrequencyImpulseResponseFunction(torch.autograd.Function):
     """core.py:254-270 with the gradient back to the one-sided response: the adjoint of irfft + roll + window
-    (``ddsp_hip_impulse_response_backward``).  A complex response is differentiable without a window
-    (``hann_window=False``, the all-pass case); the window itself (half widths) is a constant."""
+    (``ddsp_hip_impulse_response_backward``), for real and complex responses in every window mode (the reference
+    builds its magnitude responses as ``torch.complex(param, 0)``, vocoder.py:606,849,857); the window itself (half
+    widths) is a constant."""
 
     @staticmethod
     def forward(ctx, magnitudes, mode, hw):
@@ -107,8 +197,6 @@ class FrequencyImpulseResponseFunction(torch.autograd.Function):
     def backward(ctx, d_taps):
         (hw,) = ctx.saved_tensors
         mode, is_complex, (B, F, n) = ctx.cfg
-        if is_complex and mode != _ffi.MODE_ROLL:
-            raise NotImplementedError("gradient of a windowed impulse response w.r.t. a complex response")
         g = _f32c(d_taps)
         d_re = torch.empty(B, F, n, dtype=torch.float32, device=g.device)
         d_im = torch.empty_like(d_re) if is_complex else None

@@ -2,8 +2,52 @@
 // the launch sequences of the two synthesiser tails.  No allocation, no synchronisation.
 #include "../../include/ddsp_hip.h"
 #include "kernels.h"
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
 
 using namespace ddsp;
+
+// ---- tuning knobs (csrc/tuning.h): environment read once, afterwards only ddsp_hip_set_tuning() ----------------------
+namespace ddsp {
+namespace {
+const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
+                                            "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "FUSED_TAPS"};
+std::atomic<long> g_knobs[KNOB_COUNT];
+std::once_flag g_knobs_once;
+void knobs_from_env() {
+  for (int i = 0; i < KNOB_COUNT; ++i) {
+    char name[64] = "DDSP_HIP_";
+    strncat(name, kKnobNames[i], sizeof(name) - strlen(name) - 1);
+    const char* e = getenv(name);
+    g_knobs[i].store(e ? atol(e) : 0, std::memory_order_relaxed);
+  }
+}
+int knob_index(const char* name) {
+  if (!name) return -1;
+  if (strncmp(name, "DDSP_HIP_", 9) == 0) name += 9;
+  for (int i = 0; i < KNOB_COUNT; ++i)
+    if (strcmp(name, kKnobNames[i]) == 0) return i;
+  return -1;
+}
+}  // namespace
+long knob(Knob k) {
+  std::call_once(g_knobs_once, knobs_from_env);
+  return g_knobs[k].load(std::memory_order_relaxed);
+}
+int knob_set(const char* name, long v) {
+  std::call_once(g_knobs_once, knobs_from_env);
+  const int i = knob_index(name);
+  if (i < 0) return -1;
+  g_knobs[i].store(v, std::memory_order_relaxed);
+  return 0;
+}
+long knob_get(const char* name) {
+  const int i = knob_index(name);
+  return i < 0 ? -1 : knob((Knob)i);
+}
+}  // namespace ddsp
 
 namespace {
 
@@ -116,6 +160,10 @@ const char* ddsp_hip_error_string(int code) {
   }
 }
 
+int ddsp_hip_set_tuning(const char* name, long value) { return knob_set(name, value) == 0 ? 0 : DDSP_HIP_EINVAL; }
+
+long ddsp_hip_get_tuning(const char* name) { return knob_get(name); }
+
 int ddsp_hip_upsample(const float* sig, int B, int F, int C, int hop, float* out, void* stream) {
   if (B < 0 || F <= 0 || C <= 0 || hop <= 0) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
@@ -180,9 +228,19 @@ int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, l
   if (!d_taps || !table || !d_re) return DDSP_HIP_EINVAL;
   if (act == DDSP_HIP_ACT_EXP && (!ctrl || ld_ctrl < n_mag)) return DDSP_HIP_EINVAL;
   if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
-  if (d_im && (act != DDSP_HIP_ACT_NONE || mode != DDSP_HIP_MODE_ROLL)) return DDSP_HIP_ESHAPE;
+  if (d_im && act != DDSP_HIP_ACT_NONE) return DDSP_HIP_ESHAPE;
   launch_ir_gemm_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
                      S(stream));
+  return finish();
+}
+
+int ddsp_hip_window_impulse_response(const float* ir, int mode, const float* half_width, long rows, int N, float* out,
+                                     void* stream) {
+  if (rows < 0 || N < 1 || mode < 0 || mode > 2) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!ir || !out || ir == out) return DDSP_HIP_EINVAL;
+  if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
+  launch_window_taps(ir, mode, half_width, rows, N, out, S(stream));
   return finish();
 }
 

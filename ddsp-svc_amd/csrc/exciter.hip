@@ -7,6 +7,7 @@
 // amplitude rows it interpolates between in LDS and never materialises the reference's
 // [B,T,32] temporaries.
 #include "ddsp_common.h"
+#include "tuning.h"
 #include <stdlib.h>
 
 namespace ddsp {
@@ -447,7 +448,7 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
   if ((long)B * F == 0) return 0;
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
-  if (hop == 512 && (long)B * F <= 0x7fffffffL && !getenv("DDSP_HIP_SINS_V1")) {
+  if (hop == 512 && (long)B * F <= 0x7fffffffL && !knob(KNOB_SINS_V1)) {
     // block angle-addition form: one workgroup per frame
     const size_t sh2 = (size_t)2 * ((H + 15) & ~15) * sizeof(float);
     hipLaunchKernelGGL(k_sins_bank2, dim3((unsigned)((long)B * F)), dim3(256), sh2, st, f0_frames, initial_phase, c_amp,

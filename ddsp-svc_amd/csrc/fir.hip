@@ -428,8 +428,7 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
     if (occ > wave_occ) occ = wave_occ;
     if (occ < 1) occ = 1;
     long slots = 32 * occ;
-    if (const char* cap = getenv("DDSP_HIP_FIR_MAX_SLOTS")) {      // tuning / test knob: workgroups per XCD
-      long v = atol(cap);
+    if (const long v = knob(KNOB_FIR_MAX_SLOTS)) {         // tuning / test knob: workgroups per XCD
       if (v >= 1 && v < slots) slots = v;
     }
     const long per_xcd = (g.NTILES + 7) / 8;

@@ -256,7 +256,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 1) / 2;
   int wps = 2;
-  if (const char* e = getenv("DDSP_HIP_BLK_WPS")) { int v = atoi(e); if (v >= 1) wps = v; }
+  if (const long v = knob(KNOB_BLK_WPS)) { if (v >= 1) wps = (int)v; }
   // run length: as many workgroups as the chip holds at once (2 waves each), one round, equal work; every run
   // pays one warm-up pair and one extra half transform
   const long slots = (long)wps * 2 * 256;
@@ -264,14 +264,14 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 3) run = 3;
-  if (const char* e = getenv("DDSP_HIP_BLK_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (const long v = knob(KNOB_BLK_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
-  if (const char* e = getenv("DDSP_HIP_BLK_PADLDS")) pad = (size_t)atol(e);
+  if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
   if (pad > 0) {
     hipLaunchKernelGGL(k_fir_blk<2>, dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g);
     return 5;

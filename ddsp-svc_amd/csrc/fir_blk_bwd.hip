@@ -256,7 +256,7 @@ int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const fl
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 3) run = 3;
-  if (const char* e = getenv("DDSP_HIP_BLK_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (const long v = knob(KNOB_BLK_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;

@@ -341,6 +341,36 @@ __global__ void __launch_bounds__(256, 2) k_ir_gemm(const float* __restrict__ a_
 }
 
 // ------------------------------------------------------------------------------------------------
+// apply_window_to_impulse_response / apply_dynamic_window_to_impulse_response (core.py:185-251) on taps that are
+// already in the time domain: zero-phase form in, windowed causal form out,
+//     out[r][j] = in[r][(j - N/2) mod N] * w_r(j),
+// w = periodic Hann of N (MODE_HANN), the f0-dependent raised cosine with its one-sided clamp (MODE_DYNAMIC,
+// core.py:244-246; N may be odd there: positions run from -(N/2) to (N+1)/2 - 1), or 1 (MODE_ROLL).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_window_taps(const float* __restrict__ in, int mode,
+                                                     const float* __restrict__ half_width, long rows, int N,
+                                                     float* __restrict__ out) {
+  const long total = rows * (long)N;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int half = N / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / N;
+    const int j = (int)(i - r * N);
+    int src = j - half;
+    if (src < 0) src += N;
+    float w = 1.0f;
+    if (mode == IR_MODE_HANN) {
+      w = (float)(0.5 - 0.5 * cospi(2.0 * (double)j / (double)N));
+    } else if (mode == IR_MODE_DYNAMIC) {
+      float u = (float)(j - half) / half_width[r];
+      if (u > 1.0f) u = 0.0f;
+      w = (1.0f + cos_turns(kPiF * u)) / 2.0f;
+    }
+    out[i] = in[r * N + src] * w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adjoint of the tap synthesis: d_taps [rows, N] -> gradient of the one-sided response (or of the raw control
 // through the exp activation).  With dE[m] = w+ dt[N/2 + m] + w- dt[N/2 - m] and dO[m] = w+ dt[N/2 + m] - w- dt[N/2 - m]
 // (window factors of the two taps a bin pair feeds; m = 0 and m = N/2 have one tap only)
@@ -584,6 +614,13 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
 #undef DDSP_IR_LAUNCH
 }
 
+void launch_window_taps(const float* in, int mode, const float* half_width, long rows, int N, float* out, hipStream_t st) {
+  if (rows == 0) return;
+  long blocks = (rows * (long)N + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_window_taps, dim3((unsigned)blocks), dim3(256), 0, st, in, mode, half_width, rows, N, out);
+}
+
 void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                         int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                         hipStream_t st) {
@@ -592,8 +629,10 @@ void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, in
 #define DDSP_IRB_LAUNCH(ACT_, IM_, MODE_)                                                                        \
   hipLaunchKernelGGL((k_ir_gemm_bwd<ACT_, IM_, MODE_>), grid, block, 0, st, d_taps, ctrl, ld_ctrl, scale, table, \
                      half_width, rows, n, d_re, d_im)
-  if (has_im) {
-    DDSP_IRB_LAUNCH(IR_ACT_NONE, true, IR_MODE_ROLL);           // the all-pass response is the only complex one
+  if (has_im) {                                                 // complex response (all-pass: no window; torch.complex(mag, 0): windowed)
+    if (mode == IR_MODE_HANN) DDSP_IRB_LAUNCH(IR_ACT_NONE, true, IR_MODE_HANN);
+    else if (mode == IR_MODE_DYNAMIC) DDSP_IRB_LAUNCH(IR_ACT_NONE, true, IR_MODE_DYNAMIC);
+    else DDSP_IRB_LAUNCH(IR_ACT_NONE, true, IR_MODE_ROLL);
   } else if (act == IR_ACT_EXP) {
     if (mode == IR_MODE_HANN) DDSP_IRB_LAUNCH(IR_ACT_EXP, false, IR_MODE_HANN);
     else if (mode == IR_MODE_DYNAMIC) DDSP_IRB_LAUNCH(IR_ACT_EXP, false, IR_MODE_DYNAMIC);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "tuning.h"
 
 namespace ddsp {
 int spl_for_hop(int hop);
@@ -27,6 +28,7 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
 void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                         int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                         hipStream_t st);
+void launch_window_taps(const float* in, int mode, const float* half_width, long rows, int N, float* out, hipStream_t st);
 void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
                              hipStream_t st);
 size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves);

@@ -161,13 +161,13 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
   g.sb = sb; g.sm = sm; g.sf = sf;
   // pairs are independent; a run only amortises the twiddle set-up.  One round of workgroups on the chip.
   int wps = 3;
-  if (const char* e = getenv("DDSP_HIP_MEL_WPS")) { int v = atoi(e); if (v >= 1) wps = v; }
+  if (const long v = knob(KNOB_MEL_WPS)) { if (v >= 1) wps = (int)v; }
   const long slots = (long)wps * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 4) run = 4;
-  if (const char* e = getenv("DDSP_HIP_MEL_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (const long v = knob(KNOB_MEL_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;

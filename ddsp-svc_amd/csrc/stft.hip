@@ -587,7 +587,7 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
   // across the transform, so 2 waves per SIMD for both sizes (win 2048: 0.30 ms against 0.39 ms at 168 VGPRs with
   // 16 spills, 0.61 ms at 128; profiles/r01_v5_stft_variants.json)
   int wps = 2;
-  if (const char* e = getenv("DDSP_HIP_STFT_WPS")) { int v = atoi(e); if (v >= 1) wps = v; }
+  if (const long v = knob(KNOB_STFT_WPS)) { if (v >= 1) wps = (int)v; }
   const int wg_per_cu = wps * 4 / (win == 2048 ? 4 : 2);
   const int warm = win == 2048 ? 2 : 1;
   // run length: as many workgroups as the chip holds at once, so all of them run in one round with equal work (a
@@ -597,7 +597,7 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 3 * warm) run = 3 * warm;
-  if (const char* e = getenv("DDSP_HIP_STFT_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (const long v = knob(KNOB_STFT_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
@@ -635,7 +635,7 @@ int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u0
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 2) run = 2;
-  if (const char* e = getenv("DDSP_HIP_STFT_RUN")) { int v = atoi(e); if (v >= 1) run = v; }
+  if (const long v = knob(KNOB_STFT_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;

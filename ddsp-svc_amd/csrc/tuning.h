@@ -1,0 +1,18 @@
+// Tuning / test knobs of the launchers (run lengths, which occupancy build of a kernel is launched, ...).  Defaults are
+// the measured optima; a knob is read from its DDSP_HIP_<NAME> environment variable ONCE, when the library first needs
+// it, and can be changed afterwards only through ddsp_hip_set_tuning() (include/ddsp_hip.h) -- measurement tools and the
+// run-split tests use that; the launch path itself never touches the environment.
+#pragma once
+
+namespace ddsp {
+
+enum Knob {
+  KNOB_BLK_WPS = 0, KNOB_BLK_RUN, KNOB_BLK_PADLDS, KNOB_FFT_RUN, KNOB_STFT_WPS, KNOB_STFT_RUN, KNOB_MEL_WPS,
+  KNOB_MEL_RUN, KNOB_FIR_MAX_SLOTS, KNOB_SINS_V1, KNOB_FUSED_TAPS, KNOB_COUNT
+};
+
+long knob(Knob k);                       // current value; 0 = unset (use the built-in default)
+int knob_set(const char* name, long v);  // 0 on success, -1 for an unknown name
+long knob_get(const char* name);         // value, or -1 for an unknown name
+
+}  // namespace ddsp

@@ -47,12 +47,32 @@ class SourceModuleHnNSF(torch.nn.Module):
         self.l_linear = torch.nn.Linear(harmonic_num + 1, 1)
         self.l_tanh = torch.nn.Tanh()
 
-    @torch.no_grad()
     def forward(self, x, upp):
+        # In the reference only SineGen runs under no_grad (models.py:141); Linear + tanh are differentiable, so a
+        # generator that is being trained updates l_linear.  The fused kernel has no adjoint, so in that case the
+        # pre-linear waves are recovered harmonic by harmonic (one-hot weight, zero bias: out = tanh(s_k), |s_k| < 0.2, so
+        # atanh is exact to rounding) and Linear + tanh run in torch -- never a silently frozen layer.
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.l_linear.parameters()):
+            with torch.no_grad():
+                rand_ini, noise = self._draws(x, upp)
+                eye = torch.eye(self.dim, device=x.device)
+                zero = torch.zeros(1, device=x.device)
+                waves = torch.stack([torch.atanh(sine_source(x, upp, self.sampling_rate, eye[k], zero, rand_ini, noise,
+                                                             self.sine_amp, self.noise_std, self.voiced_threshold))
+                                     for k in range(self.dim)], -1)
+            return self.l_tanh(self.l_linear(waves))
+        with torch.no_grad():
+            return self._forward(x, upp)
+
+    def _draws(self, x, upp):
         B, L = x.shape
         rand_ini = torch.rand(1, 1, self.dim, device=x.device)                         # models.py:150
         rand_ini[..., 0] = 0                                                            # models.py:151
         noise = torch.randn(B, L * int(upp), self.dim, dtype=torch.float32, device=x.device)   # randn_like, :168
+        return rand_ini, noise
+
+    def _forward(self, x, upp):
+        rand_ini, noise = self._draws(x, upp)
         out = sine_source(x, upp, self.sampling_rate, self.l_linear.weight, self.l_linear.bias, rand_ini, noise,
                           self.sine_amp, self.noise_std, self.voiced_threshold)
         return out.unsqueeze(-1)
@@ -69,8 +89,9 @@ def patch_reference_source():
 
     def forward(self, x, upp):
         gen = self.l_sin_gen
-        if not getattr(x, "is_cuda", False) or gen.dim not in (1, 9) or x.dim() != 2:
-            return ref_forward(self, x, upp)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.l_linear.parameters())
+        if not getattr(x, "is_cuda", False) or gen.dim not in (1, 9) or x.dim() != 2 or training:
+            return ref_forward(self, x, upp)            # incl. training of l_linear: the reference's differentiable code
         with torch.no_grad():
             B, L = x.shape
             rand_ini = torch.rand(1, 1, gen.dim, device=x.device)

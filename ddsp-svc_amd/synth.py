@@ -87,17 +87,14 @@ def sinusoid_bank(f0_frames, state: PhaseState, amplitudes_ctrl, sampling_rate, 
     return out
 
 
-_WS = {}
-
-
 def _workspace(B, F, hop, n_max, device):
+    """Scratch of one call, taken from torch's caching allocator on the caller's current stream: the allocator's
+    stream-ordered reuse rules then cover concurrent callers (two host threads, two torch streams on one device -- the
+    GUI calls the model from its audio callback thread, gui.py:393) without any state in this module.  The part the
+    noise branch touches on the second stream needs no ``record_stream``: the call joins that stream back into the
+    caller's before its last kernel, so everything is ordered before whatever the caller's stream does next."""
     need = _ffi.lib().ddsp_hip_synth_workspace_bytes(B, F, hop, n_max)
-    key = str(device)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws, need
+    return torch.empty(need, dtype=torch.uint8, device=device), need
 
 
 def _outputs(B, T, device, want_components):
@@ -331,12 +328,7 @@ def fast_source(f0_frames, sampling_rate, block_size, want_combtooth=False) -> F
 
 def _stft_ws(B, F, hop, device):
     need = _ffi.lib().ddsp_hip_stft_workspace_bytes(B, F, hop)
-    key = "stft:" + str(device)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws, need
+    return torch.empty(need, dtype=torch.uint8, device=device), need
 
 
 def stft_filter(exciter, noise, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase, window,

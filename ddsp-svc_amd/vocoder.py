@@ -23,6 +23,14 @@ def _reference_unit2control():
 
 
 class _SynthBase(torch.nn.Module):
+    # patch_reference() stores the reference's class of the same name here: tensors that are not on the GPU are handed to
+    # ITS forward (the reference's own CPU code, e.g. load_model's default device='cpu', vocoder.py:506) -- this package
+    # has no CPU arithmetic of its own.  Without a patched-in reference a host tensor is an error (check_device).
+    _reference_cls = None
+
+    def _to_reference(self, f0_frames):
+        return self._reference_cls is not None and not f0_frames.is_cuda
+
     def __init__(self, sampling_rate, block_size, split_map, n_unit, n_spk, unit2ctrl_factory=None,
                  **unit2ctrl_kwargs):
         super().__init__()
@@ -53,6 +61,10 @@ class Sins(_SynthBase):
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, initial_phase=None,
                 infer=True, max_upsample_dim=32):
+        if self._to_reference(f0_frames):
+            return self._reference_cls.forward(self, units_frames, f0_frames, volume_frames, spk_id=spk_id,
+                                               spk_mix_dict=spk_mix_dict, initial_phase=initial_phase, infer=infer,
+                                               max_upsample_dim=max_upsample_dim)
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :564-575
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :578
@@ -76,6 +88,9 @@ class CombSub(_SynthBase):
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, initial_phase=None,
                 infer=True, **kwargs):
+        if self._to_reference(f0_frames):
+            return self._reference_cls.forward(self, units_frames, f0_frames, volume_frames, spk_id=spk_id,
+                                               spk_mix_dict=spk_mix_dict, initial_phase=initial_phase, infer=infer, **kwargs)
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :819-829
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :832
@@ -102,6 +117,10 @@ class CombSubFast(_SynthBase):
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, aug_shift=None,
                 initial_phase=None, infer=True, **kwargs):
+        if self._to_reference(f0_frames):
+            return self._reference_cls.forward(self, units_frames, f0_frames, volume_frames, spk_id=spk_id,
+                                               spk_mix_dict=spk_mix_dict, aug_shift=aug_shift,
+                                               initial_phase=initial_phase, infer=infer, **kwargs)
         st = synth.phase(f0_frames, self._sr, self._hop, initial_phase, infer)                 # :743-753
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :756
@@ -129,11 +148,17 @@ class CombSubSuperFast(_SynthBase):
 
     def fast_source_gen(self, f0_frames):
         """vocoder.py:639-651 -> ``(combtooth [B,T], phase_frames [B,F,1])``."""
+        if self._to_reference(f0_frames):
+            return self._reference_cls.fast_source_gen(self, f0_frames)
         st = synth.fast_source(f0_frames, self._sr, self._hop, want_combtooth=True)
         return st.combtooth, st.phase_frames
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id=None, spk_mix_dict=None, aug_shift=None,
                 initial_phase=None, infer=True, **kwargs):
+        if self._to_reference(f0_frames):
+            return self._reference_cls.forward(self, units_frames, f0_frames, volume_frames, spk_id=spk_id,
+                                               spk_mix_dict=spk_mix_dict, aug_shift=aug_shift,
+                                               initial_phase=initial_phase, infer=infer, **kwargs)
         st = synth.fast_source(f0_frames, self._sr, self._hop)                                  # :653
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict, aug_shift=aug_shift)   # :656
@@ -145,12 +170,27 @@ class CombSubSuperFast(_SynthBase):
         return signal, hidden, (signal, signal)                                                 # :710
 
 
+PATCHED_CORE_FUNCTIONS = ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response",
+                          "apply_window_to_impulse_response", "apply_dynamic_window_to_impulse_response")
+
+
+def _tensors(args, kwargs):
+    for v in list(args) + list(kwargs.values()):
+        if torch.is_tensor(v):
+            yield v
+
+
 def patch_reference():
     """Swap these classes (and the ddsp.core functions on the path) into an already-importable
     reference checkout so ``ddsp.vocoder.load_model``, ``main.py``, ``main_diff.py`` ... pick them up
     without edits.  The cascades bind ``CombSubFast`` / ``CombSubSuperFast`` by name when they are imported
     (diffusion/vocoder.py:13, reflow/vocoder.py:12), so either call this first or rely on the rebinding of
-    the already-imported modules done here."""
+    the already-imported modules done here.
+
+    Dispatch rule of the patched ``ddsp.core`` functions: GPU tensors go to the HIP kernels (all of them are
+    differentiable where the reference's are -- ``upsample`` / ``remove_above_fmax`` through small autograd functions,
+    the filters through the adjoint kernels); anything else -- host tensors, dtypes other than float32 / complex64 --
+    keeps the reference's own code.  The module classes route host tensors to the reference's ``forward``."""
     import sys
 
     import ddsp.core as rcore
@@ -160,6 +200,7 @@ def patch_reference():
     for name, cls in mine.items():
         if not hasattr(rvoc, "_reference_" + name):
             setattr(rvoc, "_reference_" + name, getattr(rvoc, name))
+        cls._reference_cls = getattr(rvoc, "_reference_" + name)
         setattr(rvoc, name, cls)
     for modname in ("diffusion.vocoder", "reflow.vocoder", "train"):
         mod = sys.modules.get(modname)
@@ -167,16 +208,51 @@ def patch_reference():
             for name, cls in mine.items():
                 if hasattr(mod, name):
                     setattr(mod, name, cls)
-    for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve",
-                 "frequency_impulse_response"):
-        if hasattr(rcore, "_reference_" + name):
+    for name in PATCHED_CORE_FUNCTIONS:
+        if hasattr(rcore, "_reference_" + name) or not hasattr(rcore, name):
             continue                                     # already patched
         setattr(rcore, "_reference_" + name, getattr(rcore, name))
 
         def dispatch(*a, __h=getattr(hcore, name), __r=getattr(rcore, name), **k):
-            first = a[0] if a else next(iter(k.values()))
-            return __h(*a, **k) if getattr(first, "is_cuda", False) else __r(*a, **k)
+            ts = list(_tensors(a, k))
+            on_gpu = bool(ts) and all(t.is_cuda for t in ts)
+            plain = all(t.dtype in (torch.float32, torch.complex64) for t in ts)
+            return __h(*a, **k) if on_gpu and plain else __r(*a, **k)
+        dispatch.__name__ = name
         setattr(rcore, name, dispatch)
-    rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = (rcore.upsample, rcore.remove_above_fmax,
-                                                                     rcore.frequency_filter)
+    for name in PATCHED_CORE_FUNCTIONS:                  # names the importing modules bound at import time (vocoder.py:16, ...)
+        for modname in ("ddsp.vocoder", "ddsp.loss", "main", "main_diff", "batch_infer", "gui"):
+            mod = sys.modules.get(modname)
+            if mod is not None and hasattr(mod, name) and hasattr(rcore, name):
+                setattr(mod, name, getattr(rcore, name))
     return rvoc
+
+
+def unpatch_reference():
+    """Undo ``patch_reference()``: the reference's own classes and functions are bound again everywhere."""
+    import sys
+
+    import ddsp.core as rcore
+    import ddsp.vocoder as rvoc
+    for name, cls in (("Sins", Sins), ("CombSub", CombSub), ("CombSubFast", CombSubFast), ("CombSubSuperFast", CombSubSuperFast)):
+        ref = getattr(rvoc, "_reference_" + name, None)
+        if ref is None:
+            continue
+        setattr(rvoc, name, ref)
+        for modname in ("diffusion.vocoder", "reflow.vocoder", "train"):
+            mod = sys.modules.get(modname)
+            if mod is not None and getattr(mod, name, None) is cls:
+                setattr(mod, name, ref)
+        delattr(rvoc, "_reference_" + name)
+        cls._reference_cls = None
+    for name in PATCHED_CORE_FUNCTIONS:
+        ref = getattr(rcore, "_reference_" + name, None)
+        if ref is None:
+            continue
+        patched = getattr(rcore, name)
+        setattr(rcore, name, ref)
+        delattr(rcore, "_reference_" + name)
+        for modname in ("ddsp.vocoder", "ddsp.loss", "main", "main_diff", "batch_infer", "gui"):
+            mod = sys.modules.get(modname)
+            if mod is not None and getattr(mod, name, None) is patched:
+                setattr(mod, name, ref)

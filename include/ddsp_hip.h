@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 132          /* 0.1.3: + adjoints, NSF source, spectral loss */
+#define DDSP_HIP_VERSION 140          /* 0.1.4: + tuning knobs, window_impulse_response, windowed complex adjoint */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -48,6 +48,13 @@ extern "C" {
 
 int ddsp_hip_version(void);
 const char* ddsp_hip_error_string(int code);
+
+/* Tuning / test knobs of the launchers (workgroup run lengths, which occupancy build of a kernel is launched, ...):
+ * names as in DESIGN.md section 7 without the DDSP_HIP_ prefix ("BLK_RUN", "STFT_WPS", ...).  Each knob takes its
+ * initial value from the environment variable DDSP_HIP_<NAME> ONCE, at first use; after that only set_tuning changes
+ * it (0 = built-in default).  No reference counterpart: measurement tools and the run-split tests use them. */
+int ddsp_hip_set_tuning(const char* name, long value);
+long ddsp_hip_get_tuning(const char* name);
 
 /* ddsp/core.py:66-70  upsample(signal[B,F,C], factor=hop) -> out[B,F*hop,C] */
 int ddsp_hip_upsample(const float* sig, int B, int F, int C, int hop, float* out, void* stream);
@@ -84,13 +91,20 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
 
 /* Adjoints of the two calls above (what autograd returns for the response / the raw control):
  *   impulse_response_backward: d_taps[rows,N] -> d_re[rows,n_mag] (+ d_im[rows,n_mag] when d_im is not NULL:
- *   the complex case, act NONE / mode ROLL only).  With act EXP the result is the gradient of the raw control
+ *   the complex case, act NONE only; every window mode -- the reference builds its real responses as
+ *   torch.complex(param, 0), vocoder.py:606,849,857, so a windowed complex response under autograd is the normal case).  With act EXP the result is the gradient of the raw control
  *   itself (d_re = dL/dc = dL/dresp * scale * exp(c), ctrl/ld_ctrl = the forward's resp_re/ld_re); the window
  *   (mode, half_width) is a constant factor.
  *   allpass_backward: (d_re, d_im)[rows,n_mag] of exp(1j*cumsum(pi*tanh(c))) -> d_c[rows,n_mag]. */
 int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale,
                                        int mode, const float* half_width, long rows, int n_mag, const float* table,
                                        float* d_re, float* d_im, void* stream);
+/* ddsp/core.py:185-237 apply_window_to_impulse_response (window_size = 0, causal = False) and :240-251
+ * apply_dynamic_window_to_impulse_response on taps that are already in the time domain: zero-phase taps ir[rows,N] ->
+ * windowed causal taps out[rows,N] (out != ir), out[j] = ir[(j - N/2) mod N] * w(j); MODE_ROLL = the bare roll of
+ * core.py:269.  N may be odd in MODE_DYNAMIC (the reference allows 2*n_mag-1 there). */
+int ddsp_hip_window_impulse_response(const float* ir, int mode, const float* half_width, long rows, int N, float* out,
+                                     void* stream);
 int ddsp_hip_allpass_backward(const float* c, long ld, long rows, int n_mag, const float* d_re, const float* d_im,
                               float* d_c, void* stream);
 

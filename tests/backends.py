@@ -24,7 +24,9 @@ def dev(request, monkeypatch):
         monkeypatch.setattr(_ffi, "_LIB", cdll)
         monkeypatch.setattr(_ffi, "check_device", lambda *t: None)
         monkeypatch.setattr(core, "_TABLES", {})
-        monkeypatch.setattr(synth, "_WS", {})
+        # host tensors ARE the emulated device here: never hand them to a patched-in reference class
+        from ddsp_svc_amd import vocoder
+        monkeypatch.setattr(vocoder._SynthBase, "_to_reference", lambda self, f0: False)
         return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

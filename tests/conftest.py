@@ -16,3 +16,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def knobs():
+    """Set launcher tuning knobs (``ddsp_hip_set_tuning``, include/ddsp_hip.h) for one test and restore the defaults
+    afterwards.  ``knobs("BLK_RUN", 2)`` acts on whatever library ``_ffi.lib()`` returns at that moment (the emulator
+    build under the ``emu`` backend, libddsp_hip.so on the GPU), so call it inside the test, after the ``dev`` fixture."""
+    touched = []
+
+    def set_knob(name, value):
+        from ddsp_svc_amd import _ffi
+        lib = _ffi.lib()
+        assert lib.ddsp_hip_set_tuning(name.encode(), int(value)) == 0, name
+        touched.append((lib, name))
+    yield set_knob
+    for lib, name in touched:
+        lib.ddsp_hip_set_tuning(name.encode(), 0)

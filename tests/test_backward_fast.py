@@ -59,9 +59,9 @@ def test_oracle_backward_against_reference_autograd(golden_dir):
     (1024, 1, 5, False, False, False, 1000),
     (1024, 1, 1, False, False, False, 1000),
 ])
-def test_stft_filter_backward(dev, win, B, F, reflect, normalize, nphase, run, monkeypatch):
+def test_stft_filter_backward(dev, win, B, F, reflect, normalize, nphase, run, knobs):
     from ddsp_svc_amd import synth
-    monkeypatch.setenv("DDSP_HIP_STFT_RUN", str(run))
+    knobs("STFT_RUN", run)
     rng = np.random.default_rng(win + 10 * F + B)
     n, T = win // 2 + 1, F * HOP
     exc = rng.standard_normal((B, T)).astype(np.float32)

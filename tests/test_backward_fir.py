@@ -47,11 +47,11 @@ def test_oracle_backward_against_reference_autograd():
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("B,F,N,run", [(2, 7, 510, 1000), (1, 8, 510, 1), (1, 1, 510, 1000), (2, 2, 30, 1000), (1, 5, 512, 2),
                                        (1, 13, 2, 3), (1, 12, 254, 1)])
-def test_fft_convolve_backward(dev, B, F, N, run, monkeypatch):
+def test_fft_convolve_backward(dev, B, F, N, run, knobs):
     """odd / even block counts (the held last tap row), a single frame, the largest N, several runs per utterance
     (carry rebuilt by the warm-up pair)"""
     from ddsp_svc_amd import core
-    monkeypatch.setenv("DDSP_HIP_BLK_RUN", str(run))
+    knobs("BLK_RUN", run)
     x, ir, R = _case(B, F, N, 100 * F + N)
     t = lambda a: torch.from_numpy(a).to(dev)
     dx, dh = core.fft_convolve_backward(t(R), t(x), t(ir))

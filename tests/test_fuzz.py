@@ -17,7 +17,7 @@ def _rms(a):
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("seed", range(8))
-def test_random_harmonic_plus_noise_tails(dev, seed, monkeypatch):
+def test_random_harmonic_plus_noise_tails(dev, seed, knobs):
     from ddsp_svc_amd import synth
     rng = np.random.default_rng(1000 + seed)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -26,10 +26,7 @@ def test_random_harmonic_plus_noise_tails(dev, seed, monkeypatch):
         n = int(rng.choice([256, 256, 129, 65, 33, 252, 200]))
         kind = rng.choice(["combsub", "sins"])
         run = int(rng.choice([0, 1, 2, 3, 5]))
-        if run:
-            monkeypatch.setenv("DDSP_HIP_BLK_RUN", str(run))
-        else:
-            monkeypatch.delenv("DDSP_HIP_BLK_RUN", raising=False)
+        knobs("BLK_RUN", run or 0)
         H = int(rng.choice([256, 128, 40, 17])) if kind == "sins" else n
         f0 = O.synth_f0(B, F, SR, HOP, seed=int(rng.integers(1 << 30)))
         ctrls = [rng.standard_normal((B, F, s)).astype(np.float32) * 0.7 for s in (H, n, n)]
@@ -46,7 +43,7 @@ def test_random_harmonic_plus_noise_tails(dev, seed, monkeypatch):
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("seed", range(4))
-def test_random_spectral_tails(dev, seed, monkeypatch):
+def test_random_spectral_tails(dev, seed, knobs):
     from ddsp_svc_amd import synth
     rng = np.random.default_rng(2000 + seed)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -54,10 +51,7 @@ def test_random_spectral_tails(dev, seed, monkeypatch):
         B, F = int(rng.integers(1, 3)), int(rng.integers(1, 30))
         kind = rng.choice(["fast", "super"])
         run = int(rng.choice([0, 1, 2, 3]))
-        if run:
-            monkeypatch.setenv("DDSP_HIP_STFT_RUN", str(run))
-        else:
-            monkeypatch.delenv("DDSP_HIP_STFT_RUN", raising=False)
+        knobs("STFT_RUN", run or 0)
         f0 = O.synth_f0(B, F, SR, HOP, seed=int(rng.integers(1 << 30)))
         if kind == "fast":
             c = [rng.standard_normal((B, F, 513)).astype(np.float32) * 0.5 for _ in range(3)]

@@ -81,11 +81,11 @@ def test_get_mel_golden(dev, golden_dir, tag):
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("B,T,run", [(1, 512 * 7, 1), (3, 512 * 9 + 100, 2), (1, 700, 4), (2, 300, 4), (1, 512 * 33, 3)])
-def test_get_mel_shapes(dev, B, T, run, monkeypatch):
+def test_get_mel_shapes(dev, B, T, run, knobs):
     """odd frame counts, lengths that are not a multiple of the hop, signals shorter than the padding (zero-padding
     branch, nvSTFT.py:99-102), several runs per utterance; the class builds its own Slaney basis here"""
     from ddsp_svc_amd import mel as M
-    monkeypatch.setenv("DDSP_HIP_MEL_RUN", str(run))
+    knobs("MEL_RUN", run)
     rng = np.random.default_rng(T)
     t = np.arange(T) / 44100.0
     y = (0.4 * np.sin(2 * np.pi * 330.0 * t)[None] + 0.1 * rng.standard_normal((B, T))).astype(np.float32)

@@ -234,26 +234,47 @@ def test_fast_against_reference_module(dev, kind):
 
 
 def test_patch_reference_swaps_classes_and_keeps_cpu_core():
+    """patch_reference(): classes and ddsp.core names rebound (incl. the two window helpers, core.py:185,240, and the
+    names ddsp.vocoder bound at import, vocoder.py:16); host tensors keep the reference's code -- functions AND module
+    forward (load_model's default device is 'cpu', vocoder.py:506) -- with the reference's autograd intact;
+    unpatch_reference() restores everything."""
     rcore, rvoc = _import_reference()
     from ddsp_svc_amd import vocoder as V
-    if not hasattr(rvoc, "_reference_CombSub"):
-        rvoc._reference_CombSub, rvoc._reference_Sins = rvoc.CombSub, rvoc.Sins
+    originals = {n: getattr(rcore, n) for n in V.PATCHED_CORE_FUNCTIONS}
+    ref_combsub = rvoc.CombSub
     try:
         V.patch_reference()
         assert rvoc.Sins is V.Sins and rvoc.CombSub is V.CombSub
         assert rvoc.CombSubFast is V.CombSubFast and rvoc.CombSubSuperFast is V.CombSubSuperFast
-        sig = torch.rand(1, 4, 2)
-        out = rcore.upsample(sig, 8)                         # CPU tensors keep the reference implementation
+        for n in V.PATCHED_CORE_FUNCTIONS:
+            assert getattr(rcore, n) is not originals[n] and getattr(rcore, "_reference_" + n) is originals[n]
+        assert rvoc.upsample is rcore.upsample and rvoc.frequency_filter is rcore.frequency_filter
+        sig = torch.rand(1, 4, 2, requires_grad=True)
+        out = rcore.upsample(sig, 8)                         # CPU tensors keep the reference implementation ...
         assert out.shape == (1, 32, 2)
-        np.testing.assert_array_equal(out.numpy(), O.upsample(sig.numpy(), 8))
+        np.testing.assert_array_equal(out.detach().numpy(), O.upsample(sig.detach().numpy(), 8))
+        out.sum().backward()                                 # ... and its autograd
+        assert sig.grad is not None and float(sig.grad.sum()) == pytest.approx(64.0)
+        ir = torch.randn(1, 3, 30)
+        np.testing.assert_array_equal(rcore.apply_window_to_impulse_response(ir).numpy(),
+                                      originals["apply_window_to_impulse_response"](ir).numpy())
+        # a drop-in module fed host tensors runs the reference's forward (no HIP library involved)
+        torch.manual_seed(1)
+        m = rvoc.CombSub(SR, HOP, 17, 9, 9, n_unit=8, n_spk=1).eval()
+        assert type(m) is V.CombSub and V.CombSub._reference_cls is ref_combsub
+        units, f0, vol, u = _inputs(1, 4, 8, torch.device("cpu"), seed=2)
+        with torch.no_grad(), mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)):
+            sig_cpu, _, _ = m(units, f0, vol)
+            ref = ref_combsub(SR, HOP, 17, 9, 9, n_unit=8, n_spk=1).eval()
+            ref.load_state_dict(m.state_dict(), strict=True)
+            sig_ref, _, _ = ref(units, f0, vol)
+        assert torch.equal(sig_cpu, sig_ref)
     finally:
-        rvoc.Sins, rvoc.CombSub = rvoc._reference_Sins, rvoc._reference_CombSub
-        rvoc.CombSubFast, rvoc.CombSubSuperFast = rvoc._reference_CombSubFast, rvoc._reference_CombSubSuperFast
-        for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response"):
-            if hasattr(rcore, "_reference_" + name):
-                setattr(rcore, name, getattr(rcore, "_reference_" + name))
-                delattr(rcore, "_reference_" + name)
-        rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter
+        V.unpatch_reference()
+    assert rvoc.CombSub is ref_combsub and V.CombSub._reference_cls is None
+    for n in V.PATCHED_CORE_FUNCTIONS:
+        assert getattr(rcore, n) is originals[n] and not hasattr(rcore, "_reference_" + n)
+    assert rvoc.upsample is originals["upsample"]
 
 
 @pytest.mark.parametrize("dev", ["emu"], indirect=True)
@@ -299,13 +320,7 @@ def test_patch_reference_reaches_the_cascades(dev):
             e = rms((o_wav - r_wav).numpy())
             assert e <= 2e-5 * rms(r_wav.numpy()) and e <= 1e-4, (type(ref).__name__, e, rms(r_wav.numpy()))
     finally:
+        V.unpatch_reference()
         for m, names in saved.items():
             for n, c in names.items():
                 setattr(m, n, c)
-        for n, c in ref_names.items():
-            setattr(rvoc, n, c)
-        for name in ("upsample", "remove_above_fmax", "frequency_filter", "fft_convolve", "frequency_impulse_response"):
-            if hasattr(rcore, "_reference_" + name):
-                setattr(rcore, name, getattr(rcore, "_reference_" + name))
-                delattr(rcore, "_reference_" + name)
-        rvoc.upsample, rvoc.remove_above_fmax, rvoc.frequency_filter = rcore.upsample, rcore.remove_above_fmax, rcore.frequency_filter

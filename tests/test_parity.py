@@ -288,10 +288,10 @@ def test_fft_convolve_shapes(dev, B, F, hop, N):
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("impl", [2, 3])
-def test_fft_convolve_persistent_loop(dev, impl, monkeypatch):
+def test_fft_convolve_persistent_loop(dev, impl, knobs):
     """few resident workgroups, many tiles each: exercises the tile loop and the register prefetch of tile i+1"""
     from ddsp_svc_amd import core
-    monkeypatch.setenv("DDSP_HIP_FIR_MAX_SLOTS", "1")
+    knobs("FIR_MAX_SLOTS", 1)
     rng = np.random.default_rng(77)
     B, F, hop, N = 3, 21, 512, 254
     audio = (rng.random((B, F * hop)) * 2 - 1).astype(np.float32)
@@ -305,13 +305,13 @@ def test_fft_convolve_persistent_loop(dev, impl, monkeypatch):
 @pytest.mark.parametrize("impl", [4, 5])
 @pytest.mark.parametrize("B,F,N,run", [(1, 1, 510, 12), (2, 2, 30, 12), (1, 3, 512, 12), (2, 7, 510, 2), (1, 8, 128, 1), (1, 13, 2, 3),
                                        (1, 12, 254, 1)])
-def test_fft_convolve_fft_form(dev, B, F, N, run, impl, monkeypatch):
+def test_fft_convolve_fft_form(dev, B, F, N, run, impl, knobs):
     """impl 4 / 5 (frequency-domain convolution per frame / per hop block): odd/even frame counts, single frames,
     the largest N they take, short workgroup runs (warm-up pair + hand-over between workgroups), and the fused
     input/output options"""
     from ddsp_svc_amd import _ffi
-    monkeypatch.setenv("DDSP_HIP_FFT_RUN", str(run))
-    monkeypatch.setenv("DDSP_HIP_BLK_RUN", str(run))
+    knobs("FFT_RUN", run)
+    knobs("BLK_RUN", run)
     rng = np.random.default_rng(B * 100 + F * 10 + N)
     T = F * HOP
     u = rng.uniform(0, 1, size=(B, T)).astype(np.float32)

@@ -112,7 +112,7 @@ def test_stft_filter(dev, win, B, F, reflect, normalize, nphase):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-def test_stft_filter_run_split(dev, monkeypatch):
+def test_stft_filter_run_split(dev, knobs):
     """the split of an utterance into runs of frame pairs (with warm-up) must not change a single bit"""
     from ddsp_svc_amd import synth
     win, B, F = 2048, 1, 37
@@ -120,7 +120,7 @@ def test_stft_filter_run_split(dev, monkeypatch):
     args = [T_(a, dev) for a in (exc, nz, hm, hp, nm, nph, hann(win))]
     outs = []
     for run in ("1", "3", "8", "1000"):
-        monkeypatch.setenv("DDSP_HIP_STFT_RUN", run)
+        knobs("STFT_RUN", int(run))
         outs.append(N_(synth.stft_filter(*args, HOP)))
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])

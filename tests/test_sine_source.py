@@ -67,7 +67,16 @@ def test_source_module_dropin(dev, monkeypatch):
     ri0[..., 0] = 0
     ref = O.sine_source(f0.cpu().numpy(), UPP, SR, m.l_linear.weight.detach().cpu().numpy(),
                         m.l_linear.bias.detach().cpu().numpy(), ri0.cpu().numpy().reshape(-1), nz.cpu().numpy())
-    assert np.abs(out.cpu().numpy()[..., 0] - ref).max() <= 2e-6
+    assert np.abs(out.detach().cpu().numpy()[..., 0] - ref).max() <= 2e-6
+    # grad enabled + trainable l_linear (models.py:198-204 is differentiable in the reference): Linear + tanh ran in torch
+    # on the recovered per-harmonic waves; the fused inference path gives the same values
+    assert out.requires_grad
+    with torch.no_grad():
+        fused = m(f0, UPP)
+    assert not fused.requires_grad and np.abs(fused.cpu().numpy()[..., 0] - ref).max() <= 2e-6
+    out.sum().backward()
+    gw = m.l_linear.weight.grad.cpu().numpy().reshape(-1)
+    assert np.isfinite(gw).all() and np.abs(gw).max() > 0
     with pytest.raises(RuntimeError):                                                # unsupported harmonic count
         S.sine_source(f0, UPP, SR, torch.zeros(4, device=dev), torch.zeros(1, device=dev), torch.zeros(4, device=dev),
                       torch.zeros(2, 5 * UPP, 4, device=dev))

@@ -54,7 +54,7 @@ basis, (band, packed), window = stft._tables(dev)
 frames = L.ddsp_hip_mel_frames(T, 2048, 512)
 store = torch.empty(B, frames, 128, device=dev)
 for wps in (2, 3):
-    os.environ["DDSP_HIP_MEL_WPS"] = str(wps)
+    _ffi.set_tuning("MEL_WPS", wps)
     res["mel_wps%d_ms" % wps] = timeit(lambda: _ffi.check(L.ddsp_hip_mel_spectrogram(
         y.data_ptr(), B, T, window.data_ptr(), 2048, 512, basis.data_ptr(), band.data_ptr(), packed.data_ptr(),
         packed.numel(), 128, 1e-5, store.data_ptr(), frames * 128, 1, 128, st)))

@@ -38,12 +38,12 @@ def timeit(impl, reps=20):
 res = {"impl3_mfma8_ms": timeit(3), "impl4_fft2048_ms": timeit(4)}
 y4 = y.clone()
 for wps in os.environ.get("WPS", "2 3").split():
-    os.environ["DDSP_HIP_BLK_WPS"] = wps
+    _ffi.set_tuning("BLK_WPS", int(wps))
     for run in os.environ.get("RUNS", "0").split():
         if run != "0":
-            os.environ["DDSP_HIP_BLK_RUN"] = run
+            _ffi.set_tuning("BLK_RUN", int(run))
         else:
-            os.environ.pop("DDSP_HIP_BLK_RUN", None)
+            _ffi.set_tuning("BLK_RUN", 0)
         res["impl5_blk_wps%s_run%s_ms" % (wps, run)] = timeit(5)
 res["rel_rms_impl5_vs_impl4"] = float(((y - y4).double().pow(2).mean().sqrt() / y4.double().pow(2).mean().sqrt()))
 print(json.dumps(res, indent=1))

@@ -40,12 +40,12 @@ def main():
         hm, hp, nm, nph = torch.split(c, [n] * 4, dim=-1)
         w = torch.hann_window(win, device=dev)
         for occ in occs:
-            os.environ["DDSP_HIP_STFT_WPS"] = str(occ)
+            _ffi.set_tuning("STFT_WPS", occ)
             for run in os.environ.get("RUNS", "0").split():
                 if run != "0":
-                    os.environ["DDSP_HIP_STFT_RUN"] = run
+                    _ffi.set_tuning("STFT_RUN", int(run))
                 else:
-                    os.environ.pop("DDSP_HIP_STFT_RUN", None)
+                    _ffi.set_tuning("STFT_RUN", 0)
                 ms = timeit(lambda: synth.stft_filter(exc, nz, hm, hp, nm, nph if win == 2048 else None, w, HOP,
                                                       pad_reflect=True, normalize=True))
                 res["win%d_wps%d_run%s_ms" % (win, occ, run)] = round(ms, 4)
