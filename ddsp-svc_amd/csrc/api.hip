@@ -13,7 +13,7 @@ using namespace ddsp;
 namespace ddsp {
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
-                                            "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "FUSED_TAPS"};
+                                            "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -121,6 +121,25 @@ struct Branch {
   }
 };
 
+// tap synthesis of one filter: the prime-factor form when the shape is its (n_mag = 256), else the dense contraction
+void synth_taps(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale, const float* table,
+                int mode, const float* half_width, long rows, int n, float* taps, hipStream_t st, float hw_sr = 0.f) {
+  if (launch_taps_pfa510(a_re, ld_re, a_im, ld_im, 0, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr) == 0)
+    return;
+  launch_ir_gemm(a_re, ld_re, a_im, ld_im, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr);
+}
+
+// all-pass taps from the raw group-delay control (vocoder.py:581,599 / :834,845): fused in the prime-factor kernel, else
+// response (re, im scratch of rows * n floats each) + dense contraction
+void synth_allpass_taps(const float* c_gd, long ld_gd, const float* table, long rows, int n, float* re, float* im,
+                        float* taps, hipStream_t st) {
+  if (launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n,
+                         taps, st) == 0)
+    return;
+  launch_allpass_response(c_gd, ld_gd, rows, n, re, im, st);
+  launch_ir_gemm(re, n, im, n, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n, taps, st);
+}
+
 size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_max - 1);
   w.buf0 = c.take<float>(BT);
@@ -216,7 +235,24 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
   if (rows == 0) return 0;
   if (!resp_re || !table || !taps) return DDSP_HIP_EINVAL;
   if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
-  launch_ir_gemm(resp_re, ld_re, resp_im, ld_im, act, scale, table, mode, half_width, rows, n_mag, taps, S(stream));
+  synth_taps(resp_re, ld_re, resp_im, ld_im, act, scale, table, mode, half_width, rows, n_mag, taps, S(stream));
+  return finish();
+}
+
+size_t ddsp_hip_allpass_taps_scratch_bytes(long rows, int n_mag) {
+  if (rows <= 0 || n_mag < 2) return 0;
+  return align_up((size_t)rows * n_mag * sizeof(float), 256) * 2;
+}
+
+int ddsp_hip_allpass_taps(const float* c, long ld, long rows, int n_mag, const float* table, float* taps, void* scratch,
+                          size_t scratch_bytes, void* stream) {
+  if (rows < 0 || n_mag < 2 || ld < n_mag) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!c || !table || !taps || !scratch) return DDSP_HIP_EINVAL;
+  if (scratch_bytes < ddsp_hip_allpass_taps_scratch_bytes(rows, n_mag)) return DDSP_HIP_EWS;
+  float* re = static_cast<float*>(scratch);
+  float* im = reinterpret_cast<float*>(static_cast<char*>(scratch) + align_up((size_t)rows * n_mag * sizeof(float), 256));
+  synth_allpass_taps(c, ld, table, rows, n_mag, re, im, taps, S(stream));
   return finish();
 }
 
@@ -279,8 +315,7 @@ int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_
   if (ws_bytes < ddsp_hip_frequency_filter_workspace_bytes(B, F, n_mag)) return DDSP_HIP_EWS;
   float* taps = static_cast<float*>(ws);
   const long R = (long)B * F;
-  launch_ir_gemm(resp_re, ld_re, resp_im, ld_im, DDSP_HIP_ACT_NONE, 1.0f, table, mode, half_width, R, n_mag, taps,
-                 S(stream));
+  synth_taps(resp_re, ld_re, resp_im, ld_im, DDSP_HIP_ACT_NONE, 1.0f, table, mode, half_width, R, n_mag, taps, S(stream));
   if (launch_fir(audio, 0, taps, nullptr, out, nullptr, B, F, hop, 2 * (n_mag - 1), DDSP_HIP_FIR_AUTO, S(stream)) < 0)
     return DDSP_HIP_ESHAPE;
   return finish();
@@ -363,13 +398,11 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (br.forked) {
     // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                   n_nz, w.taps_nz, br.aux);
+    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+               n_nz, w.taps_nz, br.aux);
     const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
                               br.aux);
-    launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
-    launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                   w.taps, st);
+    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
     br.join();                                           // always joined, also on the error paths below
     if (r == -1) return DDSP_HIP_EHOP;
@@ -380,9 +413,7 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
     return finish();
   }
   // all-pass taps first (their response lives in buf0 until the exciter overwrites it)
-  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
-  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                 w.taps, st);
+  synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
   // exciter: sinusoid bank (vocoder.py:585-594)
   int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
   if (r == -1) return DDSP_HIP_EHOP;
@@ -392,8 +423,8 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (launch_fir(w.buf0, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise, added to harmonic (vocoder.py:603-609)
-  launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                 n_nz, w.taps, st);
+  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+             n_nz, w.taps, st);
   if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
                  st) < 0)
     return DDSP_HIP_ESHAPE;
@@ -423,20 +454,18 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (br.forked) {
     // noise branch (vocoder.py:854-858) on the second stream, beside the harmonic chain
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                   n_nz, w.taps_nz, br.aux);
+    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+               n_nz, w.taps_nz, br.aux);
     const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
                               br.aux);
-    launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
-    launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                   w.taps, st);
+    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
     int r1 = 0;
     if (rc == 0) {
       r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
       // half_width_frames = 1.5 sr / (f0 + 1e-3) (vocoder.py:851) is formed in the kernel's epilogue
-      launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
-                     n_harm, w.taps, st, (float)sr);
+      synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
+                 n_harm, w.taps, st, (float)sr);
     }
     br.join();                                           // always joined, also on the error paths below
     if (rc != 0) return DDSP_HIP_EHOP;
@@ -448,21 +477,19 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   }
   float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
   // all-pass taps first (vocoder.py:843-846; their response lives in buf0 until the exciter overwrites it)
-  launch_allpass_response(c_gd, ld_gd, R, n_ap, w.re, w.im, st);
-  launch_ir_gemm(w.re, n_ap, w.im, n_ap, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                 w.taps, st);
+  synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
   // exciter: combtooth (vocoder.py:839-840)
   if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st) != 0) return DDSP_HIP_EHOP;
   if (launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851)
-  launch_ir_gemm(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
-                 w.taps, st, (float)sr);
+  synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
+             w.taps, st, (float)sr);
   if (launch_fir(w.buf1, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   // noise branch + mix (vocoder.py:854-860)
-  launch_ir_gemm(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                 n_nz, w.taps, st);
+  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+             n_nz, w.taps, st);
   if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
                  st) < 0)
     return DDSP_HIP_ESHAPE;

@@ -1,0 +1,348 @@
+// HOT-2b, fast form for n_mag = 256: frequency response -> per-frame FIR taps (ddsp/core.py:254-270 with the window
+// helpers :185-251, fed by the activations of ddsp/vocoder.py:580-582,599 / :834-836,845) as a PRIME-FACTOR FFT.
+//
+// torch.fft.irfft of 256 bins is an inverse DFT of N = 510 = 2 * 3 * 5 * 17 points.  The four factors are pairwise
+// coprime, so the Good-Thomas index maps split the transform into small DFTs with NO twiddle factors in between:
+//     n = (30 n1 + 17 n2) mod 510,   k = (120 k1 + 391 k2) mod 510        (17 x 30;  120 = 30 * (30^-1 mod 17), 391 = 17 * (17^-1 mod 30))
+//     n2 = (15 a + 10 b + 6 c) mod 30, k2 = (15 ka + 10 kb + 6 kc) mod 30  (2 x 3 x 5 inside the 30)
+//     z[k] = sum_n Z[n] W^(nk)  =  DFT_30 over n2 of ( DFT_17 over n1 of Z )
+// One complex transform carries TWO frames (Z = X_a + i X_b of the Hermitian-extended responses, z = ir_a + i ir_b),
+// real responses (zero-phase magnitude filters) and complex ones (the all-pass) alike: 510 * (17 + 2 + 3 + 5) / 2 ~ 7 k
+// complex multiply-adds per frame against 65 k (131 k for the all-pass) real ones of the dense contraction in ir.hip
+// -- the tap synthesis stops being GEMM-shaped and becomes what the rest of the path is: bound by its HBM streams
+// (1 KB of control in, 2 KB of taps out per frame).  The activations (exp, exp/128, all-pass pi*tanh -> cumsum ->
+// cos/sin) are applied while the rows are staged, roll + window while they are stored.  ir.hip stays the path for
+// every other n_mag (N = 2(n-1) has large prime factors in general: 254 = 2 * 127).
+//
+// Workgroup = 256 threads, 16 frames = 8 transforms per batch:
+//   stage 0  coalesced loads of the 16 control rows, activation, scaled by 1/N           -> LDS rows
+//   stage A  thread (t, n2), 240 of 256: gathers its 17 points, DFT-17                   -> LDS W[t][k1][n2]
+//   stage B  thread (t, k1), 136 of 256: 30 contiguous points, DFT-30 in registers       -> LDS O[row][tap], rolled
+//   stage C  window + fully coalesced 16-byte stores of the batch's contiguous 16 x 510 taps
+#include "ddsp_common.h"
+#include "fft2048.h"
+#include "kernels.h"
+
+namespace ddsp {
+
+using fft::add_mi;
+using fft::sub_mi;
+
+namespace pfa {
+
+constexpr int NB = 256, NT = 510, HALF = 255;
+constexpr int ROWS = 16, TR = 8;                 // frames and transforms per batch
+constexpr int WSTRIDE = 31;                      // complex words per (t, k1) row of W: odd, so 8-byte accesses spread over the banks
+constexpr int KIND_REAL = 0, KIND_COMPLEX = 1, KIND_ALLPASS = 2;
+enum { MODE_ROLL = 0, MODE_HANN = 1, MODE_DYNAMIC = 2 };
+
+// cos / sin (2 pi r / 17), r = 0..8
+__device__ constexpr float C17[9] = {1.0f, 0.93247222940435580f, 0.73900891722065910f, 0.44573835577653826f,
+                                     0.09226835946330200f, -0.27366299007208283f, -0.60263463637925640f,
+                                     -0.85021713572961420f, -0.98297309968390180f};
+__device__ constexpr float S17[9] = {0.0f, 0.36124166618715290f, 0.67369564364655720f, 0.89516329135506230f,
+                                     0.99573417629503450f, 0.96182564317281900f, 0.79801722728023950f,
+                                     0.52643216287735580f, 0.18374951781657034f};
+constexpr float C5_1 = 0.30901699437494745f, C5_2 = -0.80901699437494745f;      // cos(2 pi / 5), cos(4 pi / 5)
+constexpr float S5_1 = 0.95105651629515350f, S5_2 = 0.58778525229247310f;       // sin(2 pi / 5), sin(4 pi / 5)
+constexpr float S3 = 0.86602540378443860f;                                       // sin(2 pi / 3)
+
+__device__ __forceinline__ f32x2 fma2(float c, f32x2 a, f32x2 acc) { return __builtin_elementwise_fma(f32x2{c, c}, a, acc); }
+
+// all small transforms use the + sign (inverse DFT): X[k] = sum_n x[n] exp(+2 pi i n k / p)
+__device__ __forceinline__ void dft17(f32x2 (&z)[17]) {
+  f32x2 s[9], d[9];
+#pragma unroll
+  for (int j = 1; j <= 8; ++j) { s[j] = z[j] + z[17 - j]; d[j] = z[j] - z[17 - j]; }
+  f32x2 x0 = z[0];
+  f32x2 dc = x0;
+#pragma unroll
+  for (int j = 1; j <= 8; ++j) dc = dc + s[j];
+#pragma unroll
+  for (int k = 1; k <= 8; ++k) {
+    f32x2 p = x0, q = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = 1; j <= 8; ++j) {
+      const int r = (j * k) % 17;
+      const int rr = r <= 8 ? r : 17 - r;
+      p = fma2(C17[rr], s[j], p);
+      q = fma2(r <= 8 ? S17[rr] : -S17[rr], d[j], q);
+    }
+    z[k] = sub_mi(p, q);             // p + i q
+    z[17 - k] = add_mi(p, q);        // p - i q
+  }
+  z[0] = dc;
+}
+
+__device__ __forceinline__ void dft5(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4) {
+  const f32x2 t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+  const f32x2 m1 = fma2(C5_2, t2, fma2(C5_1, t1, x0));
+  const f32x2 m2 = fma2(C5_1, t2, fma2(C5_2, t1, x0));
+  const f32x2 n1 = fma2(S5_2, t4, f32x2{S5_1, S5_1} * t3);
+  const f32x2 n2 = fma2(-S5_1, t4, f32x2{S5_2, S5_2} * t3);
+  x0 = x0 + t1 + t2;
+  x1 = sub_mi(m1, n1);
+  x4 = add_mi(m1, n1);
+  x2 = sub_mi(m2, n2);
+  x3 = add_mi(m2, n2);
+}
+
+__device__ __forceinline__ void dft3(f32x2& x0, f32x2& x1, f32x2& x2) {
+  const f32x2 t = x1 + x2, d = x1 - x2;
+  const f32x2 m = fma2(-0.5f, t, x0);
+  const f32x2 n = f32x2{S3, S3} * d;
+  x0 = x0 + t;
+  x1 = sub_mi(m, n);
+  x2 = add_mi(m, n);
+}
+
+// 30 points in the order they arrive (n2 = 0..29) -> v[k2], k2 = 0..29, through the 2 x 3 x 5 prime-factor maps;
+// every index below is a compile-time constant after unrolling, so the 30 points stay in registers
+__device__ __forceinline__ void dft30(f32x2 (&v)[30]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int o = 15 * a + 10 * b;
+      dft5(v[o % 30], v[(o + 6) % 30], v[(o + 12) % 30], v[(o + 18) % 30], v[(o + 24) % 30]);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int o = 15 * a + 6 * c;
+      dft3(v[o % 30], v[(o + 10) % 30], v[(o + 20) % 30]);
+    }
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int o = (10 * b + 6 * c) % 30;
+      const f32x2 p = v[o], q = v[(o + 15) % 30];
+      v[o] = p + q;
+      v[(o + 15) % 30] = p - q;
+    }
+  // in place: position (15 a + 10 b + 6 c) mod 30 now holds output k2 = (15 ka + 10 kb + 6 kc) mod 30 with (ka,kb,kc) = (a,b,c)
+}
+
+// cos(a) for the dynamic window, |a| < ~10 (same reduction as sin_turns, hardware cosine in revolutions; ir.hip)
+__device__ __forceinline__ float cos_turns_w(float a) {
+  const float inv_hi = 0.15915494f, inv_lo = 6.4206383e-9f;
+  float nn = rintf(a * inv_hi);
+  float r = fmaf(a, inv_hi, -nn);
+  r = fmaf(a, inv_lo, r);
+  return __builtin_amdgcn_cosf(r);
+}
+
+// LDS: rows re[16][256] (+ im[16][256] for complex kinds) alias the output staging O[16][510]; W[8][17][31] complex
+constexpr int IN_FLOATS = 2 * ROWS * NB;                                  // 8192 floats = 32 KB >= 16 * 510
+constexpr int W_WORDS = TR * 17 * WSTRIDE;                                // complex words
+
+}  // namespace pfa
+
+template <int KIND, int ACT, int MODE>
+__global__ void __launch_bounds__(256, 2) k_taps_pfa510(const float* __restrict__ a_re, long ld_re,
+                                                     const float* __restrict__ a_im, long ld_im, float scale,
+                                                     const float* __restrict__ hann, const float* __restrict__ half_width,
+                                                     float hw_sr, long rows, float* __restrict__ taps) {
+  using namespace pfa;
+  __shared__ __attribute__((aligned(16))) float io[IN_FLOATS];
+  __shared__ __attribute__((aligned(16))) f32x2 W[W_WORDS];
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * ROWS;
+  float* re_s = io;
+  float* im_s = io + ROWS * NB;
+  const float inv_n = 1.0f / (float)NT;
+
+  // ---- stage 0: rows -> LDS, activated and scaled by 1/N.  irfft drops Im(DC) and Im(Nyquist) (core.py:259) ----
+  if (KIND == KIND_ALLPASS) {
+    // exp(1j * cumsum(pi * tanh(c))) (vocoder.py:581,599 / :834,845): wave w takes rows 4w..4w+3, a lane owns 4 consecutive
+    // bins; float64 scan reduced to revolutions before the float cosine / sine, as k_allpass_response (ir.hip)
+    const int wave = tid >> 6, lane = tid & 63;
+    const double inv_2pi = 0.15915494309189533577;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      const long gr = row0 + r;
+      float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < rows) {
+        const float* src = a_re + gr * ld_re + 4 * lane;
+        cv.x = src[0]; cv.y = src[1]; cv.z = src[2]; cv.w = src[3];
+      }
+      const float g0 = kPiF * tanhf(cv.x), g1 = kPiF * tanhf(cv.y), g2 = kPiF * tanhf(cv.z), g3 = kPiF * tanhf(cv.w);
+      const double local = (((double)g0 + (double)g1) + (double)g2) + (double)g3;
+      double run = wave_excl_scan(local, lane);
+      float co[4], si[4];
+      const float g[4] = {g0, g1, g2, g3};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        run += (double)g[e];
+        const double rev = run * inv_2pi;
+        const float fr = (float)(rev - rint(rev));
+        co[e] = __builtin_amdgcn_cosf(fr) * inv_n;
+        si[e] = __builtin_amdgcn_sinf(fr) * inv_n;
+      }
+      if (gr >= rows) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) co[e] = si[e] = 0.f;
+      }
+      if (lane == 0) si[0] = 0.f;                       // Im(DC)
+      if (lane == 63) si[3] = 0.f;                      // Im(Nyquist)
+      *reinterpret_cast<float4*>(re_s + r * NB + 4 * lane) = make_float4(co[0], co[1], co[2], co[3]);
+      *reinterpret_cast<float4*>(im_s + r * NB + 4 * lane) = make_float4(si[0], si[1], si[2], si[3]);
+    }
+  } else {
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const long gr = row0 + r;
+    const bool live = gr < rows;
+    const float sc = scale * inv_n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = c4 + 64 * q;
+      float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const float* src = a_re + gr * ld_re + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = src[e];
+        if (KIND == KIND_COMPLEX) {
+          const float* si = a_im + gr * ld_im + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = si[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = live ? (ACT == 1 ? expf(v[e]) * sc : v[e] * sc) : 0.f;
+        w[e] = live ? w[e] * sc : 0.f;
+      }
+      if (KIND == KIND_COMPLEX) {
+        if (k == 0) w[0] = 0.f;
+        if (k + 3 == NB - 1) w[3] = 0.f;
+        *reinterpret_cast<float4*>(im_s + r * NB + k) = make_float4(w[0], w[1], w[2], w[3]);
+      }
+      *reinterpret_cast<float4*>(re_s + r * NB + k) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage A: DFT-17 over n1 of Z[(30 n1 + 17 n2) mod 510], Z = X_a + i X_b, X[510 - k] = conj X[k] ----
+  if (tid < TR * 30) {
+    const int t = tid / 30, n2 = tid - 30 * t;
+    const float* ra = re_s + (2 * t) * NB;
+    const float* rb = ra + NB;
+    const float* ia = im_s + (2 * t) * NB;
+    const float* ib = ia + NB;
+    f32x2 z[17];
+    int k = 17 * n2;                                     // < 510
+#pragma unroll
+    for (int n1 = 0; n1 < 17; ++n1) {
+      const bool mir = k > HALF;
+      const int kk = mir ? NT - k : k;
+      if (KIND == KIND_REAL) {
+        z[n1] = f32x2{ra[kk], rb[kk]};
+      } else {
+        const float sg = mir ? -1.0f : 1.0f;
+        z[n1] = f32x2{fmaf(-sg, ib[kk], ra[kk]), fmaf(sg, ia[kk], rb[kk])};
+      }
+      k += 30;
+      if (k >= NT) k -= NT;
+    }
+    dft17(z);
+    f32x2* dst = W + (t * 17) * WSTRIDE + n2;
+#pragma unroll
+    for (int k1 = 0; k1 < 17; ++k1) dst[k1 * WSTRIDE] = z[k1];
+  }
+  __syncthreads();
+
+  // ---- stage B: DFT-30 over n2; output index m = (120 k1 + 391 k2) mod 510; roll by N/2: tap j = (m + 255) mod 510 ----
+  float* O = io;                                          // [16][510], the rows staged above are dead
+  if (tid < TR * 17) {
+    const int t = tid / 17, k1 = tid - 17 * t;
+    const f32x2* src = W + (t * 17 + k1) * WSTRIDE;
+    f32x2 v[30];
+#pragma unroll
+    for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
+    dft30(v);
+    float* oa = O + (2 * t) * NT;
+    float* ob = oa + NT;
+    const int base = (120 * k1 + HALF) % NT;
+#pragma unroll
+    for (int k2 = 0; k2 < 30; ++k2) {
+      int j = base + (391 * k2) % NT;                     // the second term is a compile-time constant
+      if (j >= NT) j -= NT;
+      oa[j] = v[k2].x;
+      ob[j] = v[k2].y;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage C: window and store; the batch's 16 x 510 taps are one contiguous, 16-byte aligned stretch ----
+  float* dst = taps + row0 * NT;
+  const long total = rows * (long)NT - row0 * NT;         // floats left in the tensor from this batch on
+  for (int i4 = tid; i4 < ROWS * NT / 4; i4 += 256) {
+    const int i = 4 * i4;
+    float4 o = *reinterpret_cast<const float4*>(O + i);
+    float ov[4] = {o.x, o.y, o.z, o.w};
+    if (MODE != MODE_ROLL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = (i + e) / NT;
+        const int j = (i + e) - r * NT;
+        float w;
+        if (MODE == MODE_HANN) {
+          w = hann[j];
+        } else {
+          const long gr = row0 + r;
+          float hv = gr < rows ? half_width[gr] : 1.f;
+          if (hw_sr > 0.f) hv = (1.5f * hw_sr) / (hv + 1e-3f);        // vocoder.py:851, same float32 operations
+          float u = (float)(j - HALF) / hv;                            // core.py:244
+          if (u > 1.0f) u = 0.0f;                                      // core.py:245 -- only the upper side is clamped
+          w = (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                   // core.py:246
+        }
+        ov[e] *= w;
+      }
+    }
+    if (i + 3 < total) {
+      *reinterpret_cast<float4*>(dst + i) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i + e < total) dst[i + e] = ov[e];
+    }
+  }
+}
+
+// returns 0 when the fast form took the call, -1 when the shape is not its (the caller then uses the dense contraction)
+int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
+                       float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
+                       hipStream_t st, float hw_from_f0_sr) {
+  if (n != pfa::NB || rows <= 0 || knob(KNOB_TAPS_GEMM)) return -1;
+  if ((reinterpret_cast<uintptr_t>(taps) & 15) != 0) return -1;
+  const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
+  const float* hann = table + 2 * KP * NP;                 // the periodic Hann of the basis table (k_ir_table, ir.hip)
+  dim3 grid((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), block(256);
+#define DDSP_PFA_LAUNCH(KIND_, ACT_, MODE_)                                                                     \
+  hipLaunchKernelGGL((k_taps_pfa510<KIND_, ACT_, MODE_>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, \
+                     hann, half_width, hw_from_f0_sr, rows, taps)
+#define DDSP_PFA_MODES(KIND_, ACT_)                                     \
+  do {                                                                  \
+    if (mode == pfa::MODE_HANN) DDSP_PFA_LAUNCH(KIND_, ACT_, 1);        \
+    else if (mode == pfa::MODE_DYNAMIC) DDSP_PFA_LAUNCH(KIND_, ACT_, 2); \
+    else DDSP_PFA_LAUNCH(KIND_, ACT_, 0);                               \
+  } while (0)
+  if (allpass_from_control) {
+    DDSP_PFA_MODES(pfa::KIND_ALLPASS, 0);
+  } else if (a_im) {
+    if (act != 0) return -1;
+    DDSP_PFA_MODES(pfa::KIND_COMPLEX, 0);
+  } else if (act == 1) {
+    DDSP_PFA_MODES(pfa::KIND_REAL, 1);
+  } else {
+    DDSP_PFA_MODES(pfa::KIND_REAL, 0);
+  }
+#undef DDSP_PFA_MODES
+#undef DDSP_PFA_LAUNCH
+  return 0;
+}
+
+}  // namespace ddsp

@@ -28,6 +28,11 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
 void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                         int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                         hipStream_t st);
+// prime-factor form of the tap synthesis for n_mag = 256 (ir_pfa.hip); 0 = taken, -1 = not its shape (use launch_ir_gemm).
+// allpass_from_control: a_re is the raw group-delay control (pi*tanh -> cumsum -> cos/sin done in the kernel).
+int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
+                       float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
+                       hipStream_t st, float hw_from_f0_sr = 0.f);
 void launch_window_taps(const float* in, int mode, const float* half_width, long rows, int N, float* out, hipStream_t st);
 void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
                              hipStream_t st);

@@ -211,13 +211,12 @@ class AllpassTapsFunction(torch.autograd.Function):
         cc, ld = _rows(c.detach(), n)
         dev = c.device
         N = 2 * (n - 1)
-        re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
-        im = torch.empty_like(re)
         taps = torch.empty(B, F, N, dtype=torch.float32, device=dev)
-        st = _ffi.stream_of(cc)
-        _ffi.check(_ffi.lib().ddsp_hip_allpass_response(ptr(cc), ld, B * F, n, ptr(re), ptr(im), st))
-        _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ptr(re), n, ptr(im), n, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
-                                                        B * F, n, ptr(ir_table(n, dev)), ptr(taps), st))
+        lib = _ffi.lib()
+        nbytes = lib.ddsp_hip_allpass_taps_scratch_bytes(B * F, n)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ffi.check(lib.ddsp_hip_allpass_taps(ptr(cc), ld, B * F, n, ptr(ir_table(n, dev)), ptr(taps), ptr(scratch), nbytes,
+                                             _ffi.stream_of(cc)))
         ctx.save_for_backward(cc)
         ctx.ld = ld
         return taps

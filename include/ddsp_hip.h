@@ -89,6 +89,13 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
                               float scale, int mode, const float* half_width, long rows, int n_mag,
                               const float* table, float* taps, void* stream);
 
+/* The two calls above in one, from the raw group-delay control c[rows,n_mag] (row stride ld) to the all-pass taps
+ * [rows, 2*(n_mag-1)] (vocoder.py:581,599 / :834,845 + core.py:254-270, hann_window=False).  For n_mag = 256 the response
+ * never reaches memory (prime-factor kernel); other sizes stage it in `scratch` (allpass_taps_scratch_bytes). */
+size_t ddsp_hip_allpass_taps_scratch_bytes(long rows, int n_mag);
+int ddsp_hip_allpass_taps(const float* c, long ld, long rows, int n_mag, const float* table, float* taps, void* scratch,
+                          size_t scratch_bytes, void* stream);
+
 /* Adjoints of the two calls above (what autograd returns for the response / the raw control):
  *   impulse_response_backward: d_taps[rows,N] -> d_re[rows,n_mag] (+ d_im[rows,n_mag] when d_im is not NULL:
  *   the complex case, act NONE only; every window mode -- the reference builds its real responses as

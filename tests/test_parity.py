@@ -428,3 +428,49 @@ def test_tail_golden_256_gpu(dev, golden_dir, name):
         out = synth.combsub_synth(f0, st, T_(g["ctrl_group_delay"], dev), T_(g["ctrl_harmonic_magnitude"], dev),
                                   T_(g["ctrl_noise_magnitude"], dev), T_(g["noise"], dev), SR, HOP)
     _check_tail(out, g)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("rows", [1, 16, 17, 50])
+def test_taps_prime_factor_form(dev, rows, knobs):
+    """n_mag = 256: the prime-factor tap synthesis (csrc/ir_pfa.hip: irfft-510 as 17 x 2 x 3 x 5 without twiddles, two
+    frames per complex transform) against the oracle AND against the dense contraction it replaces (knob TAPS_GEMM), for
+    real / complex responses, the fused exp activation, the all-pass from the raw control, every window mode, odd row
+    counts (a transform whose second frame is missing) and partial batches of 16"""
+    from ddsp_svc_amd import _ffi, core
+    n, N = 256, 510
+    rng = np.random.default_rng(rows)
+    re = rng.standard_normal((1, rows, n)).astype(np.float32)
+    im = rng.standard_normal((1, rows, n)).astype(np.float32)
+    hw = (rng.random((1, rows)) * 300 + 20).astype(np.float32)
+    z = torch.complex(T_(re, dev), T_(im, dev))
+    hwt = T_(hw, dev).unsqueeze(-1)
+    got = {}
+    for path in ("pfa", "gemm"):
+        knobs("TAPS_GEMM", 1 if path == "gemm" else 0)
+        for mode, kw in ((O.MODE_ROLL, dict(hann_window=False)), (O.MODE_HANN, dict()), (O.MODE_DYNAMIC, dict(half_width_frames=hwt))):
+            ref = O.impulse_response(re, im, mode, hw)
+            got[path, mode, "c"] = N_(core.frequency_impulse_response(z, **kw))
+            assert rms(got[path, mode, "c"] - ref) <= 1e-6 * rms(ref), (path, mode)
+            ref = O.impulse_response(np.exp(re.astype(np.float64)), None, mode, hw)
+            got[path, mode, "r"] = N_(core.frequency_impulse_response(torch.exp(T_(re, dev)), **kw))
+            assert rms(got[path, mode, "r"] - ref) <= 1e-6 * rms(ref), (path, mode)
+        # raw control with the activation fused (what the synthesiser tails call) and the all-pass from the raw control
+        ctrl = T_(re[0], dev)
+        taps = torch.empty(rows, N, dtype=torch.float32, device=ctrl.device)
+        tab = core.ir_table(n, ctrl.device)
+        _ffi.check(_ffi.lib().ddsp_hip_impulse_response(ctrl.data_ptr(), n, None, 0, _ffi.ACT_EXP, 1.0 / 128, _ffi.MODE_HANN,
+                                                        None, rows, n, tab.data_ptr(), taps.data_ptr(), _ffi.stream_of(ctrl)))
+        ref = O.impulse_response(np.exp(re.astype(np.float64)) / 128, None, O.MODE_HANN)[0]
+        assert rms(N_(taps) - ref) <= 1e-6 * rms(ref), path
+        nbytes = _ffi.lib().ddsp_hip_allpass_taps_scratch_bytes(rows, n)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=ctrl.device)
+        _ffi.check(_ffi.lib().ddsp_hip_allpass_taps(ctrl.data_ptr(), n, rows, n, tab.data_ptr(), taps.data_ptr(),
+                                                    scratch.data_ptr(), nbytes, _ffi.stream_of(ctrl)))
+        are, aim = O.allpass_response(re[0])
+        ref = O.impulse_response(are[None], aim[None], O.MODE_ROLL)[0]
+        got[path, "ap"] = N_(taps).copy()
+        assert rms(got[path, "ap"] - ref) <= 3e-6 * rms(ref), path          # the response itself carries <= 2e-5 abs (hardware sin/cos)
+    for key in [k for k in got if k[0] == "pfa"]:
+        other = got[("gemm",) + key[1:]]
+        assert rms(got[key] - other) <= 1e-6 * rms(other), key
