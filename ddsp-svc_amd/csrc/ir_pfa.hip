@@ -134,24 +134,49 @@ __device__ __forceinline__ float cos_turns_w(float a) {
   return __builtin_amdgcn_cosf(r);
 }
 
-// LDS: rows re[16][256] (+ im[16][256] for complex kinds) alias the output staging O[16][510]; W[8][17][31] complex
-constexpr int IN_FLOATS = 2 * ROWS * NB;                                  // 8192 floats = 32 KB >= 16 * 510
-constexpr int W_WORDS = TR * 17 * WSTRIDE;                                // complex words
+// exp(x) on the hardware base-2 exponential: x log2(e) split into its float32 rounding and the residual (two-constant
+// log2 e), exp2(t) (1 + r ln 2): relative error ~1e-7 (stft.hip uses the same form)
+__device__ __forceinline__ float exp_hw(float x) {
+  const float l2e_hi = 1.44269502f, l2e_lo = 1.92596303e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147182f, e);
+}
+
+// a / b with one true division per ROW instead of one per tap: rb = RN(1 / b); q0 = a rb; e = a - q0 b (exact in fma);
+// q = q0 + e rb is the correctly rounded quotient except for ~1 argument pair in 10^6 (off by one ulp).  The only place
+// where an ulp matters is the window's one-sided clamp u > 1 (core.py:245: the factor jumps from 0 to 1 there), so
+// quotients within a few ulps of 1 take the true division.
+__device__ __forceinline__ float div_by_row(float a, float b, float rb) {
+  const float q0 = a * rb;
+  const float e = fmaf(-q0, b, a);
+  float q = fmaf(e, rb, q0);
+  if (fabsf(q - 1.0f) < 4e-7f) q = a / b;
+  return q;
+}
+
+// One LDS region, used three times: rows re[16][256] (+ im[16][256]) -> W[8][17][31] complex -> O[16][510]
+constexpr int W_WORDS = TR * 17 * WSTRIDE;                                // complex words: 33 728 B, the largest of the three
+constexpr int U_FLOATS = 2 * W_WORDS;
+static_assert(U_FLOATS >= 2 * ROWS * NB && U_FLOATS >= ROWS * NT, "union region too small");
 
 }  // namespace pfa
 
 template <int KIND, int ACT, int MODE>
-__global__ void __launch_bounds__(256, 2) k_taps_pfa510(const float* __restrict__ a_re, long ld_re,
+__global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict__ a_re, long ld_re,
                                                      const float* __restrict__ a_im, long ld_im, float scale,
                                                      const float* __restrict__ hann, const float* __restrict__ half_width,
                                                      float hw_sr, long rows, float* __restrict__ taps) {
   using namespace pfa;
-  __shared__ __attribute__((aligned(16))) float io[IN_FLOATS];
-  __shared__ __attribute__((aligned(16))) f32x2 W[W_WORDS];
+  __shared__ __attribute__((aligned(16))) float U[U_FLOATS];
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * ROWS;
-  float* re_s = io;
-  float* im_s = io + ROWS * NB;
+  float* re_s = U;
+  float* im_s = U + ROWS * NB;
+  f32x2* W = reinterpret_cast<f32x2*>(U);
+  float* O = U;
   const float inv_n = 1.0f / (float)NT;
 
   // ---- stage 0: rows -> LDS, activated and scaled by 1/N.  irfft drops Im(DC) and Im(Nyquist) (core.py:259) ----
@@ -160,31 +185,31 @@ __global__ void __launch_bounds__(256, 2) k_taps_pfa510(const float* __restrict_
     // bins; float64 scan reduced to revolutions before the float cosine / sine, as k_allpass_response (ir.hip)
     const int wave = tid >> 6, lane = tid & 63;
     const double inv_2pi = 0.15915494309189533577;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave * 4 + q;
-      const long gr = row0 + r;
-      float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                           // the four rows' loads are in flight together
+      const long gr = row0 + wave * 4 + q;
+      cv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < rows) {
         const float* src = a_re + gr * ld_re + 4 * lane;
-        cv.x = src[0]; cv.y = src[1]; cv.z = src[2]; cv.w = src[3];
+        cv[q].x = src[0]; cv[q].y = src[1]; cv[q].z = src[2]; cv[q].w = src[3];
       }
-      const float g0 = kPiF * tanhf(cv.x), g1 = kPiF * tanhf(cv.y), g2 = kPiF * tanhf(cv.z), g3 = kPiF * tanhf(cv.w);
-      const double local = (((double)g0 + (double)g1) + (double)g2) + (double)g3;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      const bool live = row0 + r < rows;
+      const float g[4] = {kPiF * tanhf(cv[q].x), kPiF * tanhf(cv[q].y), kPiF * tanhf(cv[q].z), kPiF * tanhf(cv[q].w)};
+      const double local = (((double)g[0] + (double)g[1]) + (double)g[2]) + (double)g[3];
       double run = wave_excl_scan(local, lane);
       float co[4], si[4];
-      const float g[4] = {g0, g1, g2, g3};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         run += (double)g[e];
         const double rev = run * inv_2pi;
         const float fr = (float)(rev - rint(rev));
-        co[e] = __builtin_amdgcn_cosf(fr) * inv_n;
-        si[e] = __builtin_amdgcn_sinf(fr) * inv_n;
-      }
-      if (gr >= rows) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) co[e] = si[e] = 0.f;
+        co[e] = live ? __builtin_amdgcn_cosf(fr) * inv_n : 0.f;
+        si[e] = live ? __builtin_amdgcn_sinf(fr) * inv_n : 0.f;
       }
       if (lane == 0) si[0] = 0.f;                       // Im(DC)
       if (lane == 63) si[3] = 0.f;                      // Im(Nyquist)
@@ -196,110 +221,135 @@ __global__ void __launch_bounds__(256, 2) k_taps_pfa510(const float* __restrict_
     const long gr = row0 + r;
     const bool live = gr < rows;
     const float sc = scale * inv_n;
+    float v[4][4], w[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {                           // all loads first
       const int k = c4 + 64 * q;
-      float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[q][e] = 0.f; w[q][e] = 0.f; }
       if (live) {
         const float* src = a_re + gr * ld_re + k;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = src[e];
+        for (int e = 0; e < 4; ++e) v[q][e] = src[e];
         if (KIND == KIND_COMPLEX) {
           const float* si = a_im + gr * ld_im + k;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = si[e];
+          for (int e = 0; e < 4; ++e) w[q][e] = si[e];
         }
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = c4 + 64 * q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = live ? (ACT == 1 ? expf(v[e]) * sc : v[e] * sc) : 0.f;
-        w[e] = live ? w[e] * sc : 0.f;
+        v[q][e] = live ? (ACT == 1 ? exp_hw(v[q][e]) * sc : v[q][e] * sc) : 0.f;
+        w[q][e] = live ? w[q][e] * sc : 0.f;
       }
       if (KIND == KIND_COMPLEX) {
-        if (k == 0) w[0] = 0.f;
-        if (k + 3 == NB - 1) w[3] = 0.f;
-        *reinterpret_cast<float4*>(im_s + r * NB + k) = make_float4(w[0], w[1], w[2], w[3]);
+        if (k == 0) w[q][0] = 0.f;
+        if (k + 3 == NB - 1) w[q][3] = 0.f;
+        *reinterpret_cast<float4*>(im_s + r * NB + k) = make_float4(w[q][0], w[q][1], w[q][2], w[q][3]);
       }
-      *reinterpret_cast<float4*>(re_s + r * NB + k) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(re_s + r * NB + k) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
     }
   }
   __syncthreads();
 
   // ---- stage A: DFT-17 over n1 of Z[(30 n1 + 17 n2) mod 510], Z = X_a + i X_b, X[510 - k] = conj X[k] ----
-  if (tid < TR * 30) {
-    const int t = tid / 30, n2 = tid - 30 * t;
-    const float* ra = re_s + (2 * t) * NB;
-    const float* rb = ra + NB;
-    const float* ia = im_s + (2 * t) * NB;
-    const float* ib = ia + NB;
+  {
+    const bool act = tid < TR * 30;
+    const int t = act ? tid / 30 : 0, n2 = act ? tid - 30 * t : 0;
     f32x2 z[17];
-    int k = 17 * n2;                                     // < 510
+    {
+      const float* ra = re_s + (2 * t) * NB;
+      const float* rb = ra + NB;
+      const float* ia = im_s + (2 * t) * NB;
+      const float* ib = ia + NB;
+      int k = 17 * n2;                                     // < 510
 #pragma unroll
-    for (int n1 = 0; n1 < 17; ++n1) {
-      const bool mir = k > HALF;
-      const int kk = mir ? NT - k : k;
-      if (KIND == KIND_REAL) {
-        z[n1] = f32x2{ra[kk], rb[kk]};
-      } else {
-        const float sg = mir ? -1.0f : 1.0f;
-        z[n1] = f32x2{fmaf(-sg, ib[kk], ra[kk]), fmaf(sg, ia[kk], rb[kk])};
+      for (int n1 = 0; n1 < 17; ++n1) {
+        const bool mir = k > HALF;
+        const int kk = mir ? NT - k : k;
+        if (KIND == KIND_REAL) {
+          z[n1] = f32x2{ra[kk], rb[kk]};
+        } else {
+          const float sg = mir ? -1.0f : 1.0f;
+          z[n1] = f32x2{fmaf(-sg, ib[kk], ra[kk]), fmaf(sg, ia[kk], rb[kk])};
+        }
+        k += 30;
+        if (k >= NT) k -= NT;
       }
-      k += 30;
-      if (k >= NT) k -= NT;
     }
-    dft17(z);
-    f32x2* dst = W + (t * 17) * WSTRIDE + n2;
+    __syncthreads();                                       // every thread holds its inputs: the rows may be overwritten
+    if (act) {
+      dft17(z);
+      f32x2* dst = W + (t * 17) * WSTRIDE + n2;
 #pragma unroll
-    for (int k1 = 0; k1 < 17; ++k1) dst[k1 * WSTRIDE] = z[k1];
+      for (int k1 = 0; k1 < 17; ++k1) dst[k1 * WSTRIDE] = z[k1];
+    }
   }
   __syncthreads();
 
   // ---- stage B: DFT-30 over n2; output index m = (120 k1 + 391 k2) mod 510; roll by N/2: tap j = (m + 255) mod 510 ----
-  float* O = io;                                          // [16][510], the rows staged above are dead
-  if (tid < TR * 17) {
-    const int t = tid / 17, k1 = tid - 17 * t;
-    const f32x2* src = W + (t * 17 + k1) * WSTRIDE;
+  {
+    const bool act = tid < TR * 17;
+    const int t = act ? tid / 17 : 0, k1 = act ? tid - 17 * t : 0;
     f32x2 v[30];
+    {
+      const f32x2* src = W + (t * 17 + k1) * WSTRIDE;
 #pragma unroll
-    for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
-    dft30(v);
-    float* oa = O + (2 * t) * NT;
-    float* ob = oa + NT;
-    const int base = (120 * k1 + HALF) % NT;
+      for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
+    }
+    __syncthreads();                                       // W is in registers: the region becomes the output staging
+    if (act) {
+      dft30(v);
+      float* oa = O + (2 * t) * NT;
+      float* ob = oa + NT;
+      const int base = (120 * k1 + HALF) % NT;
 #pragma unroll
-    for (int k2 = 0; k2 < 30; ++k2) {
-      int j = base + (391 * k2) % NT;                     // the second term is a compile-time constant
-      if (j >= NT) j -= NT;
-      oa[j] = v[k2].x;
-      ob[j] = v[k2].y;
+      for (int k2 = 0; k2 < 30; ++k2) {
+        int j = base + (391 * k2) % NT;                     // the second term is a compile-time constant
+        if (j >= NT) j -= NT;
+        oa[j] = v[k2].x;
+        ob[j] = v[k2].y;
+      }
     }
   }
   __syncthreads();
 
-  // ---- stage C: window and store; the batch's 16 x 510 taps are one contiguous, 16-byte aligned stretch ----
+  // ---- stage C: window and store; the batch's 16 x 510 taps are one contiguous, 16-byte aligned stretch.  A thread's
+  // groups of four are 1024 floats apart: row + 2, tap + 4 (mod 510) ----
   float* dst = taps + row0 * NT;
   const long total = rows * (long)NT - row0 * NT;         // floats left in the tensor from this batch on
+  int r = (4 * tid) / NT, j = 4 * tid - r * NT;
   for (int i4 = tid; i4 < ROWS * NT / 4; i4 += 256) {
     const int i = 4 * i4;
-    float4 o = *reinterpret_cast<const float4*>(O + i);
+    const float4 o = *reinterpret_cast<const float4*>(O + i);
     float ov[4] = {o.x, o.y, o.z, o.w};
-    if (MODE != MODE_ROLL) {
+    const bool wrap = j + 3 >= NT;                         // j is even: the group straddles a row end only at j = 508
+    if (MODE == MODE_HANN) {
+      const int j2 = wrap ? 0 : j + 2;
+      const float2 wa = *reinterpret_cast<const float2*>(hann + j);
+      const float2 wb = *reinterpret_cast<const float2*>(hann + j2);
+      ov[0] *= wa.x; ov[1] *= wa.y; ov[2] *= wb.x; ov[3] *= wb.y;
+    } else if (MODE == MODE_DYNAMIC) {
+      float hv[2], rb[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long gr = row0 + r + h;
+        float x = (gr < rows && (h == 0 || wrap)) ? half_width[gr] : 1.f;
+        if (hw_sr > 0.f) x = (1.5f * hw_sr) / (x + 1e-3f);               // vocoder.py:851, same float32 operations
+        hv[h] = x;
+        rb[h] = 1.0f / x;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int r = (i + e) / NT;
-        const int j = (i + e) - r * NT;
-        float w;
-        if (MODE == MODE_HANN) {
-          w = hann[j];
-        } else {
-          const long gr = row0 + r;
-          float hv = gr < rows ? half_width[gr] : 1.f;
-          if (hw_sr > 0.f) hv = (1.5f * hw_sr) / (hv + 1e-3f);        // vocoder.py:851, same float32 operations
-          float u = (float)(j - HALF) / hv;                            // core.py:244
-          if (u > 1.0f) u = 0.0f;                                      // core.py:245 -- only the upper side is clamped
-          w = (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                   // core.py:246
-        }
-        ov[e] *= w;
+        const bool nx = wrap && e >= 2;
+        const int je = nx ? e - 2 : j + e;
+        float u = div_by_row((float)(je - HALF), nx ? hv[1] : hv[0], nx ? rb[1] : rb[0]);     // core.py:244
+        if (u > 1.0f) u = 0.0f;                                          // core.py:245 -- only the upper side is clamped
+        ov[e] *= (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                  // core.py:246
       }
     }
     if (i + 3 < total) {
@@ -309,6 +359,8 @@ __global__ void __launch_bounds__(256, 2) k_taps_pfa510(const float* __restrict_
       for (int e = 0; e < 4; ++e)
         if (i + e < total) dst[i + e] = ov[e];
     }
+    j += 4; r += 2;
+    if (j >= NT) { j -= NT; r += 1; }
   }
 }
 

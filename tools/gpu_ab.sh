@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
 V=${V:-ab}
 timeout 900 python -m pytest tests/test_parity.py tests/test_baseline_shapes.py tests/test_core_api.py tests/test_fullsize_gpu.py tests/test_cascade_seam.py tests/test_sharding.py -m gpu -x -q 2>&1 | tail -5 | tee "$O/${V}_pytest_subset.log"
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for g in 0 1; do
     DDSP_HIP_TAPS_GEMM=$g timeout 300 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_combsub_gemm${g}_$rep.json"
     DDSP_HIP_ONE_STREAM=1 DDSP_HIP_TAPS_GEMM=$g timeout 300 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_combsub_gemm${g}_one_stream_$rep.json"
