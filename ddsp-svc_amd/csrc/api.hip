@@ -13,7 +13,7 @@ using namespace ddsp;
 namespace ddsp {
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
-                                            "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM"};
+                                            "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -78,13 +78,14 @@ struct Carver {
 struct SynthWs {
   float *buf0, *buf1, *taps, *re, *im, *harm;
   float *taps_nz, *nzbuf;      // the noise branch's own taps and output when it runs on a second stream
+  float *taps_h;               // the second harmonic filter's taps when they are synthesised ahead on the second stream
 };
 
-// Fork / join of the independent noise branch onto a caller-provided second stream.  The two events are created once
-// per host thread and device (the only thing this library ever creates) and re-used: a wait captures the record that
-// precedes it, so re-recording an event for the next call does not disturb waits already enqueued.
+// Fork / join of independent branches of a synthesiser tail onto a caller-provided second stream.  The events are
+// created once per host thread and device (the only thing this library ever creates) and re-used: a wait captures the
+// record that precedes it, so re-recording an event for the next call does not disturb waits already enqueued.
 struct BranchEvents {
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, mid[2] = {nullptr, nullptr};
 };
 
 struct Branch {
@@ -98,12 +99,13 @@ struct Branch {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
     BranchEvents& e = per_device[dev];
     if (!e.fork) {
-      if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) { e.fork = nullptr; return; }
-      if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipEventDestroy(e.fork);
-        e.fork = e.join = nullptr;
-        return;
-      }
+      hipEvent_t made[4] = {nullptr, nullptr, nullptr, nullptr};
+      for (int i = 0; i < 4; ++i)
+        if (hipEventCreateWithFlags(&made[i], hipEventDisableTiming) != hipSuccess) {
+          for (int j = 0; j < i; ++j) (void)hipEventDestroy(made[j]);
+          return;
+        }
+      e.fork = made[0]; e.join = made[1]; e.mid[0] = made[2]; e.mid[1] = made[3];
     }
     // everything enqueued on the main stream so far (the inputs' producers) precedes the branch
     if (hipEventRecord(e.fork, m) != hipSuccess) return;
@@ -111,6 +113,13 @@ struct Branch {
     ev = &e;
     aux = S(aux_stream);
     forked = true;
+  }
+  // a point of the branch the main stream waits for while the branch keeps running (i = 0, 1)
+  void publish(int i) {
+    if (forked) (void)hipEventRecord(ev->mid[i], aux);
+  }
+  void await(int i) {
+    if (forked) (void)hipStreamWaitEvent(main, ev->mid[i], 0);
   }
   // the main stream continues only after everything the branch enqueued
   void join() {
@@ -159,6 +168,7 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   w.harm = w.buf0;
   w.taps_nz = c.take<float>(R * N);
   w.nzbuf = c.take<float>(BT);
+  w.taps_h = c.take<float>(R * N);
   return align_up(c.used, 256);
 }
 
@@ -451,6 +461,49 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   hipStream_t st = S(stream);
   const long R = (long)B * F;
   Branch br(st, aux_stream);
+  // Stream layout of the two-stream call (knob STREAM_LAYOUT).  1 (default): the noise branch -- its taps and its filter --
+  // on the second stream beside the harmonic chain, joined into the last filter as its addend.  2 / 3 (every filter at
+  // 256 bins only; otherwise the all-pass response aliases the exciter buffer): ALL taps synthesised ahead on the second
+  // stream while the first makes the exciter, each filter waiting for its own taps only, with (2) or without (3) the
+  // noise filter itself on the second stream.  Same-box A/B at B = 32 x 10 s: 0.414 / 0.424 / 0.424 ms per step, one
+  // stream 0.428 (profiles/r02_v4_*): the prime-factor tap kernels are short enough that overlapping them buys less than
+  // running the whole noise branch beside the harmonic chain.
+  long layout = knob(KNOB_STREAM_LAYOUT);
+  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !knob(KNOB_TAPS_GEMM);
+  if (layout == 0 || !all256) layout = 1;
+  if (br.forked && layout >= 2) {
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
+    br.publish(0);
+    synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
+               w.taps_h, br.aux, (float)sr);
+    br.publish(1);
+    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
+               w.taps_nz, br.aux);
+    int rn = 0;
+    if (layout == 2) rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux);
+    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
+    int r1 = 0;
+    if (rc == 0) {
+      br.await(0);
+      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
+      br.await(1);
+    }
+    br.join();                                           // always joined, also on the error paths below
+    if (rc != 0) return DDSP_HIP_EHOP;
+    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
+    if (layout == 2) {                                   // signal = harmonic + noise: the second harmonic filter adds the branch's result
+      if (launch_fir(w.buf1, 0, w.taps_h, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+        return DDSP_HIP_ESHAPE;
+      return finish();
+    }
+    float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
+    if (launch_fir(w.buf1, 0, w.taps_h, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    if (launch_fir(noise, noise_is_u01, w.taps_nz, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
   if (br.forked) {
     // noise branch (vocoder.py:854-858) on the second stream, beside the harmonic chain
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;

@@ -135,6 +135,18 @@ __device__ __forceinline__ void dft8(f32x2* v) {
   v[1] = o0; v[3] = o1; v[5] = o2; v[7] = o3;
 }
 
+// the same when v[4..7] are known to be zero (a transform whose input is zero-padded to twice its length: the first
+// pass of a linear convolution): the first butterfly column degenerates to copies
+__device__ __forceinline__ void dft8_lo4(f32x2* v) {
+  const float H = 0.70710678118654752f;
+  f32x2 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+  f32x2 o0 = v[0], o1 = cmul(v[1], f32x2{H, -H}), o2 = v[2], o3 = cmul(v[3], f32x2{-H, -H});
+  dft4(e0, e1, e2, e3);
+  dft4_rot2(o0, o1, o2, o3);
+  v[0] = e0; v[2] = e1; v[4] = e2; v[6] = e3;
+  v[1] = o0; v[3] = o1; v[5] = o2; v[7] = o3;
+}
+
 // per-thread twiddles, computed once per workgroup lifetime (exact arguments: multiples of 2^-10)
 struct Twiddles {
   f32x2 w1[8];       // W_2048^(p k),   p = tid

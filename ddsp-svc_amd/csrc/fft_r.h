@@ -124,9 +124,12 @@ struct Plan {
   }
   // v[n1] = z[P n1 + tid] -> v[k3] = Z[s_index(tid, k3)].  X must be free of readers on entry; on return X is free
   // and Y may still be read by slower waves.
+  // HI_ZERO: v[4..7] are zero on entry (input zero-padded from 512 to 1024 points)
+  template <bool HI_ZERO = false>
   static __device__ __forceinline__ void forward_s(f32x2 (&v)[8], const Tw& tw, f32x2* X, f32x2* Y, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
-    dft8(v);
+    if (HI_ZERO) dft8_lo4(v);
+    else dft8(v);
 #pragma unroll
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
 #pragma unroll

@@ -23,6 +23,7 @@
 #include "fft_r.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace ddsp {
 
@@ -44,7 +45,6 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   using PL = fft::Plan<2>;
   constexpr int NF = PL::N, P = PL::P, S = 8;                  // 1024 points, 128 threads, 8 points per thread
   __shared__ __attribute__((aligned(16))) f32x2 ex[2][NF];
-  __shared__ float ring[NF];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -59,8 +59,12 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 
   typename PL::Tw tw;
   tw.init(tid);
+  // Overlap-add ring: 1024 samples, of which a thread only ever touches the 8 congruent to its id -- they live in
+  // registers.  Transform index n = 128 m + tid of block bb is time (bb - 1) hop + n, i.e. ring slot (4 (bb - 1) + m) mod 8:
+  // a pair advances the ring by exactly one revolution, so every slot index below is a compile-time constant.
+  float ring[S];
 #pragma unroll
-  for (int m = 0; m < S; ++m) ring[P * m + tid] = 0.f;
+  for (int m = 0; m < S; ++m) ring[m] = 0.f;
   int cur = 0;                                                 // ex[cur]: the exchange buffer no wave is reading any more
 
   // Global loads are issued unconditionally from clamped addresses and masked when they are USED: a load whose
@@ -99,10 +103,10 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   // mirrored read Z[-k].  ex[cur] is the buffer no wave reads any more; the mirror copy goes there as well (its
   // readers of the first pass are behind the second barrier), so afterwards the OTHER buffer is the free one.
   const int kS0 = PL::s_index(tid, 0);                          // bin of slot 0; slot m holds bin kS0 + 64 m
-  auto transform = [&](f32x2 (&z)[S]) -> f32x2* {
+  auto transform = [&](f32x2 (&z)[S], auto hi_zero) -> f32x2* {
     f32x2* X = ex[cur];
     f32x2* Y = ex[cur ^ 1];
-    PL::forward_s(z, tw, X, Y, tid);
+    PL::template forward_s<decltype(hi_zero)::value>(z, tw, X, Y, tid);
 #pragma unroll
     for (int m = 0; m < S; ++m) X[kS0 + 64 * m] = z[m];
     __syncthreads();
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     z[0] = z[1] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int m = 2; m < S; ++m) z[m] = f32x2{tap_at(ta, m), tap_at(tb2, m)};
-    const f32x2* Zn = transform(z);
+    const f32x2* Zn = transform(z, std::false_type{});
 #pragma unroll
     for (int m = 0; m < S; ++m) {
       const int k = kS0 + 64 * m;
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
       }
 #pragma unroll
       for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
-      const f32x2* Zn = transform(z);
+      const f32x2* Zn = transform(z, std::true_type{});          // the block fills the lower half of the transform
 #pragma unroll
       for (int m = 0; m < S; ++m) {
         const int k = kS0 + 64 * m;
@@ -207,16 +211,17 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     const bool interior = own && !last && (b0 - 1) * FB_HOP + 256 >= 0 && (b0 + 1) * FB_HOP + 256 <= g.T;   // uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int base = (b0 + h - 1) * FB_HOP;                   // time of transform index 0
+      const int base = (b0 + h - 1) * FB_HOP;                   // time of transform index 0; ring slot of index 128 m: (4 (h+1) + m) & 7
+      constexpr int kRot[2] = {4, 0};
 #pragma unroll
-      for (int m = 0; m < S; ++m) ring[(base + P * m + tid) & (NF - 1)] += h == 0 ? V[m].x : -V[m].y;
-      // times below (bb+1) hop - N/2 are final once block bb is in: emit [base + 256, base + 768); the last pair
-      // also flushes what is left
+      for (int m = 0; m < S; ++m) ring[(kRot[h] + m) & 7] += h == 0 ? V[m].x : -V[m].y;
+      // times below (bb+1) hop - N/2 are final once block bb is in: emit [base + 256, base + 768) = indices 128 (2 + m),
+      // m = 0..3; the last pair also flushes what is left
       if (interior) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int t = base + 256 + P * m + tid;
-          const int ri = t & (NF - 1);
+          const int ri = (kRot[h] + 2 + m) & 7;
           const float v = ring[ri];
           ring[ri] = 0.f;
           if (out_plain) out_plain[ob + t] = v;
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
         for (int m = 0; m < S; ++m) {
           if (m < n_emit) {
             const int t = base + 256 + P * m + tid;
-            const int ri = t & (NF - 1);
+            const int ri = (kRot[h] + 2 + m) & 7;
             const float v = ring[ri];
             ring[ri] = 0.f;
             if (own && t >= 0 && t < g.T) {
