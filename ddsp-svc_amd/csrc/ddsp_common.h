@@ -117,6 +117,28 @@ struct PhaseCfg {
   }
 };
 
+// A float32 array seen through a buffer descriptor (V#, 128-bit, in SGPRs): the address is base + byte offset, and the
+// hardware drops any access whose offset is not below the byte count -- a load returns 0, a store does nothing.  Edge
+// handling (positions before / after a row, an utterance, the last block) then costs no compares, selects or exec-mask
+// branches, and the per-lane address is one 32-bit VGPR plus an instruction immediate.  Rules kept by the callers: the
+// descriptor is built from wave-uniform values only, and a byte offset is either non-negative (immediates may then be
+// folded onto it) or the constant kOutOfRange with no immediate on top.
+struct BufF32 {
+  __amdgpu_buffer_rsrc_t r;
+  static constexpr int kOutOfRange = 0x40000000;
+  static __device__ __forceinline__ BufF32 make(const float* base, int n_floats) {
+    BufF32 b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_floats > 0 ? n_floats * 4 : 0, 0x00020000);
+    return b;
+  }
+  __device__ __forceinline__ float ld(int byte_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+  }
+  __device__ __forceinline__ void st(float v, int byte_off) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 0);
+  }
+};
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);

@@ -117,8 +117,9 @@ struct Plan {
     const float sgn = (tid & 1) ? -1.0f : 1.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float px = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k].x), 0xB1, 0xF, 0xF, false));
-      const float py = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k].y), 0xB1, 0xF, 0xF, false));
+      // mov_dpp (no "old" operand: every lane of a quad_perm has a valid source, so the destination needs no initial value)
+      const float px = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[k].x), 0xB1, 0xF, 0xF, true));
+      const float py = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[k].y), 0xB1, 0xF, 0xF, true));
       v[k] = f32x2{fmaf(sgn, v[k].x, px), fmaf(sgn, v[k].y, py)};        // quad_perm [1,0,3,2]: the neighbour's value
     }
   }

@@ -52,10 +52,18 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   int q_last = q_first + g.run;
   if (q_last > g.pairs) q_last = g.pairs;
   const int SH = FB_HOP - (g.N >> 1);                          // circular tap shift
-  const float* xb = x + (long)b * g.T;
-  const float* tb = taps + (long)b * g.F * g.N;
-  const long ob = (long)b * g.T;
+  // Every global access goes through a buffer descriptor whose byte count bounds it (BufF32, ddsp_common.h): positions
+  // outside a tap row, blocks beyond the utterance and output times outside [0, T) are dropped by the address unit, so the
+  // loop carries no clamps, selects or exec-mask branches for them.  Descriptors are built from workgroup-uniform values.
+  const int bu = __builtin_amdgcn_readfirstlane(b);
+  const float* xb = x + (long)bu * g.T;
+  const float* tb = taps + (long)bu * g.F * g.N;
+  const long ob = (long)bu * g.T;
+  const BufF32 out_buf = BufF32::make(out + ob, g.T);
+  const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
+  const BufF32 add_buf = BufF32::make(addend ? addend + ob : out + ob, addend ? g.T : 0);
   const float inv_hop = 1.0f / (float)FB_HOP;
+  const int tid4 = 4 * tid;
 
   typename PL::Tw tw;
   tw.init(tid);
@@ -67,35 +75,32 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   for (int m = 0; m < S; ++m) ring[m] = 0.f;
   int cur = 0;                                                 // ex[cur]: the exchange buffer no wave is reading any more
 
-  // Global loads are issued unconditionally from clamped addresses and masked when they are USED: a load whose
-  // result feeds a select or the 2u-1 map right away would be waited for on the spot instead of staying in flight
-  // across the transforms (and a predicated load costs an exec-mask branch).
+  // Global loads are issued at the top of a pair for the NEXT pair and stay in flight across the transforms.
   // One tap row, shifted: the value at transform index n = 128 m + tid is taps[row][n - SH]; only m >= 2 can be live.
+  // The six byte offsets are loop invariants; a position before the row start gets the out-of-range constant (a
+  // position beyond the row end is out of range by itself: the descriptor spans exactly one row).
   struct TapRow { float v[6]; };
+  int tap_off[6];
+#pragma unroll
+  for (int m = 2; m < S; ++m) {
+    const int i = P * m + tid - SH;
+    tap_off[m - 2] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+  }
   auto load_taps = [&](int j) -> TapRow {
     TapRow r;
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
-    const float* tr = tb + (long)row * g.N;
+    const BufF32 tr = BufF32::make(tb + (long)row * g.N, g.N);
 #pragma unroll
-    for (int m = 2; m < S; ++m) {
-      int i = P * m + tid - SH;
-      i = i < 0 ? 0 : (i >= g.N ? g.N - 1 : i);
-      r.v[m - 2] = tr[i];
-    }
+    for (int m = 2; m < S; ++m) r.v[m - 2] = tr.ld(tap_off[m - 2]);
     return r;
   };
-  auto tap_at = [&](const TapRow& r, int m) -> float {          // m >= 2
-    const int i = P * m + tid - SH;
-    return (i >= 0 && i < g.N) ? r.v[m - 2] : 0.f;
-  };
-  // one hop block of the input: 4 samples per thread (s = 128 m + tid); blocks beyond the utterance read block F-1
-  // and are zeroed at use
+  // one hop block of the input: 4 samples per thread (s = 128 m + tid); a block beyond the utterance reads zeros
   struct Blk { float v[4]; };
   auto load_blk = [&](int bi) -> Blk {
     Blk r;
-    const float* src = xb + (long)(bi < g.F ? bi : g.F - 1) * FB_HOP + tid;
+    const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F ? FB_HOP : 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) r.v[m] = src[P * m];
+    for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
     return r;
   };
   // FFT of a packed pair (real + i imaginary) into the scrambled layout S of fft_r.h (two LDS exchanges; every
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     f32x2 z[S];
     z[0] = z[1] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int m = 2; m < S; ++m) z[m] = f32x2{tap_at(ta, m), tap_at(tb2, m)};
+    for (int m = 2; m < S; ++m) z[m] = f32x2{ta.v[m - 2], tb2.v[m - 2]};
     const f32x2* Zn = transform(z, std::false_type{});
 #pragma unroll
     for (int m = 0; m < S; ++m) {
@@ -166,8 +171,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         float xv = cx.v[m];
-        if (x_is_u01) xv = fmaf(2.0f, xv, -1.0f);               // noise = rand*2-1 (vocoder.py:603,854)
-        if (!live) xv = 0.f;
+        if (x_is_u01 && live) xv = fmaf(2.0f, xv, -1.0f);       // noise = rand*2-1 (vocoder.py:603,854); uniform condition
         const float lam = (float)(P * m + tid) * inv_hop;
         z[m] = f32x2{(1.0f - lam) * xv, lam * xv};               // the two Bartlett halves (core.py:161)
       }
@@ -188,66 +192,56 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
         else V[m] = fft::conj_minus_i_conj(V[m], y);
       }
     }
-    // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform
+    // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform.  Emitted times
+    // of this thread: t = e0 + 128 i, i = 0..7.  From the second pair of an utterance on e0 >= 0, so the byte offset is
+    // 4 e0 plus an instruction immediate; the first pair (e0 < 0 for some lanes) forms every offset in full.
     const bool own = q >= q_first;
     const int e0 = (b0 - 1) * FB_HOP + 256 + tid;               // first emitted time of this thread
+    auto t_off = [&](int i) -> int {
+      if (b0 > 0) return 4 * e0 + 4 * P * i;
+      const int t = e0 + P * i;
+      return t >= 0 ? 4 * t : BufF32::kOutOfRange;
+    };
     float add[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) add[i] = 0.f;
-    if (addend) {                                               // uniform; clamped addresses, masked by the store
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        int t = e0 + P * i;
-        t = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
-        add[i] = addend[ob + t];
-      }
-    }
+    for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));   // 0 without an addend (empty descriptor)
     // back to time order: the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid.
     // No barrier follows (the overlap-add ring is thread-private): its second buffer may still be read by the slower
     // wave, its first -- ex[cur] -- is free again, which is what the next transform expects
     PL::transposed(V, tw, ex[cur], ex[cur ^ 1], tid);
     // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb-1) hop + n.
     const bool last = q == g.pairs - 1;
-    const bool interior = own && !last && (b0 - 1) * FB_HOP + 256 >= 0 && (b0 + 1) * FB_HOP + 256 <= g.T;   // uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int base = (b0 + h - 1) * FB_HOP;                   // time of transform index 0; ring slot of index 128 m: (4 (h+1) + m) & 7
-      constexpr int kRot[2] = {4, 0};
+      constexpr int kRot[2] = {4, 0};                           // ring slot of transform index 128 m: (4 (h+1) + m) & 7
 #pragma unroll
       for (int m = 0; m < S; ++m) ring[(kRot[h] + m) & 7] += h == 0 ? V[m].x : -V[m].y;
-      // times below (bb+1) hop - N/2 are final once block bb is in: emit [base + 256, base + 768) = indices 128 (2 + m),
-      // m = 0..3; the last pair also flushes what is left
-      if (interior) {
+      // times below (bb+1) hop - N/2 are final once block bb is in: emit indices 128 (2 + m), m = 0..3, i.e. emitted
+      // sample i = 4 h + m of the pair; stores outside [0, T) are dropped by the descriptor
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int t = base + 256 + P * m + tid;
-          const int ri = (kRot[h] + 2 + m) & 7;
-          const float v = ring[ri];
-          ring[ri] = 0.f;
-          if (out_plain) out_plain[ob + t] = v;
-          out[ob + t] = v + add[4 * h + m];
-        }
-      } else {
-        const int n_emit = (last && h == 1) ? 8 : 4;
-#pragma unroll
-        for (int m = 0; m < S; ++m) {
-          if (m < n_emit) {
-            const int t = base + 256 + P * m + tid;
-            const int ri = (kRot[h] + 2 + m) & 7;
-            const float v = ring[ri];
-            ring[ri] = 0.f;
-            if (own && t >= 0 && t < g.T) {
-              if (out_plain) out_plain[ob + t] = v;
-              float a = 0.f;
-              if (m < 4) a = add[4 * h + m];                    // t == e0 + 128 (4 h + m)
-              else if (addend) a = addend[ob + t];              // the flush of the last pair
-              out[ob + t] = v + a;
-            }
-          }
+      for (int m = 0; m < 4; ++m) {
+        const int ri = (kRot[h] + 2 + m) & 7;
+        const float v = ring[ri];
+        ring[ri] = 0.f;
+        if (own) {
+          const int off = t_off(4 * h + m);
+          plain_buf.st(v, off);                                  // empty descriptor unless out_plain was asked for
+          out_buf.st(v + add[4 * h + m], off);
         }
       }
     }
-    // hand the spectrum of tap row b0 + 2 to the next pair
+    if (last && own) {                                          // the last pair also flushes what is left of the ring
+#pragma unroll
+      for (int m = 4; m < S; ++m) {
+        const int ri = (2 + m) & 7;
+        const int off = t_off(4 + m);                           // t = (b0 + 1 - 1) hop + 256 + 128 m + tid
+        const float v = ring[ri];
+        plain_buf.st(v, off);
+        out_buf.st(v + add_buf.ld(off), off);
+      }
+    }
+    // hand the spectrum of tap row b0 + 2 to the next pair (unrolling the loop by two with swapped roles instead of these
+    // 16 moves needs 256 registers and spills 9)
 #pragma unroll
     for (int m = 0; m < S; ++m) Gc[m] = Gb[m];
   }

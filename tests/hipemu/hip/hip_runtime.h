@@ -169,6 +169,9 @@ static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, 
   else { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
   return hipemu::peek<int>(s, from);
 }
+static inline int __builtin_amdgcn_mov_dpp(int src, int ctrl, int rm, int bm, bool bc) {
+  return __builtin_amdgcn_update_dpp(0, src, ctrl, rm, bm, bc);
+}
 static inline int __builtin_amdgcn_readlane(int v, int lane) {
   auto s = hipemu::exchange(v);
   return hipemu::peek<int>(s, lane);
@@ -231,6 +234,24 @@ static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; retu
 static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
 static inline double __fma_rn(double a, double b, double c) { return fma(a, b, c); }
+// buffer descriptors (raw, stride 0): base + byte count; out-of-range loads return 0, out-of-range stores are dropped
+struct hipemu_rsrc { char* base; unsigned bytes; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+static inline hipemu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+  return hipemu_rsrc{static_cast<char*>(p), bytes > 0 ? (unsigned)bytes : 0u};
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int voff, int soff, int) {
+  const unsigned long long o = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  if (o + 4 > r.bytes) return 0u;
+  unsigned v;
+  memcpy(&v, r.base + o, 4);
+  return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, hipemu_rsrc r, int voff, int soff, int) {
+  const unsigned long long o = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  if (o + 4 > r.bytes) return;
+  memcpy(r.base + o, &v, 4);
+}
 static inline float __builtin_amdgcn_sinf(float turns) { return (float)sin(2.0 * M_PI * (double)turns); }   // v_sin_f32
 static inline float __builtin_amdgcn_cosf(float turns) { return (float)cos(2.0 * M_PI * (double)turns); }   // v_cos_f32
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }                                            // v_rcp_f32
