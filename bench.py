@@ -115,9 +115,9 @@ def _cpu_worker(args):
     return float(_np.abs(r["signal"]).max())
 
 
-def hbm_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC summary (tools/gpu_traffic.sh: separate
-    FETCH_SIZE / WRITE_SIZE passes over this same workload, gfx950 read correction applied), or None."""
+def hbm_traffic(kernel, model=None):
+    """HBM bytes per launch of ``kernel`` from the newest committed PMC summary of ``model``'s step (tools/gpu_traffic.sh:
+    separate FETCH_SIZE / WRITE_SIZE passes over this same workload, gfx950 read correction applied), or None."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     def version(name):                                   # r01_v10_... after r01_v9_...: numeric, not lexicographic
@@ -128,6 +128,8 @@ def hbm_traffic(kernel):
             try:
                 d = json.load(open(os.path.join(pdir, name)))
             except Exception:
+                continue
+            if model is not None and d.get("__step__", {}).get("model", model) != model:
                 continue
             for k, v in d.items():
                 if k.startswith(kernel):
@@ -183,7 +185,7 @@ def step_traffic(model):
     return best
 
 
-def cpu_baseline_aten_chain(kind, F, sizes, budget_s=12.0):
+def cpu_baseline_aten_chain(kind, F, sizes, budget_s=14.0):
     """The reference's op chain (F.interpolate, float64 cumsum, rfft / irfft at 2 hop + N - 1 points, fold) walked with
     torch CPU operators on this host (oracle/aten_chain.py, pinned to the reference's fixtures): what the reference's DSP
     tail costs here, without the reference checkout.  BASELINE.md section 3 prescribes ``torch.set_num_threads(os.cpu_count())``;
@@ -210,7 +212,7 @@ def cpu_baseline_aten_chain(kind, F, sizes, budget_s=12.0):
     sweep = {}
     t_start = time.perf_counter()
     try:
-        for threads in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
+        for threads in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}):      # the small pools first: they are the fast ones
             if time.perf_counter() - t_start > budget_s and sweep:
                 break
             torch.set_num_threads(threads)
@@ -221,6 +223,7 @@ def cpu_baseline_aten_chain(kind, F, sizes, budget_s=12.0):
     best = max(sweep, key=sweep.get)
     return {"value": sweep[best], "unit": "samples/s", "cores": cores, "kind": "aten-chain", "threads": best,
             "thread_sweep": {str(k): v for k, v in sweep.items()},
+            "prescribed_threads_timed": cores in sweep,
             "sample": "best of 2 runs of B=%d x %d frames (%.1f s audio each) through the reference's op chain with torch %s "
                       "CPU operators, per intra-op pool size; %.1f s wall in total" %
                       (batch, F, F * HOP / SR, torch.__version__, time.perf_counter() - t_start)}
@@ -839,7 +842,7 @@ def main():
     fir_launches = 3 if a.model == "combsub" else 2
     fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
     kname = {4: "k_fir_fft", 5: "k_fir_blk"}.get(used_impl, "k_fir_mfma")
-    traffic = hbm_traffic(kname) if (B, F, n) == (32, 862, 256) else None
+    traffic = hbm_traffic(kname, a.model) if (B, F, n) == (32, 862, 256) else None
     # arithmetic the FFT forms actually execute (5 N log2 N per complex transform + spectral products): per frame pair
     # three 2048-point transforms (k_fir_fft) or per hop-block pair four 1024-point ones (k_fir_blk)
     if used_impl == 5:
