@@ -155,6 +155,46 @@ struct Plan {
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
     lane_pair_dft2(v, tid);
   }
+  // Two independent transforms in lockstep (u through X0 / Y0, v through X1 / Y1): the same passes as forward_s, but
+  // each barrier serves both, and between two barriers a wave has the other transform's arithmetic to issue while one
+  // transform's LDS round trip is in flight -- half the barriers, twice the independent work per interval.
+  template <bool HI_ZERO = false>
+  static __device__ __forceinline__ void forward_s2(f32x2 (&u)[8], f32x2 (&v)[8], const Tw& tw, f32x2* X0, f32x2* Y0,
+                                                    f32x2* X1, f32x2* Y1, int tid) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    if (HI_ZERO) { dft8_lo4(u); dft8_lo4(v); }
+    else { dft8(u); dft8(v); }
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w1[k]); v[k] = cmul(v[k], tw.w1[k]); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { X0[k * P + tid] = u[k]; X1[k * P + tid] = v[k]; }
+    __syncthreads();
+    {
+      const int k1 = tid / C, c = tid & (C - 1);
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) { u[n2] = X0[k1 * P + n2 * C + c]; v[n2] = X1[k1 * P + n2 * C + c]; }
+      dft8(u);
+      dft8(v);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w2[k]); v[k] = cmul(v[k], tw.w2[k]); }
+      const int n3 = c / R, n4 = c & (R - 1);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const int a = n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R));
+        Y0[a] = u[k2];
+        Y1[a] = v[k2];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) { u[n3] = Y0[n3 * P + (tid ^ (n3 * R))]; v[n3] = Y1[n3 * P + (tid ^ (n3 * R))]; }
+    dft8(u);
+    dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w3[k]); v[k] = cmul(v[k], tw.w3[k]); }
+    lane_pair_dft2(u, tid);
+    lane_pair_dft2(v, tid);
+  }
   // v[k3] = Z[s_index(tid, k3)] -> v[m] = sum_k Z[k] W_N^(k (P m + tid)).  Y must be free of readers on entry; X
   // becomes free at the first barrier (its last readers are whoever used it before this call); on return Y is
   // free and X may still be read by slower waves.

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
                                                      float* __restrict__ out_plain, FirBlkGeom g) {
   using PL = fft::Plan<2>;
   constexpr int NF = PL::N, P = PL::P, S = 8;                  // 1024 points, 128 threads, 8 points per thread
-  __shared__ __attribute__((aligned(16))) f32x2 ex[2][NF];
+  __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];   // two ping-pong pairs: ex[0..1] every transform, ex[2..3] the second of a lockstep pair
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -162,12 +162,14 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     f32x2 Ga[S], Gb[S];
     split_taps(ct1, ct2, Ga, Gb);                               // H_b0+1, H_b0+2
 
-    f32x2 V[S];
+    // The two block transforms of the pair run in lockstep (Plan::forward_s2): one set of barriers for both, and each
+    // wave has the other block's butterflies to issue while one block's LDS round trip is in flight.
+    f32x2 z0[S], z1[S];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const Blk& cx = h == 0 ? cx0 : cx1;
       const bool live = b0 + h < g.F;
-      f32x2 z[S];
+      f32x2 (&z)[S] = h == 0 ? z0 : z1;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         float xv = cx.v[m];
@@ -177,20 +179,24 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
       }
 #pragma unroll
       for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
-      const f32x2* Zn = transform(z, std::true_type{});          // the block fills the lower half of the transform
+    }
+    f32x2* const Xa = ex[cur];
+    f32x2* const Xb = ex[2 + cur];
+    PL::template forward_s2<true>(z0, z1, tw, Xa, ex[cur ^ 1], Xb, ex[2 + (cur ^ 1)], tid);
 #pragma unroll
-      for (int m = 0; m < S; ++m) {
-        const int k = kS0 + 64 * m;
-        const f32x2 zneg = Zn[(NF - k) & (NF - 1)];
-        const f32x2 p = fft::add_conj(z[m], zneg);              // 2 X1
-        const f32x2 d = fft::sub_conj(z[m], zneg);              // 2i X2
-        // Y = X1 H_b + X2 H_b+1 = p G_b - i d G_b+1
-        const f32x2 y = h == 0 ? fft::add_mi(cmul(p, Gc[m]), cmul(d, Ga[m]))
-                               : fft::add_mi(cmul(p, Ga[m]), cmul(d, Gb[m]));
-        // V = Y_b0 + i Y_b0+1, conjugated for the inverse-by-forward trick
-        if (h == 0) V[m] = y;
-        else V[m] = fft::conj_minus_i_conj(V[m], y);
-      }
+    for (int m = 0; m < S; ++m) { Xa[kS0 + 64 * m] = z0[m]; Xb[kS0 + 64 * m] = z1[m]; }
+    __syncthreads();
+    cur ^= 1;
+    f32x2 V[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const int k = kS0 + 64 * m;
+      const int kn = (NF - k) & (NF - 1);
+      // Y = X1 H_b + X2 H_b+1 = p G_b - i d G_b+1 with p = 2 X1, d = 2i X2 from the packed block transform
+      const f32x2 za = Xa[kn], zb = Xb[kn];
+      const f32x2 y0 = fft::add_mi(cmul(fft::add_conj(z0[m], za), Gc[m]), cmul(fft::sub_conj(z0[m], za), Ga[m]));
+      const f32x2 y1 = fft::add_mi(cmul(fft::add_conj(z1[m], zb), Ga[m]), cmul(fft::sub_conj(z1[m], zb), Gb[m]));
+      V[m] = fft::conj_minus_i_conj(y0, y1);                    // V = Y_b0 + i Y_b0+1, conjugated for the inverse-by-forward trick
     }
     // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform.  Emitted times
     // of this thread: t = e0 + 128 i, i = 0..7.  From the second pair of an utterance on e0 >= 0, so the byte offset is
