@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 // returns the implementation id (5) or < 0 when the shape is outside this kernel
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st) {
-  if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 30)) return -1;
+  if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 29)) return -1;   // byte offsets of one utterance stay below 2^31 (buffer descriptors)
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 1) / 2;

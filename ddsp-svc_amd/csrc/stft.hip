@@ -182,7 +182,11 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   constexpr int OVL = N / ST_HOP;                              // frames overlapping one sample
   constexpr int WARM = (OVL - 1 + 1) / 2;                      // warm-up pairs: OVL - 1 earlier frames reach in
   __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];       // ping-pong exchange buffers; roles swap per transform
-  __shared__ float ring[N];
+  // Overlap-add ring of `win` samples: a thread only ever touches the 8 slots congruent to its id, so they live in
+  // registers.  Frame j's sample P m + tid is slot (aj / P + m) mod 8 with aj = j hop - win/2: a frame pair advances the
+  // ring by 1024 samples = 8 slots for win 1024 (every index a compile-time constant) and 4 slots for win 2048 (the two
+  // halves of the register array are swapped after every pair instead).
+  float ring[S];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -199,13 +203,18 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
 #pragma unroll
   for (int m = 0; m < S; ++m) {
     w[m] = window[P * m + tid];
-    ring[P * m + tid] = 0.f;
+    ring[m] = 0.f;
   }
   const float cs = 0.5f / (float)N;                            // E = (..)/2, U = (..)/2i and the 1/N of the inverse
   const float cn = cs * g.noise_scale;
   int cur = 0;                                                 // ex[cur] plays "A" of the next transform
 
   const int pr0 = p_first > WARM ? p_first - WARM : 0;
+  // slot of sample index 0 of the pair's first frame, as seen by the register array: aj / P = (2 pr hop - win/2) / P.
+  // win 1024: 8 pr - 4 -> 4 for every pair.  win 2048: 4 pr - 4 -> 4 or 0; the array is kept rotated so that it is 4
+  // at the top of every pair (an odd first pair starts rotated).
+  constexpr int BASE = 4;
+  constexpr int STEP = ST_HOP / P;                             // slots between the two frames of a pair
   for (int pr = pr0; pr < p_last; ++pr) {
     f32x2 V[S];
 #pragma unroll
@@ -331,7 +340,7 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
 #pragma unroll
       for (int m = 0; m < S; ++m) {
         const float y = h == 0 ? V[m].x : -V[m].y;
-        ring[(aj + P * m + tid) & (N - 1)] += y * w[m];
+        ring[(BASE + h * STEP + m) & 7] += y * w[m];
       }
       // samples [aj, aj + hop) have now seen every frame that reaches them; the last pair flushes the rest
       const int n_emit = (pr == g.pairs - 1 && h == 1) ? S : EMIT;
@@ -339,7 +348,7 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
       for (int m = 0; m < S; ++m) {
         if (m < n_emit) {
           const int t = aj + P * m + tid;
-          const int ri = t & (N - 1);
+          const int ri = (BASE + h * STEP + m) & 7;
           float v = ring[ri];
           ring[ri] = 0.f;
           if (own && t >= 0 && t < g.T) {
@@ -358,6 +367,10 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
           }
         }
       }
+    }
+    if (R == 4) {                                              // win 2048: the next pair's first frame starts 4 slots further on
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { const float tmp = ring[m]; ring[m] = ring[m + 4]; ring[m + 4] = tmp; }
     }
   }
 }
