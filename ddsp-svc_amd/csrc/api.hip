@@ -408,11 +408,15 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (br.forked) {
     // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+    // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
+    // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
+    const bool ap_ahead = n_ap == 256 && !knob(KNOB_TAPS_GEMM) && knob(KNOB_STREAM_LAYOUT) != 1;
+    if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
     synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
                n_nz, w.taps_nz, br.aux);
     const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
                               br.aux);
-    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
+    if (!ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
     br.join();                                           // always joined, also on the error paths below
     if (r == -1) return DDSP_HIP_EHOP;
@@ -461,16 +465,50 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   hipStream_t st = S(stream);
   const long R = (long)B * F;
   Branch br(st, aux_stream);
-  // Stream layout of the two-stream call (knob STREAM_LAYOUT).  1 (default): the noise branch -- its taps and its filter --
-  // on the second stream beside the harmonic chain, joined into the last filter as its addend.  2 / 3 (every filter at
-  // 256 bins only; otherwise the all-pass response aliases the exciter buffer): ALL taps synthesised ahead on the second
-  // stream while the first makes the exciter, each filter waiting for its own taps only, with (2) or without (3) the
-  // noise filter itself on the second stream.  Same-box A/B at B = 32 x 10 s: 0.414 / 0.424 / 0.424 ms per step, one
-  // stream 0.428 (profiles/r02_v4_*): the prime-factor tap kernels are short enough that overlapping them buys less than
-  // running the whole noise branch beside the harmonic chain.
+  // Stream layout of the two-stream call (knob STREAM_LAYOUT; 2-5 need every filter at 256 bins, otherwise the all-pass
+  // response aliases the exciter buffer and 1 is used).  1: the noise branch -- its taps and its filter -- on the second
+  // stream beside the harmonic chain, joined into the last filter as its addend.  4 (default): as 1 with the exciter on the
+  // second stream too, ahead of the noise branch, so the (vector-ALU bound) exciter overlaps the (latency bound) all-pass tap
+  // synthesis instead of following it.  5: + the second harmonic filter's taps there.  2 / 3: ALL taps ahead on the second
+  // stream while the first makes the exciter, with / without the noise filter itself on the second stream.
+  // Same-box A/Bs at B = 32 x 10 s, ms per step: 1 / 2 / 3 / one stream 0.414 / 0.424 / 0.424 / 0.428 (profiles/r02_v4_*);
+  // 1 / 4 / 5 0.401 / 0.388 / 0.403 (profiles/r02_v14_*).
   long layout = knob(KNOB_STREAM_LAYOUT);
   const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !knob(KNOB_TAPS_GEMM);
-  if (layout == 0 || !all256) layout = 1;
+  if (layout == 0) layout = 4;
+  if (!all256) layout = 1;
+  if (br.forked && (layout == 4 || layout == 5)) {
+    // 4: as 1, but the exciter is made on the second stream as well (ahead of the noise branch), so it overlaps the
+    // all-pass tap synthesis on the first stream instead of following it.  5: the second harmonic filter's taps too.
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, br.aux);
+    br.publish(0);
+    float* th = w.taps;
+    if (layout == 5) {
+      th = w.taps_h;
+      synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
+                 th, br.aux, (float)sr);
+      br.publish(1);
+    }
+    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
+               w.taps_nz, br.aux);
+    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux);
+    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
+    br.await(0);
+    int r1 = 0;
+    if (rc == 0) {
+      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
+      if (layout == 4)
+        synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
+                   n_harm, th, st, (float)sr);
+    }
+    br.join();
+    if (rc != 0) return DDSP_HIP_EHOP;
+    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
+    if (launch_fir(w.buf1, 0, th, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
   if (br.forked && layout >= 2) {
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
     synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);

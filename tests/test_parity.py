@@ -379,8 +379,8 @@ def test_combsub_tail_golden(dev, golden_dir, name, infer):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("name,layout", [("sins_h128.npz", 0), ("combsub_128.npz", 0), ("combsub_256.npz", 1), ("combsub_256.npz", 2),
-                                         ("combsub_256.npz", 3)])
+@pytest.mark.parametrize("name,layout", [("sins_h128.npz", 0), ("sins_h128.npz", 1), ("sins_h256.npz", 0), ("combsub_128.npz", 0), ("combsub_256.npz", 0), ("combsub_256.npz", 1), ("combsub_256.npz", 2),
+                                         ("combsub_256.npz", 3), ("combsub_256.npz", 4), ("combsub_256.npz", 5)])
 @pytest.mark.parametrize("want_components", [True, False])
 def test_tail_second_stream(dev, golden_dir, name, layout, want_components, monkeypatch, knobs):
     """the noise branch forked onto a second stream (include/ddsp_hip.h, aux_stream): bit-identical to the one-stream
