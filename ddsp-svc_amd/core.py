@@ -5,6 +5,7 @@ Reference lines are cited per function.  All tensors must be float32 (complex64 
 on the GPU; errors mirror the reference (``ValueError`` on batch mismatch / bad padding).
 """
 import math
+import threading
 
 import torch
 
@@ -12,6 +13,7 @@ from . import _ffi
 from ._ffi import ptr
 
 _TABLES = {}
+_TABLE_LOCK = threading.Lock()
 
 
 def _f32c(t):
@@ -21,16 +23,23 @@ def _f32c(t):
 
 
 def ir_table(n_mag, device):
-    """Cosine/sine/Hann basis for ``n_mag`` bins, built once per (device, n_mag) on the GPU."""
+    """Cosine/sine/Hann basis for ``n_mag`` bins, built once per (device, n_mag) on the GPU and kept for the life of the
+    process.  Built under a lock and followed by a synchronisation of the building stream (one-time cost), so that callers
+    on other host threads / streams never see a half-built or replaced table."""
     key = (str(device), int(n_mag))
     tab = _TABLES.get(key)
     if tab is None:
         L = _ffi.lib()
-        nbytes = L.ddsp_hip_ir_table_bytes(int(n_mag))
-        tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        _ffi.check_device(tab)
-        _ffi.check(L.ddsp_hip_ir_table(int(n_mag), ptr(tab), _ffi.stream_of(tab)))
-        _TABLES[key] = tab
+        with _TABLE_LOCK:
+            tab = _TABLES.get(key)
+            if tab is None:
+                nbytes = L.ddsp_hip_ir_table_bytes(int(n_mag))
+                tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+                _ffi.check_device(tab)
+                _ffi.check(L.ddsp_hip_ir_table(int(n_mag), ptr(tab), _ffi.stream_of(tab)))
+                if tab.is_cuda:
+                    torch.cuda.current_stream(tab.device).synchronize()
+                _TABLES[key] = tab
     return tab
 
 
