@@ -261,10 +261,22 @@ def module_mode(kind, B, F, n, device, steps, warmup):
             m.unit2ctrl(units, f0, ph, vol)
         ev[3].record()
         torch.cuda.synchronize()
-    assert torch.isfinite(out).all()
+        # the same with the noise drawn inside the noise filter instead of a torch.rand tensor (opt-in, in_kernel_noise_seed)
+        m.in_kernel_noise_seed = 1234
+        for _ in range(warmup):
+            out2 = m(units, f0, vol)[0]
+        torch.cuda.synchronize()
+        e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e4.record()
+        for _ in range(steps):
+            out2 = m(units, f0, vol)[0]
+        e5.record()
+        torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(out2).all()
     ms = ev[0].elapsed_time(ev[1]) / steps
     return {"value": B * F * HOP / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms,
             "unit2ctrl_ms": ev[2].elapsed_time(ev[3]) / steps,
+            "ms_per_step_in_kernel_noise": e4.elapsed_time(e5) / steps,
             "note": "drop-in %s module forward (HOT-1 + stand-in Unit2Control of %.1f M parameters + torch.rand + HOT-2), "
                     "signal only; the stand-in is not the reference's network" %
                     (type(m).__name__, sum(p.numel() for p in m.unit2ctrl.parameters()) / 1e6)}
@@ -904,6 +916,26 @@ def main():
             res["gather_bytes_per_rank"] = 4.0 * B * T
         if world == 1 and not a.no_module_mode:
             res["value_module_mode"] = module_mode(a.model, B, F, n, device, max(5, a.steps // 5), 3)
+            # DSP-only step with the uniform noise drawn inside the noise filter (opt-in; algorithmic bytes 10.01 / sample)
+            fn = synth.combsub_synth if a.model == "combsub" else synth.sins_synth
+
+            def step_rng():
+                st = synth.phase(f0, SR, HOP)
+                return fn(f0, st, ctrls[0], ctrls[1], ctrls[2], None, SR, HOP, want_components=False, noise_seed=7)[0]
+            for _ in range(5):
+                step_rng()
+            torch.cuda.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
+            for _ in range(30):
+                o2 = step_rng()
+            r1.record()
+            torch.cuda.synchronize()
+            assert torch.isfinite(o2).all()
+            res["in_kernel_noise"] = {"ms_per_step": r0.elapsed_time(r1) / 30,
+                                      "algorithmic_bytes_per_step": (4.0 + 4.0 * (sigma_c + 1) / HOP) * B * T,
+                                      "note": "opt-in: Philox4x32-10 draw inside the noise filter instead of a resident "
+                                              "noise tensor (a stream of its own, not torch.rand's)"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, F, sizes)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

@@ -2,6 +2,7 @@
 // the launch sequences of the two synthesiser tails.  No allocation, no synchronisation.
 #include "../../include/ddsp_hip.h"
 #include "kernels.h"
+#include "philox.h"
 #include <atomic>
 #include <mutex>
 #include <stdlib.h>
@@ -309,6 +310,14 @@ int ddsp_hip_fft_convolve(const float* audio, int x_is_u01, const float* taps, c
   return finish();
 }
 
+int ddsp_hip_uniform_noise(unsigned long long seed, unsigned long long offset, int B, long T, float* out, void* stream) {
+  if (B < 0 || T <= 0) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!out) return DDSP_HIP_EINVAL;
+  if (launch_uniform_noise(seed, offset, B, T, out, S(stream)) != 0) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 size_t ddsp_hip_frequency_filter_workspace_bytes(int B, int F, int n_mag) {
   if (B <= 0 || F <= 0 || n_mag < 2) return 0;
   return align_up((size_t)B * F * 2 * (size_t)(n_mag - 1) * sizeof(float), 256);
@@ -391,12 +400,15 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
                         int noise_is_u01, int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,
                         const float* table_ap, const float* table_nz, float* signal, float* harmonic_or_null,
                         float* noise_out_or_null, void* ws, size_t ws_bytes, int fir_impl, void* stream,
-                        void* aux_stream) {
+                        void* aux_stream, unsigned long long noise_seed, unsigned long long noise_offset) {
   if (B < 0 || F <= 0 || hop <= 0 || H <= 0 || n_ap < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
   if (ld_amp < H || ld_gd < n_ap || ld_nz < n_nz) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
-  if (!f0_frames || !phase0 || !c_amp || !c_gd || !c_nz || !noise || !table_ap || !table_nz || !signal)
+  if (!f0_frames || !phase0 || !c_amp || !c_gd || !c_nz || !table_ap || !table_nz || !signal)
     return DDSP_HIP_EINVAL;
+  // noise == NULL: the uniform draw happens inside the noise filter (philox.h) from (noise_seed, noise_offset)
+  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};
+  if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   const int n_max = n_ap > n_nz ? n_ap : n_nz;
   Carver c(ws, ws_bytes);
   SynthWs w;
@@ -415,7 +427,7 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
     synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
                n_nz, w.taps_nz, br.aux);
     const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                              br.aux);
+                              br.aux, &gen);
     if (!ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
     br.join();                                           // always joined, also on the error paths below
@@ -440,7 +452,7 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
              n_nz, w.taps, st);
   if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                 st) < 0)
+                 st, &gen) < 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }
@@ -450,12 +462,15 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
                            const float* noise, int noise_is_u01, int B, int F, int hop, double sr, int infer, int n_ap,
                            int n_harm, int n_nz, const float* table_ap, const float* table_harm, const float* table_nz,
                            float* signal, float* harmonic_or_null, float* noise_out_or_null, void* ws, size_t ws_bytes,
-                           int fir_impl, void* stream, void* aux_stream) {
+                           int fir_impl, void* stream, void* aux_stream, unsigned long long noise_seed,
+                           unsigned long long noise_offset) {
   if (B < 0 || F <= 0 || hop <= 0 || n_ap < 2 || n_harm < 2 || n_nz < 2 || !(sr > 0)) return DDSP_HIP_EINVAL;
   if (ld_gd < n_ap || ld_harm < n_harm || ld_nz < n_nz) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
-  if (!f0_frames || !phase0 || !c_gd || !c_harm || !c_nz || !noise || !table_ap || !table_harm || !table_nz || !signal)
+  if (!f0_frames || !phase0 || !c_gd || !c_harm || !c_nz || !table_ap || !table_harm || !table_nz || !signal)
     return DDSP_HIP_EINVAL;
+  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};   // noise == NULL: drawn inside the noise filter (philox.h)
+  if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   int n_max = n_ap > n_nz ? n_ap : n_nz;
   if (n_harm > n_max) n_max = n_harm;
   Carver c(ws, ws_bytes);
@@ -492,7 +507,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
     }
     synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
                w.taps_nz, br.aux);
-    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux);
+    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux, &gen);
     synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     br.await(0);
     int r1 = 0;
@@ -519,7 +534,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
     synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
                w.taps_nz, br.aux);
     int rn = 0;
-    if (layout == 2) rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux);
+    if (layout == 2) rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux, &gen);
     const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
     int r1 = 0;
     if (rc == 0) {
@@ -538,7 +553,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
     float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
     if (launch_fir(w.buf1, 0, w.taps_h, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
       return DDSP_HIP_ESHAPE;
-    if (launch_fir(noise, noise_is_u01, w.taps_nz, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl, st) < 0)
+    if (launch_fir(noise, noise_is_u01, w.taps_nz, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl, st, &gen) < 0)
       return DDSP_HIP_ESHAPE;
     return finish();
   }
@@ -548,7 +563,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
     synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
                n_nz, w.taps_nz, br.aux);
     const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                              br.aux);
+                              br.aux, &gen);
     synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
     const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
     int r1 = 0;
@@ -582,7 +597,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
              n_nz, w.taps, st);
   if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                 st) < 0)
+                 st, &gen) < 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }

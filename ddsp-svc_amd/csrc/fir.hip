@@ -16,6 +16,7 @@
 // f32 fmaf chains), one 16x16 accumulator per wave, both operands read from LDS.
 #include "ddsp_common.h"
 #include "kernels.h"
+#include "philox.h"
 #include <stdlib.h>
 
 namespace ddsp {
@@ -398,10 +399,14 @@ size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves) {
 // 4 = FFT-domain block convolution (fir_fft.hip; hop 512, N <= 512).
 // Returns the implementation used, or <0 when the requested kernel cannot take the shape.
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-               int B, int F, int hop, int N, int impl, hipStream_t st) {
+               int B, int F, int hop, int N, int impl, hipStream_t st, const NoiseGen* noise_gen) {
   const long T = (long)F * hop;
   if (B == 0 || T == 0) return 0;
   if (N & 1) return -1;
+  if (noise_gen && noise_gen->on) {                   // only the hop-block form draws its input itself
+    if (!(hop == 512 && N <= 512 && (impl == 0 || impl == 5))) return -2;
+    return launch_fir_blk(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st, noise_gen);
+  }
   auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
   // the MFMA kernels move float4 / float2: hop % 4 == 0 (so T % 4 == 0), 16-byte aligned signals, 8-byte aligned taps
   const bool vec_ok = hop >= 16 && (hop & 3) == 0 && N >= 4 && N <= 1022 && T < (1L << 30) && al(x, 16) && al(out, 16) &&

@@ -22,6 +22,7 @@
 // agree to rounding: the first tap spectrum of a run comes out of a differently packed transform).
 #include "fft_r.h"
 #include "kernels.h"
+#include "philox.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -37,11 +38,12 @@ struct FirBlkGeom {
   int run, runs_per_utt;  // own pairs per workgroup
 };
 
-template <int WPS>
+// RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
+template <int WPS, bool RNG = false>
 __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ x, int x_is_u01,
                                                      const float* __restrict__ taps,
                                                      const float* __restrict__ addend, float* __restrict__ out,
-                                                     float* __restrict__ out_plain, FirBlkGeom g) {
+                                                     float* __restrict__ out_plain, FirBlkGeom g, NoiseGen rng) {
   using PL = fft::Plan<2>;
   constexpr int NF = PL::N, P = PL::P, S = 8;                  // 1024 points, 128 threads, 8 points per thread
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];   // two ping-pong pairs: ex[0..1] every transform, ex[2..3] the second of a lockstep pair
@@ -98,6 +100,12 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   struct Blk { float v[4]; };
   auto load_blk = [&](int bi) -> Blk {
     Blk r;
+    if (RNG) {                                                  // drawn, not read: 4 uniforms of (utterance, block, lane)
+      const Quad q = philox_uniform4(rng, (unsigned)bu, (unsigned)bi, (unsigned)tid);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) r.v[m] = bi < g.F ? q.u[m] : 0.f;
+      return r;
+    }
     const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F ? FB_HOP : 0);
 #pragma unroll
     for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
@@ -173,7 +181,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         float xv = cx.v[m];
-        if (x_is_u01 && live) xv = fmaf(2.0f, xv, -1.0f);       // noise = rand*2-1 (vocoder.py:603,854); uniform condition
+        if ((RNG || x_is_u01) && live) xv = fmaf(2.0f, xv, -1.0f);   // noise = rand*2-1 (vocoder.py:603,854); uniform condition
         const float lam = (float)(P * m + tid) * inv_hop;
         z[m] = f32x2{(1.0f - lam) * xv, lam * xv};               // the two Bartlett halves (core.py:161)
       }
@@ -253,9 +261,31 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   }
 }
 
+// the same draw written out as a [B,T] tensor of u in [0,1) (tests, the oracle comparison, and callers whose noise filter
+// is not served by the in-kernel form); any T: block = t / 512, lane = t % 128, output word = (t % 512) / 128
+__global__ void __launch_bounds__(128) k_uniform_noise(NoiseGen rng, int B, long T, float* __restrict__ out) {
+  const long blocks_per_utt = (T + FB_HOP - 1) / FB_HOP;
+  const long wg = blockIdx.x;
+  const unsigned b = (unsigned)(wg / blocks_per_utt);
+  const unsigned bi = (unsigned)(wg - (long)b * blocks_per_utt);
+  const Quad q = philox_uniform4(rng, b, bi, threadIdx.x);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const long t = (long)bi * FB_HOP + 128 * m + threadIdx.x;
+    if (t < T) out[(long)b * T + t] = q.u[m];
+  }
+}
+
+int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int B, long T, float* out, hipStream_t st) {
+  const long wgs = (long)B * ((T + FB_HOP - 1) / FB_HOP);
+  if (wgs <= 0 || wgs > 0x7fffffffL) return -1;
+  hipLaunchKernelGGL(k_uniform_noise, dim3((unsigned)wgs), dim3(128), 0, st, NoiseGen{seed, offset, 1}, B, T, out);
+  return 0;
+}
+
 // returns the implementation id (5) or < 0 when the shape is outside this kernel
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-                   int B, int F, int hop, int N, hipStream_t st) {
+                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen) {
   if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 29)) return -1;   // byte offsets of one utterance stay below 2^31 (buffer descriptors)
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
@@ -275,18 +305,24 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
+  NoiseGen rng{0ull, 0ull, 0};
+  if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
+    rng = *noise_gen;
+    hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+    return 5;
+  }
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
   if (pad > 0) {
-    hipLaunchKernelGGL(k_fir_blk<2>, dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
     return 5;
   }
   if (wps >= 4)
-    hipLaunchKernelGGL(k_fir_blk<4>, dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    hipLaunchKernelGGL((k_fir_blk<4, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   else if (wps == 3)
-    hipLaunchKernelGGL(k_fir_blk<3>, dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    hipLaunchKernelGGL((k_fir_blk<3, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   else
-    hipLaunchKernelGGL(k_fir_blk<2>, dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   return 5;
 }
 

@@ -37,12 +37,15 @@ void launch_window_taps(const float* in, int mode, const float* half_width, long
 void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
                              hipStream_t st);
 size_t fir_mfma_lds_bytes(int F, int hop, int N, int waves);
+struct NoiseGen;   // philox.h: (seed, offset) of the in-kernel uniform draw
+// noise_gen != null && on: the input signal is drawn inside the kernel (hop 512, N <= 512 only: -2 otherwise)
 int launch_fir(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-               int B, int F, int hop, int N, int impl, hipStream_t st);
+               int B, int F, int hop, int N, int impl, hipStream_t st, const NoiseGen* noise_gen = nullptr);
+int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int B, long T, float* out, hipStream_t st);
 int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st);
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-                   int B, int F, int hop, int N, hipStream_t st);
+                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr);
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st);
 int launch_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc, float* phase_frames,

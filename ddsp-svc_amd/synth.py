@@ -104,13 +104,40 @@ def _outputs(B, T, device, want_components):
     return signal, None, None
 
 
+def uniform_noise(B, T, seed, offset, device):
+    """The counter-based uniform draw ``u [B,T]`` in [0,1) that the tails generate inside their noise filter when
+    ``noise=None`` (``ddsp_hip_uniform_noise``; a Philox4x32-10 stream of its own, not torch.rand's)."""
+    out = torch.empty(B, T, dtype=torch.float32, device=device)
+    _ffi.check_device(out)
+    _ffi.check(_ffi.lib().ddsp_hip_uniform_noise(int(seed), int(offset), B, T, ptr(out), _ffi.stream_of(out)))
+    return out
+
+
+def _noise_arg(noise, noise_seed, noise_offset, noise_is_u01, B, T, hop, n_nz, fir_impl, device):
+    """(tensor | None, is_u01, seed, offset) for the C call: ``noise=None`` asks for the in-kernel draw from
+    ``(noise_seed, noise_offset)``; where the noise filter's shape is outside the kernel that can draw (hop 512,
+    n_mag_noise <= 257) the same numbers are written out first."""
+    if noise is not None:
+        return _f32c(noise.reshape(B, T)), noise_is_u01, 0, 0
+    if noise_seed is None:
+        raise ValueError("noise=None needs noise_seed (the in-kernel draw is keyed by (noise_seed, noise_offset))")
+    if hop == 512 and n_nz <= 257 and fir_impl in (_ffi.FIR_AUTO, _ffi.FIR_BLK):
+        return None, False, int(noise_seed), int(noise_offset)
+    return uniform_noise(B, T, noise_seed, noise_offset, device), True, 0, 0
+
+
 def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magnitude, noise, sampling_rate,
-               block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
+               block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO, noise_seed=None,
+               noise_offset=0):
     """DSP tail of ``Sins.forward`` (vocoder.py:580-611) from raw controls.  ``noise [B,T]`` is the
-    uniform draw (``noise_is_u01``: raw ``rand_like`` output, else already ``2u-1``).
+    uniform draw (``noise_is_u01``: raw ``rand_like`` output, else already ``2u-1``), or None: drawn inside the noise
+    filter from ``(noise_seed, noise_offset)`` (``uniform_noise`` gives the same numbers as a tensor).
     Returns ``(signal, harmonic|None, noise|None)``.  With gradients enabled and a control that requires grad the
     differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, amplitudes, group_delay, noise_magnitude, noise, state.phase0)
+    if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
+        noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
+                                            f0_frames.device), True
     if torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
         return _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude, noise, sampling_rate,
                                  block_size, noise_is_u01)
@@ -122,15 +149,15 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
     ca, lda = _rows(amplitudes, H)
     cg, ldg = _rows(group_delay, n_ap)
     cn, ldn = _rows(noise_magnitude, n_nz)
-    nz = _f32c(noise.reshape(B, T))
     dev = f0.device
+    nz, is_u01, seed, offset = _noise_arg(noise, noise_seed, noise_offset, noise_is_u01, B, T, hop, n_nz, fir_impl, dev)
     ws, need = _workspace(B, F, hop, max(n_ap, n_nz), dev)
     signal, harm, nzo = _outputs(B, T, dev, want_components)
     _ffi.check(_ffi.lib().ddsp_hip_sins_synth(
         ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(ca), lda, ptr(cg), ldg, ptr(cn), ldn,
-        ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), H, n_ap, n_nz,
+        ptr(nz), int(is_u01), B, F, hop, float(sampling_rate), int(state.infer), H, n_ap, n_nz,
         ptr(ir_table(n_ap, dev)), ptr(ir_table(n_nz, dev)), ptr(signal), ptr(harm), ptr(nzo),
-        ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F)))
+        ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F), seed, offset))
     return signal, harm, nzo
 
 
@@ -273,10 +300,15 @@ def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude
 
 
 def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude, noise_magnitude, noise,
-                  sampling_rate, block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO):
-    """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls.  With gradients enabled and a control
+                  sampling_rate, block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO,
+                  noise_seed=None, noise_offset=0):
+    """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls; ``noise=None``: the uniform draw happens
+    inside the noise filter from ``(noise_seed, noise_offset)`` (see ``sins_synth``).  With gradients enabled and a control
     that requires grad the differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, state.phase0)
+    if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):
+        noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
+                                            f0_frames.device), True
     if torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):
         return _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, noise_magnitude, noise,
                                     sampling_rate, block_size, noise_is_u01)
@@ -288,15 +320,16 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
     cg, ldg = _rows(group_delay, n_ap)
     ch, ldh = _rows(harmonic_magnitude, n_h)
     cn, ldn = _rows(noise_magnitude, n_nz)
-    nz = _f32c(noise.reshape(B, T))
     dev = f0.device
+    nz, is_u01, seed, offset = _noise_arg(noise, noise_seed, noise_offset, noise_is_u01, B, T, hop, n_nz, fir_impl, dev)
     ws, need = _workspace(B, F, hop, max(n_ap, n_h, n_nz), dev)
     signal, harm, nzo = _outputs(B, T, dev, want_components)
     _ffi.check(_ffi.lib().ddsp_hip_combsub_synth(
         ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(cg), ldg, ptr(ch), ldh, ptr(cn), ldn,
-        ptr(nz), int(noise_is_u01), B, F, hop, float(sampling_rate), int(state.infer), n_ap, n_h, n_nz,
+        ptr(nz), int(is_u01), B, F, hop, float(sampling_rate), int(state.infer), n_ap, n_h, n_nz,
         ptr(ir_table(n_ap, dev)), ptr(ir_table(n_h, dev)), ptr(ir_table(n_nz, dev)),
-        ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F)))
+        ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, int(fir_impl), _ffi.stream_of(f0), _ffi.aux_stream_of(f0, B * F),
+        seed, offset))
     return signal, harm, nzo
 
 

@@ -44,6 +44,18 @@ class _SynthBase(torch.nn.Module):
         self.unit2ctrl = factory(n_unit, n_spk, split_map, **unit2ctrl_kwargs)
         self.return_components = True       # the (harmonic, noise) tuple is API; set False to skip materialising it
         self.fir_impl = 0
+        # Opt-in (Sins / CombSub): an integer seed makes the noise draw happen INSIDE the noise filter (a Philox stream
+        # of its own, synth.uniform_noise -- not the numbers torch.rand_like would give) instead of a torch.rand tensor;
+        # every forward call advances the stream (offset = number of calls so far).  None: torch.rand as the reference.
+        self.in_kernel_noise_seed = None
+        self._noise_calls = 0
+
+    def _noise(self, B, T, device):
+        """(noise tensor | None, kwargs) for the synth call"""
+        if self.in_kernel_noise_seed is None:
+            return torch.rand(B, T, dtype=torch.float32, device=device), {}
+        self._noise_calls += 1
+        return None, {"noise_seed": int(self.in_kernel_noise_seed), "noise_offset": self._noise_calls - 1}
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
@@ -69,11 +81,11 @@ class Sins(_SynthBase):
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :578
         B, F = f0_frames.shape[0], f0_frames.shape[1]
-        u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :603
+        u01, rng = self._noise(B, F * self._hop, f0_frames.device)                               # rand_like, :603
         signal, harmonic, noise = synth.sins_synth(
             f0_frames, st, ctrls["amplitudes"], ctrls["group_delay"], ctrls["noise_magnitude"], u01,
             self._sr, self._hop, noise_is_u01=True, want_components=self.return_components,
-            fir_impl=self.fir_impl)
+            fir_impl=self.fir_impl, **rng)
         return signal, hidden, (harmonic, noise)
 
 
@@ -95,11 +107,11 @@ class CombSub(_SynthBase):
         ctrls, hidden = self.unit2ctrl(units_frames, f0_frames, st.phase_frames, volume_frames,
                                        spk_id=spk_id, spk_mix_dict=spk_mix_dict)                # :832
         B, F = f0_frames.shape[0], f0_frames.shape[1]
-        u01 = torch.rand(B, F * self._hop, dtype=torch.float32, device=f0_frames.device)        # rand_like, :854
+        u01, rng = self._noise(B, F * self._hop, f0_frames.device)                               # rand_like, :854
         signal, harmonic, noise = synth.combsub_synth(
             f0_frames, st, ctrls["group_delay"], ctrls["harmonic_magnitude"], ctrls["noise_magnitude"], u01,
             self._sr, self._hop, noise_is_u01=True, want_components=self.return_components,
-            fir_impl=self.fir_impl)
+            fir_impl=self.fir_impl, **rng)
         return signal, hidden, (harmonic, noise)
 
 

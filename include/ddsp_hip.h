@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 140          /* 0.1.4: + tuning knobs, window_impulse_response, windowed complex adjoint */
+#define DDSP_HIP_VERSION 141          /* 0.1.4.1: + tuning knobs, window_impulse_response, windowed complex adjoint, in-kernel noise draw */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -137,8 +137,19 @@ int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_
 int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float* taps, const float* grad_out,
                                    float* d_audio, float* d_taps, int B, int F, int hop, int N, void* stream);
 
+/* The uniform draw of the noise branch (vocoder.py:603, :854 rand_like) as a counter-based stream, for callers that do
+ * not want to materialise torch.rand: u[B,T] in [0,1) from Philox4x32-10 keyed by `seed`, counter = (128 * (t / 512) +
+ * t % 128, utterance, offset lo, offset hi), output word (t % 512) / 128 -- reproducible from (seed, offset), independent
+ * of launch geometry.  It is NOT torch's stream: the same seed gives different numbers than torch.rand (torch's mapping
+ * of elements to counters depends on its launch geometry; reproducing it inside the filter would cost four generator
+ * calls per block and thread instead of one).  The synthesiser tails below draw exactly these numbers inside their noise
+ * filter when `noise` is NULL (hop 512, n_nz <= 257); this entry point writes them out. */
+int ddsp_hip_uniform_noise(unsigned long long seed, unsigned long long offset, int B, long T, float* out, void* stream);
+
 /* DSP tail of Sins.forward (ddsp/vocoder.py:580-611) from raw controls and the phase state.
- * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1); tables for n_ap / n_nz bins.
+ * noise[B,T]: uniform draw (noise_is_u01 ? U[0,1) : already 2u-1), or NULL: drawn inside the noise filter from
+ * (noise_seed, noise_offset) as ddsp_hip_uniform_noise defines it (opt-in: 4 B / sample less HBM traffic and no separate
+ * generator kernel, for ~20 % more arithmetic in that one filter launch); tables for n_ap / n_nz bins.
  * signal[B,T]; harmonic_or_null / noise_out_or_null [B,T] only if the caller wants the tuple. */
 int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
                         const float* c_amp, long ld_amp, const float* c_gd, long ld_gd,
@@ -146,7 +157,8 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
                         int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,
                         const float* table_ap, const float* table_nz,
                         float* signal, float* harmonic_or_null, float* noise_out_or_null,
-                        void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream);
+                        void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream,
+                        unsigned long long noise_seed, unsigned long long noise_offset);
 
 /* DSP tail of CombSub.forward (ddsp/vocoder.py:834-862). */
 int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, const double* phase0,
@@ -155,7 +167,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
                            int B, int F, int hop, double sr, int infer, int n_ap, int n_harm, int n_nz,
                            const float* table_ap, const float* table_harm, const float* table_nz,
                            float* signal, float* harmonic_or_null, float* noise_out_or_null,
-                           void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream);
+                           void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream,
+                           unsigned long long noise_seed, unsigned long long noise_offset);
 
 /* aux_stream (both calls above): NULL, or a second stream of the same device, which must be the calling thread's
  * current device (hipSetDevice) -- the fork / join events are created there.  The noise branch (its taps and its

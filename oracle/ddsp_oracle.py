@@ -342,6 +342,44 @@ def synth_noise(B: int, T: int, seed: int = 99) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# opt-in in-kernel noise draw (include/ddsp_hip.h, ddsp_hip_uniform_noise): Philox4x32-10
+# (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- the published algorithm; pinned
+# below in tests/test_noise_rng.py against the known-answer vectors of the Random123 distribution)
+# --------------------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """``counter [..., 4]``, ``key [..., 2]`` uint32 -> ``[..., 4]`` uint32"""
+    c = np.array(counter, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    k = np.array(key, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    M0, M1, W0, W1, MASK = (np.uint64(v) for v in (0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF))
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2                      # 32 x 32 -> 64 bit products
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack([c0, c1, c2, c3], -1).astype(np.uint32)
+
+
+def uniform_noise(B: int, T: int, seed: int, offset: int) -> np.ndarray:
+    """``u [B,T]`` float32 in [0,1): counter = (128 * (t // 512) + t % 128, b, offset lo, offset hi), key = (seed lo, hi),
+    output word (t % 512) // 128, ``u = (x >> 8) * 2**-24``."""
+    t = np.arange(T, dtype=np.uint64)
+    blocks = (T + 511) // 512
+    lane, word, blk = t % np.uint64(128), (t % np.uint64(512)) // np.uint64(128), t // np.uint64(512)
+    ctr = np.zeros((B, blocks * 128, 4), dtype=np.uint64)
+    idx = np.arange(blocks * 128, dtype=np.uint64)
+    ctr[..., 0] = idx[None, :]
+    ctr[..., 1] = np.arange(B, dtype=np.uint64)[:, None]
+    ctr[..., 2] = np.uint64(offset & 0xFFFFFFFF)
+    ctr[..., 3] = np.uint64((offset >> 32) & 0xFFFFFFFF)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    x = philox4x32_10(ctr, np.broadcast_to(key, ctr.shape[:-1] + (2,)))
+    sel = x[:, (blk * np.uint64(128) + lane).astype(np.int64), word.astype(np.int64)]
+    return ((sel >> np.uint32(8)).astype(np.float32) * F32(2.0 ** -24)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
 # 8-f #1  CombSubFast / CombSubSuperFast: short-time spectral filtering     vocoder.py:613-786
 # --------------------------------------------------------------------------------------
 def fast_source_gen(f0_frames: np.ndarray, sr: float, hop: int):
