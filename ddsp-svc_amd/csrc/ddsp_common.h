@@ -122,7 +122,7 @@ struct PhaseCfg {
 // handling (positions before / after a row, an utterance, the last block) then costs no compares, selects or exec-mask
 // branches, and the per-lane address is one 32-bit VGPR plus an instruction immediate.  Rules kept by the callers: the
 // descriptor is built from wave-uniform values only, and a byte offset is either non-negative (immediates may then be
-// folded onto it) or the constant kOutOfRange with no immediate on top.
+// folded onto it) or the constant kOutOfRange plus an immediate below 64 KiB; a descriptor spans less than 2^30 bytes.
 struct BufF32 {
   __amdgpu_buffer_rsrc_t r;
   static constexpr int kOutOfRange = 0x40000000;

@@ -112,6 +112,9 @@ struct Plan {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
     return ((tid >> 1) & 7) + 8 * (tid >> 4) + 64 * slot + 512 * (tid & 1);
   }
+  // Where bin k is parked for the mirrored read Z[-k]: lane pairs hold k and k + 512 -- the same banks -- so the upper
+  // half is stored with bits 3 and 4 flipped (conflict-free 16-lane stores and, but for two lanes, 32-lane loads).
+  static __device__ __forceinline__ int parked(int k) { return k ^ (((k >> 9) & 1) * 24); }
   // DFT_2 over the low lane bit: even lane a0 + a1, odd lane a0 - a1
   static __device__ __forceinline__ void lane_pair_dft2(f32x2 (&v)[8], int tid) {
     const float sgn = (tid & 1) ? -1.0f : 1.0f;
@@ -134,12 +137,12 @@ struct Plan {
 #pragma unroll
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) X[k * P + tid] = v[k];
+    for (int k = 0; k < 8; ++k) X[k * P + (tid ^ ((k & 1) * C))] = v[k];             // odd rows: 16-blocks swapped in pairs
     __syncthreads();
     {
       const int k1 = tid / C, c = tid & (C - 1);
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) v[n2] = X[k1 * P + n2 * C + c];
+      for (int n2 = 0; n2 < 8; ++n2) v[n2] = X[k1 * P + (n2 ^ (k1 & 1)) * C + c];    // rows k1, k1 + 1 of a 32-lane read: other banks
       dft8(v);
 #pragma unroll
       for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
@@ -167,12 +170,15 @@ struct Plan {
 #pragma unroll
     for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w1[k]); v[k] = cmul(v[k], tw.w1[k]); }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { X0[k * P + tid] = u[k]; X1[k * P + tid] = v[k]; }
+    for (int k = 0; k < 8; ++k) { X0[k * P + (tid ^ ((k & 1) * C))] = u[k]; X1[k * P + (tid ^ ((k & 1) * C))] = v[k]; }
     __syncthreads();
     {
       const int k1 = tid / C, c = tid & (C - 1);
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) { u[n2] = X0[k1 * P + n2 * C + c]; v[n2] = X1[k1 * P + n2 * C + c]; }
+      for (int n2 = 0; n2 < 8; ++n2) {
+        u[n2] = X0[k1 * P + (n2 ^ (k1 & 1)) * C + c];
+        v[n2] = X1[k1 * P + (n2 ^ (k1 & 1)) * C + c];
+      }
       dft8(u);
       dft8(v);
 #pragma unroll
@@ -204,14 +210,15 @@ struct Plan {
 #pragma unroll
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
     dft8(v);
+    const int ts = tid ^ (((tid / R) & 1) * C);                  // tid = n4 + R k1 + 8R k2: odd k1 sit in the neighbouring 16-block
 #pragma unroll
-    for (int n3 = 0; n3 < 8; ++n3) Y[n3 * P + (tid ^ (n3 * R))] = v[n3];
+    for (int n3 = 0; n3 < 8; ++n3) Y[n3 * P + (ts ^ (n3 * R))] = v[n3];
     __syncthreads();
     {
       const int k1 = tid / C, c = tid & (C - 1);
       const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) v[k2] = Y[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))];
+      for (int k2 = 0; k2 < 8; ++k2) v[k2] = Y[n3 * P + (((k2 ^ (k1 & 1)) * C + k1 * R + n4) ^ (n3 * R))];   // rows k1, k1 + 1: other banks
 #pragma unroll
       for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
       dft8(v);
@@ -224,6 +231,53 @@ struct Plan {
 #pragma unroll
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
     dft8(v);
+  }
+  // transposed(v) and forward_s<true>(u) in lockstep: an inverse transform (layout S -> natural order) beside the forward
+  // transform of an unrelated zero-padded input (natural order -> layout S) -- the same two exchanges and three butterfly
+  // columns each, in opposite order, so every barrier serves both and each wave has the other transform's arithmetic to
+  // issue while one's LDS round trip is in flight.  Four distinct buffers: Yv and Xu must be free of readers on entry,
+  // Xv and Yu become free at the first barrier; on return Yv and Xu are free, Xv and Yu may still be read by slower waves.
+  static __device__ __forceinline__ void transposed_and_forward_s(f32x2 (&v)[8], f32x2 (&u)[8], const Tw& tw, f32x2* Yv,
+                                                                  f32x2* Xv, f32x2* Xu, f32x2* Yu, int tid) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    lane_pair_dft2(v, tid);
+    dft8_lo4(u);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w3[k]); u[k] = cmul(u[k], tw.w1[k]); }
+    dft8(v);
+    const int ts = tid ^ (((tid / R) & 1) * C);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      Yv[k * P + (ts ^ (k * R))] = v[k];
+      Xu[k * P + (tid ^ ((k & 1) * C))] = u[k];
+    }
+    __syncthreads();
+    {
+      const int k1 = tid / C, c = tid & (C - 1);
+      const int n3 = c / R, n4 = c & (R - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = Yv[n3 * P + (((k ^ (k1 & 1)) * C + k1 * R + n4) ^ (n3 * R))];
+        u[k] = Xu[k1 * P + (k ^ (k1 & 1)) * C + c];
+      }
+      dft8(u);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w2[k]); u[k] = cmul(u[k], tw.w2[k]); }
+      dft8(v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        Xv[k1 * P + k * C + c] = v[k];
+        Yu[n3 * P + ((k * C + k1 * R + n4) ^ (n3 * R))] = u[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = Xv[k * P + tid]; u[k] = Yu[k * P + (tid ^ (k * R))]; }
+    dft8(u);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w1[k]); u[k] = cmul(u[k], tw.w3[k]); }
+    dft8(v);
+    lane_pair_dft2(u, tid);
   }
 };
 

@@ -14,10 +14,10 @@
 // 40 % fewer flops and a third less LDS exchange traffic.
 //
 // A 128-thread workgroup (2 waves, fft_r.h with R = 2) walks a run of consecutive block pairs of one utterance
-// and keeps the spectra of three tap rows in registers.  The taps enter the transform circularly shifted by
-// 512 - N/2, which moves the (circular, but alias-free: support <= 1023) result of block b to the output range
-// starting at (b-1) hop -- a multiple of the thread count -- so every thread only ever touches overlap-add
-// ring slots congruent to its id and the ring needs no barriers.  A run starts one pair early (discarded) so
+// and keeps the spectra of three tap rows in registers.  The taps enter the transform shifted by 256 - N/2: they
+// then sit in the lower half of the transform (its first pass is pruned like the block's) and the result of block b
+// (support <= 1023: no aliasing) starts at output time (b - 1/2) hop -- a multiple of the thread count -- so every
+// thread only ever touches overlap-add ring slots congruent to its id and the ring needs no barriers.  A run starts one pair early (discarded) so
 // the ring holds its predecessor's tail: no atomics, so a launch geometry is bit-reproducible (different run splits
 // agree to rounding: the first tap spectrum of a run comes out of a differently packed transform).
 #include "fft_r.h"
@@ -32,10 +32,24 @@ using fft::cmul;
 
 constexpr int FB_HOP = 512;
 
+#ifdef DDSP_HIP_TIMELINE
+// diagnostics build only (tools/fir_blk_timeline.py): per-workgroup wall-clock stamps (100 MHz, one epoch for the chip)
+__device__ long long* g_blk_timeline = nullptr;
+__global__ void k_set_blk_timeline(long long* p) { g_blk_timeline = p; }
+#define BLK_STAMP(slot) do { if (g_blk_timeline && threadIdx.x == 0 && (slot) < 32) g_blk_timeline[(long)blockIdx.x * 32 + (slot)] = (long long)wall_clock64(); } while (0)
+#define BLK_STAMP_CYC(slot) do { if (g_blk_timeline && threadIdx.x == 0 && (slot) < 32) g_blk_timeline[(long)blockIdx.x * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BLK_STAMP_WHERE(slot) do { if (g_blk_timeline && threadIdx.x == 0) g_blk_timeline[(long)blockIdx.x * 32 + (slot)] = ((long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804); } while (0)
+#else
+#define BLK_STAMP(slot) do { } while (0)
+#define BLK_STAMP_CYC(slot) do { } while (0)
+#define BLK_STAMP_WHERE(slot) do { } while (0)
+#endif
+
 struct FirBlkGeom {
   int F, N, T;            // frames, taps, samples per utterance
   int pairs;              // block pairs per utterance: ceil(F / 2)
-  int run, runs_per_utt;  // own pairs per workgroup
+  int run, runs_per_utt;  // most pairs a workgroup owns; workgroups per utterance
+  int turns;              // waves sharing a SIMD alternate priority (knob BLK_TURNS: 1 = off)
 };
 
 // RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
@@ -49,11 +63,15 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];   // two ping-pong pairs: ex[0..1] every transform, ex[2..3] the second of a lockstep pair
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
-  const int run_no = blockIdx.x - b * g.runs_per_utt;
-  const int q_first = run_no * g.run;
-  int q_last = q_first + g.run;
-  if (q_last > g.pairs) q_last = g.pairs;
-  const int SH = FB_HOP - (g.N >> 1);                          // circular tap shift
+  // which run of the utterance: rotated by the utterance number (and by its higher digits), so that the longer and the
+  // shorter runs of the even split below line up neither with the XCD round-robin of the dispatcher (blockIdx % 8) nor
+  // with the workgroups a CU collects (blockIdx 256 apart at the headline shape): every CU gets a mix
+  const int run_no = (int)((blockIdx.x - b * g.runs_per_utt + b + (b >> 4) + (b >> 8)) % g.runs_per_utt);
+  // an utterance's pairs are split evenly over its runs (lengths differ by at most one: workgroups that share a SIMD
+  // then finish together instead of leaving it half empty)
+  const int q_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);
+  const int q_last = (int)(((long)(run_no + 1) * g.pairs) / g.runs_per_utt);
+  const int SH = FB_HOP / 2 - (g.N >> 1);                      // tap shift: row centred on transform index 256
   // Every global access goes through a buffer descriptor whose byte count bounds it (BufF32, ddsp_common.h): positions
   // outside a tap row, blocks beyond the utterance and output times outside [0, T) are dropped by the address unit, so the
   // loop carries no clamps, selects or exec-mask branches for them.  Descriptors are built from workgroup-uniform values.
@@ -64,36 +82,39 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   const BufF32 out_buf = BufF32::make(out + ob, g.T);
   const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
   const BufF32 add_buf = BufF32::make(addend ? addend + ob : out + ob, addend ? g.T : 0);
+  const bool has_addend = addend != nullptr, has_plain = out_plain != nullptr;   // workgroup-uniform: scalar branches
   const float inv_hop = 1.0f / (float)FB_HOP;
   const int tid4 = 4 * tid;
 
+  BLK_STAMP(0);
+  BLK_STAMP_WHERE(31);
   typename PL::Tw tw;
   tw.init(tid);
+  BLK_STAMP(1);
   // Overlap-add ring: 1024 samples, of which a thread only ever touches the 8 congruent to its id -- they live in
-  // registers.  Transform index n = 128 m + tid of block bb is time (bb - 1) hop + n, i.e. ring slot (4 (bb - 1) + m) mod 8:
+  // registers.  Transform index n = 128 m + tid of block bb is time (bb - 1/2) hop + n, i.e. ring slot (4 bb - 2 + m) mod 8:
   // a pair advances the ring by exactly one revolution, so every slot index below is a compile-time constant.
   float ring[S];
 #pragma unroll
   for (int m = 0; m < S; ++m) ring[m] = 0.f;
-  int cur = 0;                                                 // ex[cur]: the exchange buffer no wave is reading any more
-
-  // Global loads are issued at the top of a pair for the NEXT pair and stay in flight across the transforms.
-  // One tap row, shifted: the value at transform index n = 128 m + tid is taps[row][n - SH]; only m >= 2 can be live.
-  // The six byte offsets are loop invariants; a position before the row start gets the out-of-range constant (a
+  // Global loads are issued at the top of a pair: the blocks of the NEXT pair, and the tap rows whose transform rides
+  // beside this pair's inverse (see the loop).
+  // One tap row, shifted: the value at transform index n = 128 m + tid is taps[row][n - SH]; only m < 4 can be live.
+  // The four byte offsets are loop invariants; a position before the row start gets the out-of-range constant (a
   // position beyond the row end is out of range by itself: the descriptor spans exactly one row).
-  struct TapRow { float v[6]; };
-  int tap_off[6];
+  struct TapRow { float v[4]; };
+  int tap_off[4];
 #pragma unroll
-  for (int m = 2; m < S; ++m) {
+  for (int m = 0; m < 4; ++m) {
     const int i = P * m + tid - SH;
-    tap_off[m - 2] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+    tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
   }
   auto load_taps = [&](int j) -> TapRow {
     TapRow r;
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
     const BufF32 tr = BufF32::make(tb + (long)row * g.N, g.N);
 #pragma unroll
-    for (int m = 2; m < S; ++m) r.v[m - 2] = tr.ld(tap_off[m - 2]);
+    for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
     return r;
   };
   // one hop block of the input: 4 samples per thread (s = 128 m + tid); a block beyond the utterance reads zeros
@@ -111,153 +132,192 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
     return r;
   };
-  // FFT of a packed pair (real + i imaginary) into the scrambled layout S of fft_r.h (two LDS exchanges; every
-  // spectral array of this kernel lives in S), then the same values parked in LDS at their natural bin index for the
-  // mirrored read Z[-k].  ex[cur] is the buffer no wave reads any more; the mirror copy goes there as well (its
-  // readers of the first pass are behind the second barrier), so afterwards the OTHER buffer is the free one.
-  const int kS0 = PL::s_index(tid, 0);                          // bin of slot 0; slot m holds bin kS0 + 64 m
-  auto transform = [&](f32x2 (&z)[S], auto hi_zero) -> f32x2* {
-    f32x2* X = ex[cur];
-    f32x2* Y = ex[cur ^ 1];
-    PL::template forward_s<decltype(hi_zero)::value>(z, tw, X, Y, tid);
+  // transform inputs: two tap rows packed as real + i imaginary; one block as its two Bartlett halves (core.py:161).
+  // Both occupy the lower half of the transform (pruned first pass).
+  auto pack_taps = [&](const TapRow& ta, const TapRow& tb2, f32x2 (&z)[S]) {
 #pragma unroll
-    for (int m = 0; m < S; ++m) X[kS0 + 64 * m] = z[m];
-    __syncthreads();
-    cur ^= 1;
-    return X;
+    for (int m = 0; m < 4; ++m) z[m] = f32x2{ta.v[m], tb2.v[m]};
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
   };
-  const float ch = 0.25f / (float)NF;                          // the 1/2 of both splits and the 1/N of the inverse
-  // Ga = ch * H_j, Gb = ch * H_j+1 from Z = FFT(h_j + i h_j+1):  H_j = (Z[k] + conj Z[-k]) / 2,
-  // H_j+1 = (Z[k] - conj Z[-k]) / 2i
-  auto split_taps = [&](const TapRow& ta, const TapRow& tb2, f32x2 (&Ga)[S], f32x2 (&Gb)[S]) {
-    f32x2 z[S];
-    z[0] = z[1] = f32x2{0.f, 0.f};
+  auto pack_blk = [&](const Blk& cx, bool live, f32x2 (&z)[S]) {
 #pragma unroll
-    for (int m = 2; m < S; ++m) z[m] = f32x2{ta.v[m - 2], tb2.v[m - 2]};
-    const f32x2* Zn = transform(z, std::false_type{});
+    for (int m = 0; m < 4; ++m) {
+      float xv = cx.v[m];
+      if ((RNG || x_is_u01) && live) xv = fmaf(2.0f, xv, -1.0f);   // noise = rand*2-1 (vocoder.py:603,854); uniform condition
+      const float lam = (float)(P * m + tid) * inv_hop;
+      z[m] = f32x2{(1.0f - lam) * xv, lam * xv};
+    }
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
+  };
+  // Every spectral array of this kernel lives in the scrambled layout S of fft_r.h (slot m of thread tid holds bin
+  // kS0 + 64 m); for the mirrored read Z[-k] a transform's bins are parked in LDS by (swizzled) bin index.
+  const int kS0 = PL::s_index(tid, 0);
+  const int kP0 = PL::parked(kS0);                              // where slot 0 is parked (bits 3, 4, 9 are not touched by 64 m)
+  auto park = [&](const f32x2 (&z)[S], f32x2* X) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) X[kP0 + 64 * m] = z[m];
+  };
+  auto mirrored = [&](const f32x2* X, int m) -> f32x2 { return X[PL::parked((NF - (kS0 + 64 * m)) & (NF - 1))]; };
+  const float ch = 0.25f / (float)NF;                          // the 1/2 of both splits and the 1/N of the inverse
+  // Ga = ch * H_j, Gb = ch * H_j+1 from Z = FFT(h_j + i h_j+1) (in z, and parked in Zp):  H_j = (Z[k] + conj Z[-k]) / 2,
+  // H_j+1 = (Z[k] - conj Z[-k]) / 2i
+  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Ga)[S], f32x2 (&Gb)[S]) {
 #pragma unroll
     for (int m = 0; m < S; ++m) {
-      const int k = kS0 + 64 * m;
-      const f32x2 zneg = Zn[(NF - k) & (NF - 1)];
+      const f32x2 zneg = mirrored(Zp, m);
       const f32x2 p = fft::add_conj(z[m], zneg);                // 2 H_j
       const f32x2 d = fft::sub_conj(z[m], zneg);                // 2i H_j+1
       Ga[m] = p * ch;
       Gb[m] = f32x2{d.y * ch, -d.x * ch};                      // d / i
     }
   };
+  // Y = X1 H_b + X2 H_b+1 = p G_b - i d G_b+1 with p = 2 X1, d = 2i X2 from the packed block transform (z, parked in Zp)
+  auto filtered = [&](f32x2 zm, const f32x2* Zp, int m, f32x2 G0, f32x2 G1) -> f32x2 {
+    const f32x2 zn = mirrored(Zp, m);
+    return fft::add_mi(cmul(fft::add_conj(zm, zn), G0), cmul(fft::sub_conj(zm, zn), G1));
+  };
 
-  const int q0 = q_first > 0 ? q_first - 1 : 0;
-  // prologue: spectrum of the first block's own tap row (packed with the row after it, which the loop recomputes
-  // together with its successor -- one extra half transform per run)
-  f32x2 Gc[S];
+  // The four exchange buffers have fixed roles.  A pair is two lockstep stages (fft_r.h), three barriers each:
+  //   forward_s2:  the two block transforms; first exchange through A / B, second through C / D, bins parked in A / B
+  //   transposed_and_forward_s:  the pair's inverse beside the transform of the NEXT pair's two tap rows; first exchange
+  //       through C / D (free since the park barrier), second through A / B (free at the first barrier: the product is
+  //       done with them), tap bins parked in C (last read before the second barrier)
+  // so when a stage writes a buffer, every wave is past the barrier that followed its last read.
+  f32x2* const bA = ex[0];
+  f32x2* const bB = ex[1];
+  f32x2* const bC = ex[2];
+  f32x2* const bD = ex[3];
+
+  // Prologue.  The loop wants the spectra of its first pair's three tap rows (Gc, Ga, Gb) and the predecessor's tail in
+  // the ring.  Of the pair before the run only its SECOND block b_w = 2 q_first - 1 reaches into the run's first emitted
+  // sample (the result of block b ends before (b + 3/2) hop), so the warm-up is that one block, and it has the shape of
+  // a loop pass: [rows b_w, b_w+1 | block b_w] in lockstep, product, then [inverse | rows of the first pair] in lockstep.
+  // An utterance's first run has no predecessor: a zero block, and row 0 twice (Gc = H_0).
+  // What the first transform needs is fetched first.
+  const int bw = 2 * q_first - 1;
+  const TapRow pa = load_taps(bw > 0 ? bw : 0), pb = load_taps(bw + 1);
+  const Blk px = load_blk(bw >= 0 ? bw : g.F);
+  TapRow t1 = load_taps(2 * q_first + 1), t2 = load_taps(2 * q_first + 2);
+  Blk x0 = load_blk(2 * q_first), x1 = load_blk(2 * q_first + 1);
+  f32x2 Ga[S], Gb[S], Gc[S];
   {
-    f32x2 Gdrop[S];
-    split_taps(load_taps(2 * q0), load_taps(2 * q0 + 1), Gc, Gdrop);
+    f32x2 zt[S], zx[S];
+    pack_taps(pa, pb, zt);
+    pack_blk(px, bw >= 0, zx);
+    PL::template forward_s2<true>(zt, zx, tw, bA, bC, bB, bD, tid);
+    park(zt, bA);
+    park(zx, bB);
+    __syncthreads();
+    f32x2 G1[S];
+    split_taps(zt, bA, G1, Gc);                                 // H_b_w, H_b_w+1 -- the second is the loop's first Gc
+#pragma unroll
+    for (int m = 0; m < S; ++m)                                 // the odd block of a pair rides in the imaginary part
+      zx[m] = fft::conj_minus_i_conj(f32x2{0.f, 0.f}, filtered(zx[m], bB, m, G1[m], Gc[m]));
+    pack_taps(t1, t2, zt);
+    PL::transposed_and_forward_s(zx, zt, tw, bC, bA, bD, bB, tid);
+    park(zt, bC);
+    __syncthreads();
+    split_taps(zt, bC, Ga, Gb);
+    // block b_w sits where the second block of a pair does: slots (2 + m) & 7; its first four belong to the predecessor
+#pragma unroll
+    for (int m = 4; m < S; ++m) ring[(2 + m) & 7] = -zx[m].y;
   }
-  TapRow t1 = load_taps(2 * q0 + 1), t2 = load_taps(2 * q0 + 2);
-  Blk x0 = load_blk(2 * q0), x1 = load_blk(2 * q0 + 1);
 
-  for (int q = q0; q < q_last; ++q) {
+  BLK_STAMP(2);
+  // The two waves that share a SIMD belong to different workgroups, and its arbiter serves the older one first: left
+  // alone, one workgroup of each such pair runs ahead and finishes early, and its partner does the rest of its run at
+  // single-wave throughput (tools/fir_blk_timeline.py: lifetimes of 83 / 105 us inside one CU).  The waves take turns
+  // instead: priority 1 on alternate pairs, the phase taken from the wave slot.
+  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
+  for (int q = q_first; q < q_last; ++q) {
+    if (g.turns && ((q + turn) & 1)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     const int b0 = 2 * q;
-    const TapRow ct1 = t1, ct2 = t2;
-    const Blk cx0 = x0, cx1 = x1;
-    // the next pair's global loads are issued now and land while this pair is transformed
+    const bool stamp_it = q - q_first == 5;
+    if (stamp_it) BLK_STAMP_CYC(24);
+    f32x2 z0[S], z1[S];
+    pack_blk(x0, b0 < g.F, z0);
+    pack_blk(x1, b0 + 1 < g.F, z1);
+    // fetched now: the tap rows of the next pair (their transform rides beside this pair's inverse) and its blocks
     t1 = load_taps(b0 + 3);
     t2 = load_taps(b0 + 4);
     x0 = load_blk(b0 + 2);
     x1 = load_blk(b0 + 3);
-
-    f32x2 Ga[S], Gb[S];
-    split_taps(ct1, ct2, Ga, Gb);                               // H_b0+1, H_b0+2
-
-    // The two block transforms of the pair run in lockstep (Plan::forward_s2): one set of barriers for both, and each
-    // wave has the other block's butterflies to issue while one block's LDS round trip is in flight.
-    f32x2 z0[S], z1[S];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const Blk& cx = h == 0 ? cx0 : cx1;
-      const bool live = b0 + h < g.F;
-      f32x2 (&z)[S] = h == 0 ? z0 : z1;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float xv = cx.v[m];
-        if ((RNG || x_is_u01) && live) xv = fmaf(2.0f, xv, -1.0f);   // noise = rand*2-1 (vocoder.py:603,854); uniform condition
-        const float lam = (float)(P * m + tid) * inv_hop;
-        z[m] = f32x2{(1.0f - lam) * xv, lam * xv};               // the two Bartlett halves (core.py:161)
-      }
-#pragma unroll
-      for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
-    }
-    f32x2* const Xa = ex[cur];
-    f32x2* const Xb = ex[2 + cur];
-    PL::template forward_s2<true>(z0, z1, tw, Xa, ex[cur ^ 1], Xb, ex[2 + (cur ^ 1)], tid);
-#pragma unroll
-    for (int m = 0; m < S; ++m) { Xa[kS0 + 64 * m] = z0[m]; Xb[kS0 + 64 * m] = z1[m]; }
+    PL::template forward_s2<true>(z0, z1, tw, bA, bC, bB, bD, tid);
+    park(z0, bA);
+    park(z1, bB);
     __syncthreads();
-    cur ^= 1;
+    if (stamp_it) BLK_STAMP_CYC(25);
     f32x2 V[S];
 #pragma unroll
     for (int m = 0; m < S; ++m) {
-      const int k = kS0 + 64 * m;
-      const int kn = (NF - k) & (NF - 1);
-      // Y = X1 H_b + X2 H_b+1 = p G_b - i d G_b+1 with p = 2 X1, d = 2i X2 from the packed block transform
-      const f32x2 za = Xa[kn], zb = Xb[kn];
-      const f32x2 y0 = fft::add_mi(cmul(fft::add_conj(z0[m], za), Gc[m]), cmul(fft::sub_conj(z0[m], za), Ga[m]));
-      const f32x2 y1 = fft::add_mi(cmul(fft::add_conj(z1[m], zb), Ga[m]), cmul(fft::sub_conj(z1[m], zb), Gb[m]));
+      const f32x2 y0 = filtered(z0[m], bA, m, Gc[m], Ga[m]);
+      const f32x2 y1 = filtered(z1[m], bB, m, Ga[m], Gb[m]);
       V[m] = fft::conj_minus_i_conj(y0, y1);                    // V = Y_b0 + i Y_b0+1, conjugated for the inverse-by-forward trick
     }
     // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform.  Emitted times
-    // of this thread: t = e0 + 128 i, i = 0..7.  From the second pair of an utterance on e0 >= 0, so the byte offset is
-    // 4 e0 plus an instruction immediate; the first pair (e0 < 0 for some lanes) forms every offset in full.
-    const bool own = q >= q_first;
-    const int e0 = (b0 - 1) * FB_HOP + 256 + tid;               // first emitted time of this thread
-    auto t_off = [&](int i) -> int {
-      if (b0 > 0) return 4 * e0 + 4 * P * i;
-      const int t = e0 + P * i;
-      return t >= 0 ? 4 * t : BufF32::kOutOfRange;
-    };
+    // of this thread: t = e0 + 128 i, i = 0..7 (and 8..11 for the flush).  e0 >= -256, and negative times are exactly
+    // i = 0, 1 of an utterance's first pair -- for every lane -- so those two take a base that a scalar select turns into
+    // the out-of-range constant, and the rest a base that is never negative: no per-lane clamps, no branches, and no
+    // negative offset that an instruction immediate could carry back into range.
+    const int e0 = b0 * FB_HOP - 256 + tid;                     // first emitted time of this thread
+    const int off_a = b0 > 0 ? 4 * e0 : BufF32::kOutOfRange;
+    const int off_b = 4 * e0 + 8 * P;
+    auto t_off = [&](int i) -> int { return i < 2 ? off_a + 4 * P * i : off_b + 4 * P * (i - 2); };
     float add[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));   // 0 without an addend (empty descriptor)
-    // back to time order: the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid.
-    // No barrier follows (the overlap-add ring is thread-private): its second buffer may still be read by the slower
-    // wave, its first -- ex[cur] -- is free again, which is what the next transform expects
-    PL::transposed(V, tw, ex[cur], ex[cur ^ 1], tid);
-    // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb-1) hop + n.
+    for (int i = 0; i < S; ++i) add[i] = 0.f;
+    if (has_addend) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));
+    }
+    if (stamp_it) BLK_STAMP_CYC(26);
+    // back to time order (the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid),
+    // beside the transform of the next pair's tap rows b0 + 3, b0 + 4
+    f32x2 zt[S];
+    pack_taps(t1, t2, zt);
+    PL::transposed_and_forward_s(V, zt, tw, bC, bA, bD, bB, tid);
+    park(zt, bC);
+    __syncthreads();
+    if (stamp_it) BLK_STAMP_CYC(27);
+    // the spectrum of tap row b0 + 2 moves on to the next pair as its first
+#pragma unroll
+    for (int m = 0; m < S; ++m) Gc[m] = Gb[m];
+    split_taps(zt, bC, Ga, Gb);
+    if (stamp_it) BLK_STAMP_CYC(28);
+    // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb - 1/2) hop + n.
     const bool last = q == g.pairs - 1;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      constexpr int kRot[2] = {4, 0};                           // ring slot of transform index 128 m: (4 (h+1) + m) & 7
+      constexpr int kRot[2] = {6, 2};                           // ring slot of transform index 128 m: (4 h - 2 + m) & 7
 #pragma unroll
       for (int m = 0; m < S; ++m) ring[(kRot[h] + m) & 7] += h == 0 ? V[m].x : -V[m].y;
-      // times below (bb+1) hop - N/2 are final once block bb is in: emit indices 128 (2 + m), m = 0..3, i.e. emitted
-      // sample i = 4 h + m of the pair; stores outside [0, T) are dropped by the descriptor
+      // times below (bb + 1/2) hop are final once block bb is in (the next block's result starts there): emit indices
+      // 128 m, m = 0..3, i.e. emitted sample i = 4 h + m of the pair; stores outside [0, T) are dropped by the descriptor
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int ri = (kRot[h] + 2 + m) & 7;
+        const int ri = (kRot[h] + m) & 7;
         const float v = ring[ri];
         ring[ri] = 0.f;
-        if (own) {
-          const int off = t_off(4 * h + m);
-          plain_buf.st(v, off);                                  // empty descriptor unless out_plain was asked for
-          out_buf.st(v + add[4 * h + m], off);
-        }
+        const int off = t_off(4 * h + m);
+        if (has_plain) plain_buf.st(v, off);
+        out_buf.st(v + add[4 * h + m], off);
       }
     }
-    if (last && own) {                                          // the last pair also flushes what is left of the ring
+    if (last) {                                                 // the last pair also flushes what is left of the ring
 #pragma unroll
       for (int m = 4; m < S; ++m) {
         const int ri = (2 + m) & 7;
-        const int off = t_off(4 + m);                           // t = (b0 + 1 - 1) hop + 256 + 128 m + tid
+        const int off = t_off(4 + m);                           // t = (b0 + 1/2) hop + 128 m + tid
         const float v = ring[ri];
-        plain_buf.st(v, off);
-        out_buf.st(v + add_buf.ld(off), off);
+        if (has_plain) plain_buf.st(v, off);
+        out_buf.st(v + (has_addend ? add_buf.ld(off) : 0.f), off);
       }
     }
-    // hand the spectrum of tap row b0 + 2 to the next pair (unrolling the loop by two with swapped roles instead of these
-    // 16 moves needs 256 registers and spills 9)
-#pragma unroll
-    for (int m = 0; m < S; ++m) Gc[m] = Gb[m];
+    if (stamp_it) BLK_STAMP_CYC(29);
+    BLK_STAMP(3 + q - q_first);
   }
 }
 
@@ -286,14 +346,14 @@ int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int
 // returns the implementation id (5) or < 0 when the shape is outside this kernel
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen) {
-  if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 29)) return -1;   // byte offsets of one utterance stay below 2^31 (buffer descriptors)
+  if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance stays below 2^30 bytes (buffer descriptors, BufF32::kOutOfRange)
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 1) / 2;
   int wps = 2;
   if (const long v = knob(KNOB_BLK_WPS)) { if (v >= 1) wps = (int)v; }
   // run length: as many workgroups as the chip holds at once (2 waves each), one round, equal work; every run
-  // pays one warm-up pair and one extra half transform
+  // but an utterance's first pays one warm-up block (three transforms; a pair costs four)
   const long slots = (long)wps * 2 * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
@@ -303,6 +363,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
+  g.turns = knob(KNOB_BLK_TURNS) == 1 ? 0 : 1;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
@@ -327,3 +388,10 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
 }
 
 }  // namespace ddsp
+
+#ifdef DDSP_HIP_TIMELINE
+extern "C" int ddsp_hip_debug_set_blk_timeline(long long* p, void* stream) {
+  hipLaunchKernelGGL(ddsp::k_set_blk_timeline, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+#endif

@@ -177,6 +177,7 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) {
   return hipemu::peek<int>(s, lane);
 }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) (0)          /* hardware status registers: placement only, never data */
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_s_barrier() __syncthreads()

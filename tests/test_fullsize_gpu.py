@@ -85,7 +85,7 @@ def test_fir_forms_agree(cuda, batch):
     g = torch.Generator().manual_seed(4)
     taps = (torch.randn(B, F, N, generator=g) / N ** 0.5 * torch.rand(B, F, 1, generator=g) * 4).to(cuda)
     y3, y4 = core.fft_convolve(x, taps, impl=3), core.fft_convolve(x, taps, impl=4)
-    assert rms(y3 - y4) <= 1.5e-6 * rms(y3)
+    assert rms(y3 - y4) <= 1.5e-6 * rms(y3), ("direct vs per-frame FFT form", rms(y3 - y4), rms(y3))
     u = (x + 1) / 2
     add = torch.roll(x, 5, 1)
     out, plain = torch.empty_like(x), torch.empty_like(x)
@@ -93,8 +93,8 @@ def test_fir_forms_agree(cuda, batch):
                                                 plain.data_ptr(), B, F, HOP, N, 4, _ffi.stream_of(u)))
     x_re = torch.addcmul(torch.full_like(u, -1.0), u, torch.full_like(u, 2.0))     # 2u-1 as fma, like the kernel
     ref = core.fft_convolve(x_re, taps, impl=3)
-    assert rms(plain - ref) <= 1.5e-6 * rms(ref)
-    assert rms(out - (plain + add)) <= 1e-7 * rms(out)
+    assert rms(plain - ref) <= 1.5e-6 * rms(ref), ("2u-1 in the load path", rms(plain - ref), rms(ref))
+    assert rms(out - (plain + add)) <= 1e-7 * rms(out), ("addend", rms(out - (plain + add)), rms(out))
 
 
 @pytest.mark.parametrize("kind", ["combsub", "sins"])
