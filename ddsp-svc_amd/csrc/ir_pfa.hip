@@ -28,11 +28,25 @@ namespace ddsp {
 using fft::add_mi;
 using fft::sub_mi;
 
+#ifdef DDSP_HIP_TIMELINE
+// diagnostics build only (tools/pfa_timeline.py): per-workgroup wall-clock stamps (100 MHz)
+__device__ long long* g_pfa_timeline = nullptr;
+__global__ void k_set_pfa_timeline(long long* p) { g_pfa_timeline = p; }
+#define PFA_STAMP(slot) do { if (g_pfa_timeline && threadIdx.x == 0) g_pfa_timeline[(long)blockIdx.x * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define PFA_STAMP(slot) do { } while (0)
+#endif
+
 namespace pfa {
 
 constexpr int NB = 256, NT = 510, HALF = 255;
 constexpr int ROWS = 16, TR = 8;                 // frames and transforms per batch
-constexpr int WSTRIDE = 31;                      // complex words per (t, k1) row of W: odd, so 8-byte accesses spread over the banks
+// W[t][k1][n2], complex: row (t, k1) = 30 words, plus one pad word every 16 rows -- the 32 rows a 32-lane LDS access of stage B
+// touches then start in 32 different bank pairs (30 words = 60 banks = -4 mod 64: 16 rows a revolution, the pad shifts the
+// next 16 by one pair) -- and the array fits the 32 KiB the staged rows need anyway.  (Four workgroups per CU either way: a
+// fifth needs <= 31 744 B per workgroup, tools/probes/lds_occupancy.hip, and the 16 x 510 output staging alone is 32 640.)
+constexpr int WSTRIDE = 30;
+__device__ __forceinline__ int w_row(int row) { return row * WSTRIDE + (row >> 4); }
 constexpr int KIND_REAL = 0, KIND_COMPLEX = 1, KIND_ALLPASS = 2;
 enum { MODE_ROLL = 0, MODE_HANN = 1, MODE_DYNAMIC = 2 };
 
@@ -157,10 +171,12 @@ __device__ __forceinline__ float div_by_row(float a, float b, float rb) {
   return q;
 }
 
-// One LDS region, used three times: rows re[16][256] (+ im[16][256]) -> W[8][17][31] complex -> O[16][510]
-constexpr int W_WORDS = TR * 17 * WSTRIDE;                                // complex words: 33 728 B, the largest of the three
-constexpr int U_FLOATS = 2 * W_WORDS;
-static_assert(U_FLOATS >= 2 * ROWS * NB && U_FLOATS >= ROWS * NT, "union region too small");
+// One LDS region of 32 KiB, used three times: rows re[16][256] (+ im[16][256]) -> W[8][17][30+] complex -> O[16][510] followed
+// by the 16 rows' window half widths and their reciprocals (MODE_DYNAMIC)
+constexpr int W_WORDS = TR * 17 * WSTRIDE + (TR * 17 + 15) / 16;          // complex words
+constexpr int U_FLOATS = 2 * ROWS * NB;                                   // 8192 floats
+constexpr int HW_AT = ROWS * NT;                                          // 8160: hw[16], then 1/hw[16]
+static_assert(U_FLOATS >= 2 * W_WORDS && U_FLOATS >= HW_AT + 2 * ROWS, "union region too small");
 
 }  // namespace pfa
 
@@ -178,6 +194,7 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
   f32x2* W = reinterpret_cast<f32x2*>(U);
   float* O = U;
   const float inv_n = 1.0f / (float)NT;
+  PFA_STAMP(0);
 
   // ---- stage 0: rows -> LDS, activated and scaled by 1/N.  irfft drops Im(DC) and Im(Nyquist) (core.py:259) ----
   if (KIND == KIND_ALLPASS) {
@@ -255,6 +272,7 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     }
   }
   __syncthreads();
+  PFA_STAMP(1);
 
   // ---- stage A: DFT-17 over n1 of Z[(30 n1 + 17 n2) mod 510], Z = X_a + i X_b, X[510 - k] = conj X[k] ----
   {
@@ -284,12 +302,12 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     __syncthreads();                                       // every thread holds its inputs: the rows may be overwritten
     if (act) {
       dft17(z);
-      f32x2* dst = W + (t * 17) * WSTRIDE + n2;
 #pragma unroll
-      for (int k1 = 0; k1 < 17; ++k1) dst[k1 * WSTRIDE] = z[k1];
+      for (int k1 = 0; k1 < 17; ++k1) W[w_row(t * 17 + k1) + n2] = z[k1];
     }
   }
   __syncthreads();
+  PFA_STAMP(2);
 
   // ---- stage B: DFT-30 over n2; output index m = (120 k1 + 391 k2) mod 510; roll by N/2: tap j = (m + 255) mod 510 ----
   {
@@ -297,11 +315,22 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     const int t = act ? tid / 17 : 0, k1 = act ? tid - 17 * t : 0;
     f32x2 v[30];
     {
-      const f32x2* src = W + (t * 17 + k1) * WSTRIDE;
+      const f32x2* src = W + w_row(t * 17 + k1);
 #pragma unroll
       for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
     }
+    float hw_row = 1.f;
+    if (MODE == MODE_DYNAMIC && tid < ROWS) {              // the batch's 16 half widths: in flight across the barrier
+      const long gr = row0 + tid;
+      if (gr < rows) hw_row = half_width[gr];
+    }
     __syncthreads();                                       // W is in registers: the region becomes the output staging
+    if (MODE == MODE_DYNAMIC && tid < ROWS) {
+      float x = hw_row;
+      if (hw_sr > 0.f) x = (1.5f * hw_sr) / (x + 1e-3f);   // vocoder.py:851, same float32 operations
+      U[HW_AT + tid] = x;
+      U[HW_AT + ROWS + tid] = 1.0f / x;
+    }
     if (act) {
       dft30(v);
       float* oa = O + (2 * t) * NT;
@@ -317,32 +346,48 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     }
   }
   __syncthreads();
+  PFA_STAMP(3);
 
   // ---- stage C: window and store; the batch's 16 x 510 taps are one contiguous, 16-byte aligned stretch.  A thread's
-  // groups of four are 1024 floats apart: row + 2, tap + 4 (mod 510) ----
+  // groups of four are 1024 floats apart: row + 2, tap + 4 (mod 510).  Eight groups per thread, unrolled: the window
+  // values of all eight are fetched first (MODE_HANN) or come from LDS (MODE_DYNAMIC), so a memory latency is paid once
+  // and not once per group (tools/pfa_timeline.py: stage C 3.5 -> 2.2 us and 4.9 -> 4.0 us) ----
   float* dst = taps + row0 * NT;
   const long total = rows * (long)NT - row0 * NT;         // floats left in the tensor from this batch on
-  int r = (4 * tid) / NT, j = 4 * tid - r * NT;
-  for (int i4 = tid; i4 < ROWS * NT / 4; i4 += 256) {
-    const int i = 4 * i4;
+  constexpr int GROUPS = (ROWS * NT / 4 + 255) / 256;     // 8; the last one is partial
+  const int r0 = (4 * tid) / NT, j0 = 4 * tid - r0 * NT;
+  int rr[GROUPS], jj[GROUPS];
+#pragma unroll
+  for (int it = 0; it < GROUPS; ++it) {
+    const int j = j0 + 4 * it;
+    const bool c = j >= NT;
+    jj[it] = c ? j - NT : j;
+    rr[it] = r0 + 2 * it + (c ? 1 : 0);
+  }
+  float2 wa[GROUPS], wb[GROUPS];
+  if (MODE == MODE_HANN) {
+#pragma unroll
+    for (int it = 0; it < GROUPS; ++it) {
+      const int j = jj[it];
+      const int j2 = j + 3 >= NT ? 0 : j + 2;              // j is even: a group straddles a row end only at j = 508
+      wa[it] = *reinterpret_cast<const float2*>(hann + j);
+      wb[it] = *reinterpret_cast<const float2*>(hann + j2);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < GROUPS; ++it) {
+    const int i4 = tid + 256 * it;
+    if (it == GROUPS - 1 && i4 >= ROWS * NT / 4) break;
+    const int i = 4 * i4, j = jj[it], r = rr[it];
     const float4 o = *reinterpret_cast<const float4*>(O + i);
     float ov[4] = {o.x, o.y, o.z, o.w};
-    const bool wrap = j + 3 >= NT;                         // j is even: the group straddles a row end only at j = 508
+    const bool wrap = j + 3 >= NT;
     if (MODE == MODE_HANN) {
-      const int j2 = wrap ? 0 : j + 2;
-      const float2 wa = *reinterpret_cast<const float2*>(hann + j);
-      const float2 wb = *reinterpret_cast<const float2*>(hann + j2);
-      ov[0] *= wa.x; ov[1] *= wa.y; ov[2] *= wb.x; ov[3] *= wb.y;
+      ov[0] *= wa[it].x; ov[1] *= wa[it].y; ov[2] *= wb[it].x; ov[3] *= wb[it].y;
     } else if (MODE == MODE_DYNAMIC) {
-      float hv[2], rb[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const long gr = row0 + r + h;
-        float x = (gr < rows && (h == 0 || wrap)) ? half_width[gr] : 1.f;
-        if (hw_sr > 0.f) x = (1.5f * hw_sr) / (x + 1e-3f);               // vocoder.py:851, same float32 operations
-        hv[h] = x;
-        rb[h] = 1.0f / x;
-      }
+      const int r1 = wrap ? r + 1 : r;                      // (a straddling group never reaches row 16: it would start past the batch)
+      const float hv[2] = {U[HW_AT + r], U[HW_AT + r1]};
+      const float rb[2] = {U[HW_AT + ROWS + r], U[HW_AT + ROWS + r1]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool nx = wrap && e >= 2;
@@ -359,9 +404,8 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
       for (int e = 0; e < 4; ++e)
         if (i + e < total) dst[i + e] = ov[e];
     }
-    j += 4; r += 2;
-    if (j >= NT) { j -= NT; r += 1; }
   }
+  PFA_STAMP(4);
 }
 
 // returns 0 when the fast form took the call, -1 when the shape is not its (the caller then uses the dense contraction)
@@ -398,3 +442,10 @@ int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld
 }
 
 }  // namespace ddsp
+
+#ifdef DDSP_HIP_TIMELINE
+extern "C" int ddsp_hip_debug_set_pfa_timeline(long long* p, void* stream) {
+  hipLaunchKernelGGL(ddsp::k_set_pfa_timeline, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+#endif
