@@ -88,9 +88,6 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 
   BLK_STAMP(0);
   BLK_STAMP_WHERE(31);
-  typename PL::Tw tw;
-  tw.init(tid);
-  BLK_STAMP(1);
   // Overlap-add ring: 1024 samples, of which a thread only ever touches the 8 congruent to its id -- they live in
   // registers.  Transform index n = 128 m + tid of block bb is time (bb - 1/2) hop + n, i.e. ring slot (4 bb - 2 + m) mod 8:
   // a pair advances the ring by exactly one revolution, so every slot index below is a compile-time constant.
@@ -201,6 +198,9 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   const Blk px = load_blk(bw >= 0 ? bw : g.F);
   TapRow t1 = load_taps(2 * q_first + 1), t2 = load_taps(2 * q_first + 2);
   Blk x0 = load_blk(2 * q_first), x1 = load_blk(2 * q_first + 1);
+  typename PL::Tw tw;                                           // the twiddles are formed while those loads are in flight
+  tw.init(tid);
+  BLK_STAMP(1);
   f32x2 Ga[S], Gb[S], Gc[S];
   {
     f32x2 zt[S], zx[S];
