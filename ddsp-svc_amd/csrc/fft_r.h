@@ -50,13 +50,16 @@ struct Plan {
     dft8(v);
 #pragma unroll
     for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+    // R = 2: a row of the second pass is 16 words, so the two rows k1, k1 + 1 that a 32-lane read touches would start in
+    // the same banks; odd rows are stored with their 16-blocks swapped in pairs (R = 4: 32-word rows, nothing to do)
+    constexpr int SW = R == 2 ? C : 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) A[k * P + tid] = v[k];                              // [k1][p]
+    for (int k = 0; k < 8; ++k) A[k * P + (tid ^ ((k & 1) * SW))] = v[k];            // [k1][p]
     __syncthreads();
     {
       const int k1 = tid / C, c = tid & (C - 1);
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + n2 * C + c];
+      for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + (R == 2 ? (n2 ^ (k1 & 1)) : n2) * C + c];
       dft8(v);
 #pragma unroll
       for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);

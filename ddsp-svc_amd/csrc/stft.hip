@@ -189,10 +189,11 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   float ring[S];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
-  const int run_no = blockIdx.x - b * g.runs_per_utt;
-  const int p_first = run_no * g.run;
-  int p_last = p_first + g.run;
-  if (p_last > g.pairs) p_last = g.pairs;
+  // an utterance's pairs are split evenly over its runs, and the run number is rotated by the utterance number so that
+  // the longer and the shorter runs spread over XCDs and CUs (as in k_fir_blk, fir_blk.hip)
+  const int run_no = (int)((blockIdx.x - b * g.runs_per_utt + b + (b >> 4) + (b >> 8)) % g.runs_per_utt);
+  const int p_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);
+  const int p_last = (int)(((long)(run_no + 1) * g.pairs) / g.runs_per_utt);
   const long ob = (long)b * g.T;
   const float* eb = exc + ob;
   const float* nb = noise + ob;
@@ -215,7 +216,11 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   // at the top of every pair (an odd first pair starts rotated).
   constexpr int BASE = 4;
   constexpr int STEP = ST_HOP / P;                             // slots between the two frames of a pair
+  // the waves that share a SIMD (of different workgroups) take turns at its arbiter's priority, pair by pair (fir_blk.hip)
+  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
   for (int pr = pr0; pr < p_last; ++pr) {
+    if ((pr + turn) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     f32x2 V[S];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
