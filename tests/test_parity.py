@@ -331,6 +331,27 @@ def test_fft_convolve_fft_form(dev, B, F, N, run, impl, knobs):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F,N", [(3, 45, 510), (2, 16, 254), (1, 5, 512)])
+def test_fft_convolve_hop_block_scheduling(dev, B, F, N, knobs):
+    """what only schedules the hop-block kernel leaves its result alone: the waves' turn-taking (knob BLK_TURNS) bit for bit;
+    the even split of an utterance's pairs over its runs against one run per utterance to rounding (a run's first tap
+    spectrum comes out of a differently packed transform), with runs of unequal length and a warm-up block in every one"""
+    from ddsp_svc_amd import core
+    rng = np.random.default_rng(F * 7 + N)
+    x = T_((rng.random((B, F * HOP)) * 2 - 1).astype(np.float32), dev)
+    ir = T_((rng.standard_normal((B, F, N)) / np.sqrt(N)).astype(np.float32), dev)
+    knobs("BLK_RUN", 4)                                     # e.g. 23 pairs -> six runs of 3 or 4 pairs
+    y = core.fft_convolve(x, ir, impl=5)
+    knobs("BLK_TURNS", 1)
+    assert torch.equal(core.fft_convolve(x, ir, impl=5), y)
+    knobs("BLK_RUN", 1 << 20)                               # one run per utterance
+    one = core.fft_convolve(x, ir, impl=5)
+    assert rms(N_(one) - N_(y)) <= 3e-7 * rms(N_(one))
+    ref = O.ltv_fir_direct(N_(x), N_(ir))
+    assert rms(N_(y) - ref) <= 2e-6 * rms(ref)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_fft_convolve_errors(dev):
     from ddsp_svc_amd import core
     a = torch.zeros(2, 1024, device=dev)
