@@ -7,6 +7,8 @@ V=${V:-box}
 {
   echo "== idle"; rocm-smi --showclocks --showperflevel --showpower --showmemuse 2>&1 | grep -v "^$" | head -40
   rocm-smi --showclkfrq 2>&1 | grep -E "\*|Supported" | head -30
+  echo "== partitions"; rocm-smi --showmemorypartition --showcomputepartition 2>&1 | grep -i "partition" | head -6; cat /sys/class/drm/card*/device/current_memory_partition /sys/class/drm/card*/device/current_compute_partition 2>/dev/null | tr "\n" " "; echo
+  rocm-smi --showtopo 2>&1 | grep -i "numa" | head -4
   echo "== kernel params"; cat /proc/cmdline; cat /sys/module/amdgpu/parameters/noretry /sys/module/amdgpu/parameters/vm_fragment_size /sys/module/amdgpu/parameters/sched_policy 2>&1 | tr '\n' ' '; echo
   cat /sys/kernel/mm/transparent_hugepage/enabled 2>&1
   echo "== under load"
