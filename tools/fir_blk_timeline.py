@@ -30,6 +30,10 @@ if "--build" in sys.argv or not os.path.exists(so):
     if "--build" in sys.argv:
         sys.exit(0)
 L = _ffi.bind(ctypes.CDLL(so))
+for kv in sys.argv[1:]:
+    if "=" in kv:
+        k, v = kv.split("=")
+        assert L.ddsp_hip_set_tuning(k.encode(), int(v)) == 0, kv
 L.ddsp_hip_debug_set_blk_timeline.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda:0")
 B, F, n, HOP = 64, 431, 256, 512
