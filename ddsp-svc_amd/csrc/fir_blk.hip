@@ -50,7 +50,6 @@ struct FirBlkGeom {
   int pairs;              // block pairs per utterance: ceil(F / 2)
   int run, runs_per_utt;  // most pairs a workgroup owns; workgroups per utterance
   int turns;              // waves sharing a SIMD alternate priority (knob BLK_TURNS: 1 = off)
-  int xcd_map;            // knob BLK_XCDMAP
 };
 
 // RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
@@ -63,14 +62,11 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   constexpr int NF = PL::N, P = PL::P, S = 8;                  // 1024 points, 128 threads, 8 points per thread
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];   // two ping-pong pairs: ex[0..1] every transform, ex[2..3] the second of a lockstep pair
   const int tid = threadIdx.x;
-  // experiment (knob BLK_XCDMAP): workgroups are dealt to the XCDs round-robin (blockIdx % 8); with the map each XCD
-  // works on one contiguous eighth of the batch instead of on every eighth run of all of it
-  const unsigned bid = g.xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int b = (int)(bid / (unsigned)g.runs_per_utt);
+  const int b = blockIdx.x / g.runs_per_utt;
   // which run of the utterance: rotated by the utterance number (and by its higher digits), so that the longer and the
   // shorter runs of the even split below line up neither with the XCD round-robin of the dispatcher (blockIdx % 8) nor
   // with the workgroups a CU collects (blockIdx 256 apart at the headline shape): every CU gets a mix
-  const int run_no = (int)((bid - b * g.runs_per_utt + (g.xcd_map ? (b >> 1) : b + (b >> 4) + (b >> 8))) % g.runs_per_utt);
+  const int run_no = (int)((blockIdx.x - b * g.runs_per_utt + b + (b >> 4) + (b >> 8)) % g.runs_per_utt);
   // an utterance's pairs are split evenly over its runs (lengths differ by at most one: workgroups that share a SIMD
   // then finish together instead of leaving it half empty)
   const int q_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);
@@ -368,7 +364,6 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
   g.turns = knob(KNOB_BLK_TURNS) == 1 ? 0 : 1;
-  g.xcd_map = (knob(KNOB_BLK_XCDMAP) == 1 && ((long)B * g.runs_per_utt) % 8 == 0) ? 1 : 0;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};

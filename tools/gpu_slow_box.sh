@@ -6,10 +6,6 @@ V=${V:-slow}
 {
   echo "== translation probe"; timeout 60 tools/ab/tlb_probe.bin
   echo "== timeline, default map"; timeout 100 python tools/fir_blk_timeline.py 2>&1 | grep -E "launch|prologue|pair  0|pair  1:|end  "
-  echo "== timeline, BLK_XCDMAP=1"; timeout 100 python tools/fir_blk_timeline.py BLK_XCDMAP=1 2>&1 | grep -E "launch|prologue|pair  0|pair  1:|end  "
-  for rep in 1 2; do
-    for k in 0 1; do
-      DDSP_HIP_BLK_XCDMAP=$k timeout 200 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('xcdmap $k step ms', round(d['ms_per_step'],4), 'fir', round(d['roofline']['avg_ms'],4))"
-    done
-  done
+  echo "== first-launch effect"; timeout 200 python tools/fir_cold_start.py
+  timeout 200 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step ms', round(d['ms_per_step'],4), 'fir', round(d['roofline']['avg_ms'],4))"
 } 2>&1 | tee "$O/${V}_slow_box.txt"
