@@ -883,8 +883,9 @@ def main():
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": fir_bytes, "avg_ms": fir_ms, "launches_per_step": fir_launches,
                          "note": "north-star roofline (algorithmic HBM bytes / time; avg_ms from HIP events around 20 "
-                                 "back-to-back launches, i.e. including the inter-launch gap: the kernel trace reads "
-                                 "~10 % less).  The kernel is NOT HBM-bound: see roofline_compute for the roof that "
+                                 "back-to-back launches of the kernel on resident data; inside a step, after other "
+                                 "kernels, the rocprofv3 trace reads a few per cent more: profiles/*_kernel_stats.csv).  "
+                                 "The kernel is NOT HBM-bound: see roofline_compute for the roof that "
                                  "binds it (DESIGN.md section 5)"},
             "roofline_compute": (
                 {"kernel": kname, "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
