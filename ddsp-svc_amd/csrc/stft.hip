@@ -137,6 +137,39 @@ __global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict_
   }
 }
 
+// The same for hop % 4 == 0 (every shipped configuration) without the index arithmetic of the general form: the grid's
+// second dimension is the utterance (no 64-bit division of a flat sample index), the frame of a thread's four samples
+// is a shift when the hop is a power of two, and the two divisions by float(hop) of the recipe (vocoder.py:643-644)
+// are then exact multiplications by its reciprocal -- bit-identical, and 2.5 instead of 5.5 division sequences per
+// sample.  The divisions that round (f0 / sr, rad / (s0 + 1e-5)) stay IEEE divisions.
+template <bool POW2>
+__global__ void __launch_bounds__(256) k_fast_combtooth4(const float* __restrict__ f0_frames,
+                                                         const float* __restrict__ rad_acc, FastSrc cfg, int T,
+                                                         int shift, float* __restrict__ out) {
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= T) return;
+  const long b = blockIdx.y;
+  const int f = POW2 ? t >> shift : (int)((unsigned)t / (unsigned)cfg.hop);
+  const int n = t - f * cfg.hop;
+  float s0, ds0;
+  cfg.frame(f0_frames + b * cfg.F, f, s0, ds0);
+  const float acc = f > 0 ? rad_acc[b * cfg.F + f - 1] : 0.0f;
+  const float hopf = (float)cfg.hop, rhop = 1.0f / hopf;      // rhop is exact for POW2, unused otherwise
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float nf = (float)(n + r), n1 = (float)(n + r + 1);
+    const float q = ((0.5f * ds0) * nf) * n1;
+    float rad = s0 * n1 + (POW2 ? q * rhop : q / hopf);                              // :643
+    const float dn = ds0 * nf;
+    const float s0n = s0 + (POW2 ? dn * rhop : dn / hopf);                           // :644
+    rad = rad + acc;                                                                 // :647
+    rad = rad - rintf(rad);                                                          // :648
+    v[r] = sinc_f32(rad / (s0n + 1e-5f));                                            // :649
+  }
+  *reinterpret_cast<float4*>(out + b * (long)T + t) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the spectral filter itself
 // ------------------------------------------------------------------------------------------------
@@ -627,6 +660,16 @@ int launch_fast_combtooth(const float* f0_frames, const float* rad_acc, int B, i
   FastSrc cfg;
   cfg.sr = (float)sr; cfg.F = F; cfg.hop = hop;
   const long total = (long)B * F * hop;
+  if ((hop & 3) == 0 && B <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int T = F * hop;
+    int shift = 0;
+    while ((1 << shift) < hop) ++shift;
+    const bool pow2 = (1 << shift) == hop;
+    const dim3 grid((unsigned)((T + 1023) / 1024), (unsigned)B);
+    if (pow2) hipLaunchKernelGGL(k_fast_combtooth4<true>, grid, dim3(256), 0, st, f0_frames, rad_acc, cfg, T, shift, out);
+    else hipLaunchKernelGGL(k_fast_combtooth4<false>, grid, dim3(256), 0, st, f0_frames, rad_acc, cfg, T, shift, out);
+    return 0;
+  }
   const long blocks = (total + 1023) / 1024;
   if (blocks > 0x7fffffffL) return -1;
   hipLaunchKernelGGL(k_fast_combtooth, dim3((unsigned)blocks), dim3(256), 0, st, f0_frames, rad_acc, cfg, total, out);

@@ -47,12 +47,14 @@ def test_fast_source_golden(dev, golden_dir):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("B,F", [(1, 1), (2, 300), (1, 257)])
-def test_fast_source_shapes(dev, B, F):
+@pytest.mark.parametrize("B,F,hop", [(1, 1, HOP), (2, 300, HOP), (1, 257, HOP), (2, 37, 440), (1, 21, 441), (3, 9, 64)])
+def test_fast_source_shapes(dev, B, F, hop):
+    """hop 512 / 64: the four-samples-per-thread exciter kernel with a shift for the frame index and exact reciprocal
+    multiplications for the recipe's divisions by the hop; 440: the same kernel with true divisions; 441: the general form"""
     from ddsp_svc_amd import synth
-    f0 = O.synth_f0(B, F, SR, HOP, seed=F)
-    st = synth.fast_source(T_(f0, dev), SR, HOP, want_combtooth=True)
-    comb, pf, ra = O.fast_source_gen(f0, SR, HOP)
+    f0 = O.synth_f0(B, F, SR, hop, seed=F)
+    st = synth.fast_source(T_(f0, dev), SR, hop, want_combtooth=True)
+    comb, pf, ra = O.fast_source_gen(f0, SR, hop)
     assert np.array_equal(N_(st.rad_acc), ra)
     assert np.array_equal(N_(st.phase_frames)[..., 0], pf)
     assert np.abs(N_(st.combtooth) - comb).max() <= 3e-7
