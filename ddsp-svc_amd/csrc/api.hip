@@ -78,9 +78,8 @@ struct Carver {
 };
 
 struct SynthWs {
-  float *buf0, *buf1, *taps, *re, *im, *harm;
+  float *buf0, *buf1, *taps, *re, *im;
   float *taps_nz, *nzbuf;      // the noise branch's own taps and output when it runs on a second stream
-  float *taps_h;               // the second harmonic filter's taps when they are synthesised ahead on the second stream
 };
 
 // Fork / join of independent branches of a synthesiser tail onto a caller-provided second stream.  The events are
@@ -167,10 +166,8 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
     w.re = c.take<float>(R * n_max);
     w.im = c.take<float>(R * n_max);
   }
-  w.harm = w.buf0;
   w.taps_nz = c.take<float>(R * N);
   w.nzbuf = c.take<float>(BT);
-  w.taps_h = c.take<float>(R * N);
   return align_up(c.used, 256);
 }
 
@@ -417,43 +414,25 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
-  Branch br(st, aux_stream);
-  if (br.forked) {
-    // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
-    // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
-    const bool ap_ahead = n_ap == 256 && !knob(KNOB_TAPS_GEMM) && knob(KNOB_STREAM_LAYOUT) != 1;
-    if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
-    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-               n_nz, w.taps_nz, br.aux);
-    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                              br.aux, &gen);
-    if (!ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-    const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
-    br.join();                                           // always joined, also on the error paths below
-    if (r == -1) return DDSP_HIP_EHOP;
-    if (r == -2 || rn < 0) return DDSP_HIP_ESHAPE;
-    // harmonic = all-pass(sinusoids) (vocoder.py:597-600); signal = harmonic + noise (:609)
-    if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
-  }
-  // all-pass taps first (their response lives in buf0 until the exciter overwrites it)
-  synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-  // exciter: sinusoid bank (vocoder.py:585-594)
-  int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
-  if (r == -1) return DDSP_HIP_EHOP;
-  if (r == -2) return DDSP_HIP_ESHAPE;
-  // harmonic = all-pass(group delay) applied to the sinusoids (vocoder.py:597-600)
-  float* harmonic = harmonic_or_null ? harmonic_or_null : w.buf1;
-  if (launch_fir(w.buf0, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
-    return DDSP_HIP_ESHAPE;
-  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise, added to harmonic (vocoder.py:603-609)
+  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
+  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
+  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+  // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
+  // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
+  const bool ap_ahead = n_ap == 256 && !knob(KNOB_TAPS_GEMM) && knob(KNOB_STREAM_LAYOUT) != 1;
+  if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
   synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-             n_nz, w.taps, st);
-  if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                 st, &gen) < 0)
+             n_nz, w.taps_nz, br.aux);
+  const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                            br.aux, &gen);
+  if (!ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
+  // exciter: sinusoid bank (vocoder.py:585-594)
+  const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
+  br.join();                                           // always joined, also on the error paths below
+  if (r == -1) return DDSP_HIP_EHOP;
+  if (r == -2 || rn < 0) return DDSP_HIP_ESHAPE;
+  // harmonic = all-pass(sinusoids) (vocoder.py:597-600); signal = harmonic + noise (:609)
+  if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }
@@ -480,125 +459,46 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
-  Branch br(st, aux_stream);
-  // Stream layout of the two-stream call (knob STREAM_LAYOUT; 2-5 need every filter at 256 bins, otherwise the all-pass
-  // response aliases the exciter buffer and 1 is used).  1: the noise branch -- its taps and its filter -- on the second
-  // stream beside the harmonic chain, joined into the last filter as its addend.  4 (default): as 1 with the exciter on the
-  // second stream too, ahead of the noise branch, so the (vector-ALU bound) exciter overlaps the (latency bound) all-pass tap
-  // synthesis instead of following it.  5: + the second harmonic filter's taps there.  2 / 3: ALL taps ahead on the second
-  // stream while the first makes the exciter, with / without the noise filter itself on the second stream.
-  // Same-box A/Bs at B = 32 x 10 s, ms per step: 1 / 2 / 3 / one stream 0.414 / 0.424 / 0.424 / 0.428 (profiles/r02_v4_*);
-  // 1 / 4 / 5 0.401 / 0.388 / 0.403 (profiles/r02_v14_*).
+  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
+  // Stream layout (knob STREAM_LAYOUT).  1: the noise branch -- its taps and its filter -- on the second stream beside the
+  // harmonic chain, joined into the last filter as its addend.  4 (default where every filter has 256 bins; otherwise the
+  // all-pass response is staged in the exciter buffer and 1 is used): as 1 with the exciter on the second stream too, ahead
+  // of the noise branch, so the (vector-ALU bound) exciter runs beside the (latency bound) all-pass tap synthesis instead
+  // of after it.  Same-box A/Bs at B = 32 x 10 s, ms per step: 1 / 4 0.401 / 0.388 (profiles/r02_v14_*); three more that
+  // lost (all taps ahead on the second stream, 0.424; the second harmonic filter's taps there too, 0.403; the harmonic
+  // chain's front on the second stream, 0.439 against 0.422) are in DESIGN.md section 7 and no longer in the code.
   long layout = knob(KNOB_STREAM_LAYOUT);
   const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !knob(KNOB_TAPS_GEMM);
-  if (layout == 0) layout = 4;
+  if (layout != 1) layout = 4;
   if (!all256) layout = 1;
-  if (br.forked && (layout == 4 || layout == 5)) {
-    // 4: as 1, but the exciter is made on the second stream as well (ahead of the noise branch), so it overlaps the
-    // all-pass tap synthesis on the first stream instead of following it.  5: the second harmonic filter's taps too.
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, br.aux);
+  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+  int rc = 0;
+  if (layout == 4) {                                       // exciter: combtooth (vocoder.py:839-840)
+    rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, br.aux);
     br.publish(0);
-    float* th = w.taps;
-    if (layout == 5) {
-      th = w.taps_h;
-      synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
-                 th, br.aux, (float)sr);
-      br.publish(1);
-    }
-    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
-               w.taps_nz, br.aux);
-    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux, &gen);
-    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-    br.await(0);
-    int r1 = 0;
-    if (rc == 0) {
-      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
-      if (layout == 4)
-        synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
-                   n_harm, th, st, (float)sr);
-    }
-    br.join();
-    if (rc != 0) return DDSP_HIP_EHOP;
-    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
-    if (launch_fir(w.buf1, 0, th, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
   }
-  if (br.forked && layout >= 2) {
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
-    br.publish(0);
-    synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
-               w.taps_h, br.aux, (float)sr);
-    br.publish(1);
-    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
-               w.taps_nz, br.aux);
-    int rn = 0;
-    if (layout == 2) rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, br.aux, &gen);
-    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
-    int r1 = 0;
-    if (rc == 0) {
-      br.await(0);
-      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
-      br.await(1);
-    }
-    br.join();                                           // always joined, also on the error paths below
-    if (rc != 0) return DDSP_HIP_EHOP;
-    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
-    if (layout == 2) {                                   // signal = harmonic + noise: the second harmonic filter adds the branch's result
-      if (launch_fir(w.buf1, 0, w.taps_h, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-        return DDSP_HIP_ESHAPE;
-      return finish();
-    }
-    float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
-    if (launch_fir(w.buf1, 0, w.taps_h, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    if (launch_fir(noise, noise_is_u01, w.taps_nz, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl, st, &gen) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
-  }
-  if (br.forked) {
-    // noise branch (vocoder.py:854-858) on the second stream, beside the harmonic chain
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-               n_nz, w.taps_nz, br.aux);
-    const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                              br.aux, &gen);
-    synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-    const int rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
-    int r1 = 0;
-    if (rc == 0) {
-      r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
-      // half_width_frames = 1.5 sr / (f0 + 1e-3) (vocoder.py:851) is formed in the kernel's epilogue
-      synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
-                 n_harm, w.taps, st, (float)sr);
-    }
-    br.join();                                           // always joined, also on the error paths below
-    if (rc != 0) return DDSP_HIP_EHOP;
-    if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
-    // signal = harmonic + noise (vocoder.py:860): the second harmonic filter adds the branch's result
-    if (launch_fir(w.buf1, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
-  }
-  float* harmonic = harmonic_or_null ? harmonic_or_null : w.harm;
-  // all-pass taps first (vocoder.py:843-846; their response lives in buf0 until the exciter overwrites it)
+  // noise branch (vocoder.py:854-858)
+  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
+             w.taps_nz, br.aux);
+  const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
+                            br.aux, &gen);
+  // all-pass taps (vocoder.py:843-846; at other bin counts their response lives in buf0 until the exciter overwrites it)
   synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-  // exciter: combtooth (vocoder.py:839-840)
-  if (launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st) != 0) return DDSP_HIP_EHOP;
-  if (launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
-    return DDSP_HIP_ESHAPE;
-  // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851)
-  synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
-             w.taps, st, (float)sr);
-  if (launch_fir(w.buf1, 0, w.taps, nullptr, harmonic, nullptr, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-    return DDSP_HIP_ESHAPE;
-  // noise branch + mix (vocoder.py:854-860)
-  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-             n_nz, w.taps, st);
-  if (launch_fir(noise, noise_is_u01, w.taps, harmonic, signal, noise_out_or_null, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                 st, &gen) < 0)
+  if (layout == 4) br.await(0);
+  else rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
+  int r1 = 0;
+  if (rc == 0) {
+    r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
+    // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851); half_width_frames = 1.5 sr / (f0 + 1e-3)
+    // (:851) is formed in the kernel's epilogue
+    synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
+               w.taps, st, (float)sr);
+  }
+  br.join();                                             // always joined, also on the error paths below
+  if (rc != 0) return DDSP_HIP_EHOP;
+  if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
+  // signal = harmonic + noise (vocoder.py:860): the second harmonic filter adds the branch's result
+  if (launch_fir(w.buf1, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }

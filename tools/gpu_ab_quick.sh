@@ -3,7 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
 V=${V:-abq}
-timeout 600 python -m pytest tests/test_parity.py tests/test_fuzz.py tests/test_backward_fir.py tests/test_noise_rng.py tests/test_fullsize_gpu.py tests/test_core_api.py tests/test_baseline_shapes.py -m gpu -x -q 2>&1 | tail -3 | tee "$O/${V}_pytest_subset.log"
+timeout 600 python -m pytest tests/test_parity.py tests/test_fuzz.py tests/test_backward_fir.py tests/test_noise_rng.py tests/test_fullsize_gpu.py tests/test_core_api.py tests/test_baseline_shapes.py tests/test_modules.py tests/test_sharding.py -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee "$O/${V}_pytest_subset.log"
 B="python bench.py --no-cpu-baseline --no-module-mode"
 run() { tag=$1; shift; env "$@" timeout 300 $B 2>&1 | tail -1 > "$O/${V}_bench_$tag.json"; }
 for rep in 1 2; do
