@@ -187,7 +187,11 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
         }
       }
     }
-    // the zeroed ring slots are next written after the barriers inside the coming transforms
+    // The zeroed ring slots are next written after the barriers inside the coming transforms -- except the eight at the end
+    // of the emitted stretch, which the next pair borrows for its energy reduction right away: without this barrier a wave
+    // that runs ahead puts its two sums there before a slower wave has emitted those samples (found by tools/flaky_probe.py:
+    // two wrong output samples in about one launch of a hundred).
+    __syncthreads();
   }
 }
 

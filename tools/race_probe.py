@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Every kernel of the library is deterministic: the same launch on the same inputs must give the same bits.  This probe
+repeats each operation at full size many times (other work in between shifts the waves' relative timing) and compares
+every result with the first one bit for bit -- a difference is a race between waves or workgroups.  It found the missing
+barrier of k_fir_fft (two wrong samples in about one launch of a hundred).  Exit status 1 on any mismatch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ddsp_svc_amd import _ffi, core, synth
+
+n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+dev = torch.device("cuda:0")
+SR, HOP, n = 44100, 512, 256
+B, F = 32, 862
+N = 2 * (n - 1)
+f0, (c0, c1, c2), noise = bench.make_inputs("combsub", B, F, (n, n, n), dev, 7)
+g = torch.Generator().manual_seed(11)
+x = (torch.rand(B, F * HOP, generator=g) * 2 - 1).to(dev)
+taps = (torch.randn(B, F, N, generator=g) / N ** 0.5).to(dev)
+gout = torch.randn(B, F * HOP, generator=g).to(dev)
+st = synth.phase(f0, SR, HOP)
+fs = synth.fast_source(f0, SR, HOP, want_combtooth=True)
+ops = {
+    "fft_convolve impl 3 (direct form, MFMA)": lambda: core.fft_convolve(x, taps, impl=3),
+    "fft_convolve impl 4 (per-frame FFT form)": lambda: core.fft_convolve(x, taps, impl=4),
+    "fft_convolve impl 5 (hop-block FFT form)": lambda: core.fft_convolve(x, taps, impl=5),
+    "fft_convolve backward": lambda: torch.cat([t.reshape(-1) for t in core.fft_convolve_backward(gout, x, taps)]),
+    "phase": lambda: synth.phase(f0, SR, HOP, want_x=True).x,
+    "combtooth": lambda: synth.combtooth(f0, st, SR, HOP),
+    "combsub tail (two streams)": lambda: synth.combsub_synth(f0, st, c0, c1, c2, noise, SR, HOP, want_components=False)[0],
+    "sins tail (two streams)": lambda: synth.sins_synth(f0, st, c0, c1, c2, noise, SR, HOP, want_components=False)[0],
+    "tap synthesis, dynamic window": lambda: core.frequency_impulse_response(torch.exp(c1), half_width_frames=(1.5 * SR / (f0.reshape(B, F, 1) + 1e-3))),
+    "fast source": lambda: synth.fast_source(f0, SR, HOP, want_combtooth=True).combtooth,
+}
+for win, name in ((1024, "combsubfast"), (2048, "combsubsuperfast")):
+    nb = win // 2 + 1
+    gg = torch.Generator().manual_seed(win)
+    hm, hp, nm, nph = (torch.randn(B, F, nb, generator=gg).mul_(0.3).to(dev) for _ in range(4))
+    w = torch.hann_window(win).to(dev) if win == 2048 else torch.sqrt(torch.hann_window(win)).to(dev)
+    gz = torch.randn(B, F * HOP, generator=gg).to(dev)
+    if win == 2048:
+        ops["combsubsuperfast tail"] = lambda hm=hm, hp=hp, nm=nm, nph=nph, gz=gz, w=w: synth.combsubsuperfast_synth(f0, fs, hm, hp, nm, nph, gz, w, SR, HOP)
+        ops["stft filter backward (win 2048)"] = lambda hm=hm, hp=hp, nm=nm, nph=nph, gz=gz, w=w: torch.cat([t.reshape(-1) for t in synth.stft_filter_backward(gout, fs.combtooth, gz, hm, hp, nm, nph, w, HOP) if t is not None])
+    else:
+        ops["combsubfast tail"] = lambda hm=hm, hp=hp, nm=nm, w=w: synth.combsubfast_synth(f0, st, hm, hp, nm, noise, w, SR, HOP)
+bad = 0
+filler = torch.empty(64 << 20, device=dev)
+for name, fn in ops.items():
+    first = fn().clone()
+    miss = 0
+    for it in range(n_rep):
+        if it % 3 == 1:
+            filler.normal_()                       # something else on the chip in between
+        r = fn()
+        if not torch.equal(r, first):
+            miss += 1
+            d = (r.float() - first.float()).abs()
+            print("  %s: repetition %d differs in %d elements, max |diff| %.3g" % (name, it, int((d > 0).sum()), float(d.max())))
+    torch.cuda.synchronize()
+    print("%-44s %d repetitions, %d mismatches" % (name, n_rep, miss))
+    bad += miss
+sys.exit(1 if bad else 0)
