@@ -45,6 +45,45 @@ for win, name in ((1024, "combsubfast"), (2048, "combsubsuperfast")):
         ops["stft filter backward (win 2048)"] = lambda hm=hm, hp=hp, nm=nm, nph=nph, gz=gz, w=w: torch.cat([t.reshape(-1) for t in synth.stft_filter_backward(gout, fs.combtooth, gz, hm, hp, nm, nph, w, HOP) if t is not None])
     else:
         ops["combsubfast tail"] = lambda hm=hm, hp=hp, nm=nm, w=w: synth.combsubfast_synth(f0, st, hm, hp, nm, noise, w, SR, HOP)
+# the remaining operations: autograd through the tails, the mel front-end, the NSF source, the spectral loss
+from ddsp_svc_amd import mel as hmel, nsf_source, loss as hloss
+
+
+def tail_grads(fn, ctrls):
+    leaves = [c.detach().clone().requires_grad_(True) for c in ctrls]
+    out = fn(f0, st, *leaves, noise, SR, HOP, want_components=False)[0]
+    out.backward(gout)
+    return torch.cat([l.grad.reshape(-1) for l in leaves])
+
+
+ops["combsub tail, backward to the controls"] = lambda: tail_grads(synth.combsub_synth, (c0, c1, c2))
+ops["sins tail, backward to the controls"] = lambda: tail_grads(synth.sins_synth, (c0, c1, c2))
+ops["fft_convolve, 2u-1 + addend + plain output"] = lambda: torch.cat([t.reshape(-1) for t in (lambda o, p: (_ffi.check(_ffi.lib().ddsp_hip_fft_convolve(
+    ((x + 1) / 2).data_ptr(), 1, taps.data_ptr(), gout.data_ptr(), o.data_ptr(), p.data_ptr(), B, F, HOP, N, 5, _ffi.stream_of(x))), (o, p))[1])(torch.empty_like(x), torch.empty_like(x))])
+ops["combsub tail, noise drawn in the kernel"] = lambda: synth.combsub_synth(f0, st, c0, c1, c2, None, SR, HOP, want_components=False, noise_seed=5, noise_offset=9)[0]
+try:
+    basis = torch.as_tensor(hmel.slaney_mel_filterbank(44100, 2048, 128, 40, 16000)).float().to(dev)
+    wmel = torch.hann_window(2048).to(dev)
+    band = hmel._bands(basis)
+    ops["log-mel front-end"] = lambda: hmel.mel_spectrogram(x[:, : 430 * 512], wmel, basis, band, 512)
+except Exception as e:                                  # the banded basis helper wants a real filterbank shape
+    print("mel skipped:", e)
+L_, upp = 862, 512
+rnd = torch.rand(9, generator=g).to(dev); rnd[0] = 0
+nzs = torch.randn(8, L_ * upp, 9, generator=g).to(dev)
+wgt = torch.randn(9, generator=g).to(dev); bia = torch.randn(1, generator=g).to(dev)
+ops["NSF harmonic source"] = lambda: nsf_source.sine_source(f0[:8].reshape(8, -1), upp, SR, wgt, bia, rnd, nzs)
+lossm = hloss.SSSLoss(1024, 1.0, 0.75).to(dev)
+
+
+def loss_grad():
+    xp = x[:8].detach().clone().requires_grad_(True)
+    l = lossm(gout[:8] * 0.1, xp)
+    l.backward()
+    return torch.cat([l.detach().reshape(-1), xp.grad.reshape(-1)])
+
+
+ops["spectral loss, forward + backward (ATen stft backward: not deterministic, informational)"] = loss_grad
 bad = 0
 filler = torch.empty(64 << 20, device=dev)
 for name, fn in ops.items():
@@ -57,8 +96,10 @@ for name, fn in ops.items():
         if not torch.equal(r, first):
             miss += 1
             d = (r.float() - first.float()).abs()
-            print("  %s: repetition %d differs in %d elements, max |diff| %.3g" % (name, it, int((d > 0).sum()), float(d.max())))
+            if miss <= 3:
+                print("  %s: repetition %d differs in %d elements, max |diff| %.3g" % (name, it, int((d > 0).sum()), float(d.max())))
     torch.cuda.synchronize()
     print("%-44s %d repetitions, %d mismatches" % (name, n_rep, miss))
-    bad += miss
+    if "informational" not in name:
+        bad += miss
 sys.exit(1 if bad else 0)
