@@ -78,6 +78,24 @@ def test_fir_linearity_and_frame_locality(cuda, batch, impl):
     assert float(diff[lo:hi].max()) > 0.1
 
 
+@pytest.mark.parametrize("impl", [3, 4, 5])
+def test_fir_repeated_launches_bit_identical(cuda, batch, impl):
+    """every kernel of the library is deterministic, so the same launch must give the same bits every time: a difference is
+    a race between waves.  150 full-size launches per form, with other work on the chip in between (the per-frame FFT form
+    once lost a barrier's worth of ordering here: two wrong samples in about one launch of a hundred; tools/race_probe.py
+    runs the same check over every operation)"""
+    from ddsp_svc_amd import core
+    _, _, x = batch
+    g = torch.Generator().manual_seed(5)
+    taps = (torch.randn(B, F, N, generator=g) / N ** 0.5).to(cuda)
+    first = core.fft_convolve(x, taps, impl=impl).clone()
+    filler = torch.empty(16 << 20, device=cuda)
+    for it in range(150):
+        if it % 3 == 1:
+            filler.normal_()
+        assert torch.equal(core.fft_convolve(x, taps, impl=impl), first), it
+
+
 def test_fir_forms_agree(cuda, batch):
     """FFT-domain kernel vs direct-form MFMA kernel on the full batch, plus the fused 2u-1 / addend options"""
     from ddsp_svc_amd import _ffi, core
