@@ -17,9 +17,11 @@
 // and keeps the spectra of three tap rows in registers.  The taps enter the transform shifted by 256 - N/2: they
 // then sit in the lower half of the transform (its first pass is pruned like the block's) and the result of block b
 // (support <= 1023: no aliasing) starts at output time (b - 1/2) hop -- a multiple of the thread count -- so every
-// thread only ever touches overlap-add ring slots congruent to its id and the ring needs no barriers.  A run starts one pair early (discarded) so
-// the ring holds its predecessor's tail: no atomics, so a launch geometry is bit-reproducible (different run splits
-// agree to rounding: the first tap spectrum of a run comes out of a differently packed transform).
+// thread only ever touches overlap-add ring slots congruent to its id and the ring needs no barriers.  A run starts
+// one BLOCK early (discarded) so the ring holds its predecessor's tail: no atomics, so a launch geometry is
+// bit-reproducible (different run splits agree to rounding: the first tap spectrum of a run comes out of a differently
+// packed transform).  A pair of blocks is two lockstep stages (fft_r.h): the two block transforms, then the pair's
+// inverse beside the transform of the next pair's tap rows.
 #include "fft_r.h"
 #include "kernels.h"
 #include "philox.h"
