@@ -58,6 +58,25 @@ def tail_grads(fn, ctrls):
 
 ops["combsub tail, backward to the controls"] = lambda: tail_grads(synth.combsub_synth, (c0, c1, c2))
 ops["sins tail, backward to the controls"] = lambda: tail_grads(synth.sins_synth, (c0, c1, c2))
+# paths off the headline shape: dense tap synthesis (other bin counts) and its adjoint, the first sinusoid bank (other hops),
+# the simple per-sample filter
+n2 = 129
+z2 = torch.complex(torch.randn(B, F, n2, generator=g), torch.randn(B, F, n2, generator=g)).to(dev)
+ops["tap synthesis, dense contraction (129 bins, complex)"] = lambda: core.frequency_impulse_response(z2)
+
+
+def taps_grad():
+    zz = torch.randn(B, F, n2, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_(True)
+    core.frequency_impulse_response(torch.exp(zz)).square().sum().backward()
+    return zz.grad
+
+
+ops["tap synthesis adjoint (129 bins)"] = taps_grad
+f0h = bench.make_inputs("combsub", 8, 300, (64, 64, 64), dev, 3)
+sth = synth.phase(f0h[0], SR, 256)
+ops["sinusoid bank, hop 256"] = lambda: synth.sinusoid_bank(f0h[0], sth, f0h[1][0], SR, 256)
+xs, ts = x[:2, : 40 * 441].contiguous(), torch.randn(2, 40, 64, generator=g).to(dev)
+ops["fft_convolve, hop 441 (simple / direct forms)"] = lambda: core.fft_convolve(xs, ts)
 ops["fft_convolve, 2u-1 + addend + plain output"] = lambda: torch.cat([t.reshape(-1) for t in (lambda o, p: (_ffi.check(_ffi.lib().ddsp_hip_fft_convolve(
     ((x + 1) / 2).data_ptr(), 1, taps.data_ptr(), gout.data_ptr(), o.data_ptr(), p.data_ptr(), B, F, HOP, N, 5, _ffi.stream_of(x))), (o, p))[1])(torch.empty_like(x), torch.empty_like(x))])
 ops["combsub tail, noise drawn in the kernel"] = lambda: synth.combsub_synth(f0, st, c0, c1, c2, None, SR, HOP, want_components=False, noise_seed=5, noise_offset=9)[0]
