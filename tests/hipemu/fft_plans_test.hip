@@ -1,0 +1,62 @@
+// Unit-test kernels for the in-register / LDS FFT plans of ddsp-svc_amd/csrc/fft_r.h, run under the CPU emulator
+// (tests/test_fft_plans.py compares them with numpy.fft).  TEST INFRASTRUCTURE ONLY.
+#include "fft_r.h"
+
+namespace {
+using ddsp::f32x2;
+using ddsp::fft::Plan;
+
+// mode 0: Plan<R>::forward                 natural order in  -> natural order out
+// mode 1: Plan<2>::forward_s<false>        natural in        -> out[s_index(tid, slot)]  (so out is in natural bin order)
+// mode 2: Plan<2>::forward_s<true>         (upper half of the input must be zero)
+// mode 3: Plan<2>::transposed              in[k] is read into layout S, out natural = DFT of in
+// mode 4: Plan<2>::forward_s2<true>        two inputs (in, in2) -> (out, out2), both as mode 2
+// mode 5: Plan<2>::transposed_and_forward_s   in -> out as mode 3, in2 -> out2 as mode 2
+template <int R>
+__global__ void k_plan(int mode, const f32x2* in, const f32x2* in2, f32x2* out, f32x2* out2) {
+  using PL = Plan<R>;
+  constexpr int N = PL::N, P = PL::P;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
+  const int tid = threadIdx.x;
+  typename PL::Tw tw;
+  tw.init(tid);
+  f32x2 v[8], u[8];
+  if (mode == 0) {
+    for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
+    PL::forward(v, tw, ex[0], ex[1], tid);
+    for (int m = 0; m < 8; ++m) out[P * m + tid] = v[m];
+  }
+  if constexpr (R == 2) {
+    if (mode == 1 || mode == 2) {
+      for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
+      if (mode == 1) PL::template forward_s<false>(v, tw, ex[0], ex[1], tid);
+      else PL::template forward_s<true>(v, tw, ex[0], ex[1], tid);
+      for (int m = 0; m < 8; ++m) out[PL::s_index(tid, m)] = v[m];
+    } else if (mode == 3) {
+      for (int m = 0; m < 8; ++m) v[m] = in[PL::s_index(tid, m)];
+      PL::transposed(v, tw, ex[0], ex[1], tid);
+      for (int m = 0; m < 8; ++m) out[P * m + tid] = v[m];
+    } else if (mode == 4) {
+      for (int m = 0; m < 8; ++m) { v[m] = in[P * m + tid]; u[m] = in2[P * m + tid]; }
+      PL::template forward_s2<true>(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+      for (int m = 0; m < 8; ++m) { out[PL::s_index(tid, m)] = v[m]; out2[PL::s_index(tid, m)] = u[m]; }
+    } else if (mode == 5) {
+      for (int m = 0; m < 8; ++m) { v[m] = in[PL::s_index(tid, m)]; u[m] = in2[P * m + tid]; }
+      PL::transposed_and_forward_s(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+      for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m]; out2[PL::s_index(tid, m)] = u[m]; }
+    }
+  }
+}
+}  // namespace
+
+// complex arrays as interleaved float pairs; returns 0
+extern "C" int emu_fft_plan(int R, int mode, const float* in, const float* in2, float* out, float* out2) {
+  const f32x2* a = reinterpret_cast<const f32x2*>(in);
+  const f32x2* b = reinterpret_cast<const f32x2*>(in2);
+  f32x2* c = reinterpret_cast<f32x2*>(out);
+  f32x2* d = reinterpret_cast<f32x2*>(out2);
+  if (R == 2) hipLaunchKernelGGL(k_plan<2>, dim3(1), dim3(128), 0, nullptr, mode, a, b, c, d);
+  else if (R == 4) hipLaunchKernelGGL(k_plan<4>, dim3(1), dim3(256), 0, nullptr, mode, a, b, c, d);
+  else return -1;
+  return 0;
+}
