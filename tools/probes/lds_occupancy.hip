@@ -35,7 +35,7 @@ void run(long long* d, float* sink) {
 int main() {
   long long* d; float* sink;
   hipMalloc(&d, 256 * 8 * sizeof(long long)); hipMalloc(&sink, 4);
-  run<32768>(d, sink); run<32768>(d, sink); run<32704>(d, sink); run<32256>(d, sink); run<31744>(d, sink); run<30720>(d, sink);
+  run<40960>(d, sink); run<39936>(d, sink); run<32768>(d, sink); run<32768>(d, sink); run<32704>(d, sink); run<32256>(d, sink); run<31744>(d, sink); run<30720>(d, sink);
   run<27000>(d, sink); run<23000>(d, sink); run<16384>(d, sink);
   return 0;
 }
