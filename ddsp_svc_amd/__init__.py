@@ -1,6 +1,5 @@
 """ddsp_svc_amd -- MI355X-native DDSP harmonic-plus-noise synthesiser (drop-in for the
-Sins/CombSub forward pass of yxlllc/DDSP-SVC).  Import name: ``ddsp_svc_amd`` (the directory is
-``ddsp-svc_amd/``; ``ddsp_svc_amd.py`` at the repo root aliases it).
+Sins/CombSub forward pass of yxlllc/DDSP-SVC).
 
   core      -- ddsp/core.py functions (upsample, frequency_filter, ...) on HIP kernels
   synth     -- phase state, exciters, fused Sins / CombSub DSP tails

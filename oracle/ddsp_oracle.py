@@ -1,7 +1,7 @@
 """CPU oracle for the DDSP harmonic-plus-noise hot path (TEST INFRASTRUCTURE ONLY).
 
 This file is the *checker*, never the product: only ``tests/``, ``__graft_entry__.smoke()``
-and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under ``ddsp-svc_amd/``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under ``ddsp_svc_amd/``
 imports it, and the product path raises if the HIP library is missing.
 
 It restates, in numpy, what ``/root/reference/ddsp/core.py`` and the DSP tails of

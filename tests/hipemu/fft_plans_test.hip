@@ -1,4 +1,4 @@
-// Unit-test kernels for the in-register / LDS FFT plans of ddsp-svc_amd/csrc/fft_r.h, run under the CPU emulator
+// Unit-test kernels for the in-register / LDS FFT plans of ddsp_svc_amd/csrc/fft_r.h, run under the CPU emulator
 // (tests/test_fft_plans.py compares them with numpy.fft).  TEST INFRASTRUCTURE ONLY.
 #include "fft_r.h"
 

@@ -1,13 +1,13 @@
 // hipemu -- a minimal single-process CPU emulator of the HIP device model, TEST INFRASTRUCTURE ONLY.
 //
-// The product kernels under ddsp-svc_amd/csrc/*.hip are pure HIP for gfx950.  There is no GPU in
+// The product kernels under ddsp_svc_amd/csrc/*.hip are pure HIP for gfx950.  There is no GPU in
 // the build container, so tests/hipemu compiles those *same source files* as host C++ (clang++
 // -x c++ -I tests/hipemu) against this header: every workgroup runs as a set of cooperatively
 // scheduled fibers (one per work-item), __syncthreads() and the wave64 cross-lane operations
 // (__shfl*, f32 MFMA) are rendez-vous points between fibers.  That lets the CPU test-suite check
 // kernel *logic* (indexing, LDS staging, wave scans, MFMA fragment layouts, tails) under
 // AddressSanitizer before a GPU minute is spent.  It is never loaded by the product package and
-// is not a fallback: ddsp-svc_amd/_ffi.py only ever loads the hipcc-built libddsp_hip.so.
+// is not a fallback: ddsp_svc_amd/_ffi.py only ever loads the hipcc-built libddsp_hip.so.
 #pragma once
 #include <cmath>
 #include <cstdint>

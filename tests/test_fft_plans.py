@@ -1,4 +1,4 @@
-"""The in-register / LDS FFT plans of ddsp-svc_amd/csrc/fft_r.h (the building blocks of k_fir_blk, k_stft_filter, k_mel) on
+"""The in-register / LDS FFT plans of ddsp_svc_amd/csrc/fft_r.h (the building blocks of k_fir_blk, k_stft_filter, k_mel) on
 their own, under the CPU emulator, against numpy.fft: the full three-exchange transform at 1024 and 2048 points, the
 two-exchange pair that stays in the scrambled layout S (forward_s with and without the pruned first pass, transposed), and
 the two lockstep forms, which must equal their separate transforms bit for bit (same arithmetic, shared barriers)."""
