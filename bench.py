@@ -14,7 +14,12 @@ ranks: fewer than N visible devices is an error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline               the dominant kernel (the time-varying FIR, k_fir_blk) timed alone with events on the launch stream
-  roofline_step_traffic  PMC HBM bytes of one whole step (committed profiles/*_hbm_traffic.json) over its algorithmic bytes
+  roofline_step_traffic  PMC HBM bytes of one whole step over its algorithmic bytes: measured IN this run when rocprofv3 is
+                         on the box (two --pmc passes over ``bench.py --only-steps``, ``traffic_source: "live"``), otherwise the
+                         newest committed profiles/*_hbm_traffic.json (``traffic_source: "committed"``)
+  also                   (N = 1) the other single-GPU BASELINE configs attested by the same command: the Sins cfg-3 step with its
+                         dominant kernel's roofline, and the as-shipped CombSubSuperFast model (informative)
+  cfg4                   (N = 8, or --cfg4) BASELINE cfg 4: 64 utterances per GPU, samples/s without and with the RCCL gather
   ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
   cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
                          on this host's cores over a bounded sample of the same workload (N=1 only)
@@ -135,6 +140,233 @@ def hbm_traffic(kernel, model=None):
                 if k.startswith(kernel):
                     best = {"bytes": v["hbm_bytes"], "read": v["read_bytes"], "write": v["write_bytes"], "source": "profiles/" + name}
     return best
+
+
+def live_traffic(model, extra_args=()):
+    """HBM bytes per kernel launch and per step of ``model``, measured now: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
+    separate passes (they do not fit one; kernel trace only) over ``bench.py --model M --only-steps --steps 3 --warmup 1``,
+    FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM), both in KiB.  The same
+    arithmetic as tools/gpu_traffic.sh + tools/traffic_summary.py.  None if rocprofv3 is absent or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    steps, warm = 3, 1
+    raw = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ddsp_traffic_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable,
+                   os.path.abspath(__file__), "--model", model, "--only-steps", "--steps", str(steps), "--warmup", str(warm),
+                   *extra_args]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            rows = c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? "
+                             "group by kernel_name", (counter,)).fetchall()
+            c.close()
+            for name, v, cnt in rows:
+                if "ddsp::" not in name:
+                    continue
+                key = name.split("(")[0].split("ddsp::")[-1].strip()
+                raw.setdefault(key, {})[counter] = float(v)
+                raw[key]["launches"] = int(cnt)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    res = {}
+    for k, d in raw.items():
+        rd, wr = d.get("FETCH_SIZE", 0.0) * 2048.0, d.get("WRITE_SIZE", 0.0) * 1024.0
+        res[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "launches_sampled": d.get("launches")}
+    per_step = {k: v["launches_sampled"] / float(steps + warm) for k, v in res.items() if k != "k_ir_table"}
+    res["__step__"] = {"model": model, "steps_profiled": steps + warm,
+                       "hbm_bytes": sum(res[k]["hbm_bytes"] * n for k, n in per_step.items()),
+                       "read_bytes": sum(res[k]["read_bytes"] * n for k, n in per_step.items()),
+                       "write_bytes": sum(res[k]["write_bytes"] * n for k, n in per_step.items()),
+                       "launches_per_step": per_step, "seconds": time.perf_counter() - t0}
+    return res
+
+
+def traffic_of(kernel, model, live):
+    """(per-launch traffic of ``kernel``, whole-step traffic, source) from the live measurement if there is one, else from
+    the newest committed summary"""
+    if live:
+        k = next((v for name, v in live.items() if name.startswith(kernel)), None)
+        kt = None if k is None else {"bytes": k["hbm_bytes"], "read": k["read_bytes"], "write": k["write_bytes"],
+                                     "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"}
+        return kt, dict(live["__step__"], source="live"), "live"
+    return hbm_traffic(kernel, model), step_traffic(model), "committed"
+
+
+def build_step(model, B, F, n, device, seed, fir_impl=0):
+    """(step, inputs) of ``model``: HOT-1 + HOT-2 from resident f0 / raw controls / noise, signal only"""
+    from ddsp_svc_amd import synth
+    sizes = model_sizes(model, n)
+    f0, ctrls, noise = make_inputs(model, B, F, sizes, device, seed=seed)
+    win = 2048 if model == "combsubsuperfast" else 2 * HOP
+    window = torch.hann_window(win, device=device)
+    if model == "combsubfast":
+        window = torch.sqrt(window)
+
+    def step():
+        if model == "combsubsuperfast":
+            fs = synth.fast_source(f0, SR, HOP)
+            return synth.combsubsuperfast_synth(f0, fs, ctrls[0], ctrls[1], ctrls[2], ctrls[3], noise, window, SR, HOP)
+        st = synth.phase(f0, SR, HOP)
+        if model == "combsubfast":
+            return synth.combsubfast_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, window, SR, HOP)
+        if model == "combsub":
+            return synth.combsub_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
+                                       want_components=False, fir_impl=fir_impl)[0]
+        return synth.sins_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
+                                want_components=False, fir_impl=fir_impl)[0]
+    return step, {"f0": f0, "ctrls": ctrls, "noise": noise, "sizes": sizes, "window": window, "win": win}
+
+
+def time_steps(step, steps, warmup, fence):
+    """(wall seconds, HIP-event ms per step, last output) of exactly ``steps`` steps after ``warmup`` untimed ones"""
+    for _ in range(warmup):
+        out = step()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        out = step()
+    e1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, e0.elapsed_time(e1) / steps, out
+
+
+def time_alone(fn, reps=20):
+    """HIP-event ms per call of ``fn`` launched back to back on the current stream"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def also_lines(a, device, B, F, n, want_traffic):
+    """The other single-GPU BASELINE configs, measured by the same command (N = 1): cfg 3 = the Sins step with the
+    roofline of its dominant kernel (the sinusoid bank), and the as-shipped configs/combsub.yaml model CombSubSuperFast
+    (informative).  Fewer steps than the headline (the whole block costs about two seconds)."""
+    from ddsp_svc_amd import synth
+    T = F * HOP
+    steps, warm = max(10, min(a.steps, 30)), 5
+    fence = torch.cuda.synchronize
+    out = {}
+    # ---- cfg 3: Sins, 256 harmonics / 256 / 256 bins
+    step, inp = build_step("sins", B, F, n, device, seed=4321)
+    prewarm(step, min(a.prewarm_seconds, 0.2))
+    el, ev_ms, y = time_steps(step, steps, warm, fence)
+    assert torch.isfinite(y).all()
+    st = synth.phase(inp["f0"], SR, HOP)
+    bank_ms = time_alone(lambda: synth.sinusoid_bank(inp["f0"], st, inp["ctrls"][0], SR, HOP))
+    bank_bytes = (4.0 + 4.0 * n / HOP) * B * T                 # amplitude controls in, exciter out
+    alg = (8.0 + 4.0 * (sum(inp["sizes"]) + 1) / HOP) * B * T
+    live = live_traffic("sins") if want_traffic else None
+    kt, stt, src = traffic_of("k_sins_bank2", "sins", live) if (B, F, n) == (32, 862, 256) else (None, None, None)
+    ms = el / steps * 1e3
+    out["sins"] = {
+        "metric": "audio samples/sec, Sins 44.1kHz 256-harm hop512", "value": B * T * steps / el, "unit": "samples/s",
+        "steps": steps, "warmup": warm, "ms_per_step": ms, "ms_per_step_events": ev_ms, "dtype": "f32",
+        "config": {"workload": "sins B=%d x %.0f s utterances (F=%d, T=%d), %d harmonics, n_mag %d/%d, DSP path from resident "
+                               "f0 / raw controls / uniform noise, signal only (BASELINE cfg 3)" % (B, a.seconds, F, T, n, n, n)},
+        "roofline": {"kernel": "k_sins_bank2", "bound": "hbm", "achieved": bank_bytes / (bank_ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": bank_bytes / (bank_ms * 1e-3) / 1e9 / 8000.0,
+                     "traffic": kt["bytes"] if kt else None, "traffic_source": src,
+                     "algorithmic_bytes_per_launch": bank_bytes, "avg_ms": bank_ms, "launches_per_step": 1,
+                     "note": "issue-bound, not HBM-bound: %.2f G sine terms per launch (DESIGN.md, sinusoid bank)" % (n * B * T / 1e9)},
+        "roofline_step_hbm": {"algorithmic_bytes_per_step": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
+                              "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / 8000.0},
+        "roofline_step_traffic": None if not stt else {"pmc_bytes_per_step": stt["hbm_bytes"], "ratio": stt["hbm_bytes"] / alg,
+                                                       "source": stt["source"]}}
+    del step, inp, y
+    # ---- the as-shipped configs/combsub.yaml model
+    step, inp = build_step("combsubsuperfast", B, F, n, device, seed=4322)
+    el, ev_ms, y = time_steps(step, steps, warm, fence)
+    assert torch.isfinite(y).all()
+    exc = torch.randn(B, T, device=device)
+    c = inp["ctrls"]
+    k_ms = time_alone(lambda: synth.stft_filter(exc, inp["noise"], c[0], c[1], c[2], c[3], inp["window"], HOP,
+                                                pad_reflect=True, normalize=True))
+    k_bytes = (12.0 + 4.0 * sum(inp["sizes"]) / HOP) * B * T
+    ms = el / steps * 1e3
+    out["combsubsuperfast"] = {
+        "metric": "audio samples/sec, CombSubSuperFast 44.1kHz win2048 hop512", "value": B * T * steps / el,
+        "unit": "samples/s", "steps": steps, "warmup": warm, "ms_per_step": ms, "ms_per_step_events": ev_ms, "dtype": "f32",
+        "config": {"workload": "combsubsuperfast B=%d x %.0f s (F=%d, T=%d), 4 x 1025 control bins (configs/combsub.yaml as "
+                               "shipped; informative)" % (B, a.seconds, F, T)},
+        "roofline": {"kernel": "k_stft_filter<4>", "bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_per_step": 1}}
+    return out
+
+
+def cfg4_line(a, rank, world, device, F, n, comm):
+    """BASELINE cfg 4 (combsub, 512 utterances sharded over 8 GPUs = 64 per GPU, RCCL gather over xGMI): samples/s of the
+    sharded synthesis alone and with the gather of every step's waveforms to rank 0, max over ranks."""
+    import torch.distributed as dist
+    from ddsp_svc_amd import sharding
+    B4 = 64
+    T = F * HOP
+    step, _ = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
+    steps, warm = max(5, min(a.steps, 20)), 3
+
+    def fence():
+        if dist.is_initialized() and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(*vals):
+        if not (dist.is_initialized() and world > 1):
+            return vals
+        tt = torch.tensor(vals, dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tuple(float(v) for v in tt)
+    el, ev_ms, out = time_steps(step, steps, warm, fence)
+    (el,) = reduce_max(el)
+    res = {"workload": "combsub B=%d/GPU x %.0f s on %d GPU(s): %d utterances, n_mag %d/%d/%d (BASELINE cfg 4)"
+                       % (B4, a.seconds, world, B4 * world, n, n, n),
+           "batch_per_gpu": B4, "n_gpus": world, "steps": steps, "warmup": warm,
+           "ms_per_step": el / steps * 1e3, "value": B4 * world * T * steps / el, "unit": "samples/s",
+           "rccl_ranks": comm.get("rccl_ranks")}
+    if dist.is_initialized():
+        def step_g():
+            return sharding.gather_utterances(step(), B4 * world, dst=0)
+        elg, _, full = time_steps(step_g, steps, warm, fence)
+        t1 = time.perf_counter()
+        full = sharding.gather_utterances(out, B4 * world, dst=0)
+        fence()
+        g_ms = (time.perf_counter() - t1) * 1e3
+        elg, g_ms = reduce_max(elg, g_ms)
+        if rank == 0:
+            assert full.shape == (B4 * world, T) and torch.isfinite(full[::8, ::4096]).all()
+        res.update({"ms_per_step_with_gather": elg / steps * 1e3, "value_with_gather": B4 * world * T * steps / elg,
+                    "gather_ms": g_ms, "gather_bytes_per_rank": 4.0 * B4 * T,
+                    "gather": "torch.distributed.gather (nccl = RCCL) of every step's [64, T] waveforms into slices of the "
+                              "result on rank 0"})
+    else:
+        res["gather"] = "not timed: no process group (run with --gather or N > 1)"
+    return res
 
 
 def cpu_baseline(kind, F, sizes, budget_s=12.0):
@@ -317,7 +549,7 @@ def setup_ranks(a):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     info = {}
-    if world > 1 or a.gather:
+    if world > 1 or a.gather or a.cfg4:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -731,6 +963,11 @@ def main():
                     help="run exactly warmup + steps of the step and nothing else (no clock ramp-up, no separately timed "
                          "kernels, no baselines): what tools/gpu_traffic.sh and the kernel-trace profiles wrap")
     ap.add_argument("--no-module-mode", action="store_true", help="skip the control-mode (i) timing")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the rocprofv3 PMC passes; report the newest committed traffic summary instead")
+    ap.add_argument("--no-also", action="store_true", help="skip the Sins (cfg 3) / CombSubSuperFast lines of the N = 1 run")
+    ap.add_argument("--cfg4", action="store_true",
+                    help="also run BASELINE cfg 4's per-GPU shape (64 utterances per GPU) -- default at --gpus 8")
     a = ap.parse_args()
     if a.only_steps:
         a.prewarm_seconds = 0.0
@@ -754,25 +991,8 @@ def main():
     F = int(a.seconds * SR) // HOP + 1              # the reference's frame-count rule (vocoder.py:222)
     T = F * HOP
     n = a.bins
-    sizes = model_sizes(a.model, n)
-    f0, ctrls, noise = make_inputs(a.model, B, F, sizes, device, seed=1234 + rank)
-    win = 2048 if a.model == "combsubsuperfast" else 2 * HOP
-    window = torch.hann_window(win, device=device)
-    if a.model == "combsubfast":
-        window = torch.sqrt(window)
-
-    def step():
-        if a.model == "combsubsuperfast":
-            fs = synth.fast_source(f0, SR, HOP)
-            return synth.combsubsuperfast_synth(f0, fs, ctrls[0], ctrls[1], ctrls[2], ctrls[3], noise, window, SR, HOP)
-        st = synth.phase(f0, SR, HOP)
-        if a.model == "combsubfast":
-            return synth.combsubfast_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, window, SR, HOP)
-        if a.model == "combsub":
-            return synth.combsub_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
-                                       want_components=False, fir_impl=a.fir_impl)[0]
-        return synth.sins_synth(f0, st, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP,
-                                want_components=False, fir_impl=a.fir_impl)[0]
+    step, inp = build_step(a.model, B, F, n, device, seed=1234 + rank, fir_impl=a.fir_impl)
+    sizes, f0, ctrls, noise, window, win = inp["sizes"], inp["f0"], inp["ctrls"], inp["noise"], inp["window"], inp["win"]
 
     def fence():
         if world > 1:
@@ -854,7 +1074,8 @@ def main():
     fir_launches = 3 if a.model == "combsub" else 2
     fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
     kname = {4: "k_fir_fft", 5: "k_fir_blk"}.get(used_impl, "k_fir_mfma")
-    traffic = hbm_traffic(kname, a.model) if (B, F, n) == (32, 862, 256) else None
+    # BASELINE cfg 4's per-GPU shape: every rank takes part (collectives inside)
+    cfg4 = cfg4_line(a, rank, world, device, F, n, comm) if a.model == "combsub" and (world == 8 or a.cfg4) else None
     # arithmetic the FFT forms actually execute (5 N log2 N per complex transform + spectral products): per frame pair
     # three 2048-point transforms (k_fir_fft) or per hop-block pair four 1024-point ones (k_fir_blk)
     if used_impl == 5:
@@ -867,6 +1088,10 @@ def main():
         value = total / elapsed
         ms = elapsed / a.steps * 1e3
         sigma_c = sum(sizes)
+        headline_shape = (B, F, n) == (32, 862, 256)
+        want_live = world == 1 and headline_shape and not a.no_live_traffic
+        live = live_traffic(a.model, ("--fir-impl", str(a.fir_impl)) if a.fir_impl else ()) if want_live else None
+        traffic, tr, traffic_source = traffic_of(kname, a.model, live) if headline_shape else (None, None, None)
         alg_bytes = (8.0 + 4.0 * (sigma_c + 1) / HOP) * B * T          # out + noise + controls + f0
         res = {
             "metric": "audio samples/sec, CombSub 44.1kHz 256-harm hop512" if a.model == "combsub"
@@ -881,6 +1106,7 @@ def main():
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": fir_bytes / (fir_ms * 1e-3) / 1e9, "peak": 8000.0,
                          "unit": "GB/s", "frac": fir_bytes / (fir_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": fir_bytes, "avg_ms": fir_ms, "launches_per_step": fir_launches,
                          "note": "north-star roofline (algorithmic HBM bytes / time; avg_ms from HIP events around 20 "
                                  "back-to-back launches of the kernel on resident data; inside a step, after other "
@@ -908,10 +1134,14 @@ def main():
                                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},
         }
         res.update(comm)
-        tr = step_traffic(a.model) if (B, F, n) == (32, 862, 256) else None
         res["roofline_step_traffic"] = None if tr is None else {
             "pmc_bytes_per_step": tr["hbm_bytes"], "algorithmic_bytes_per_step": alg_bytes,
-            "ratio": tr["hbm_bytes"] / alg_bytes, "launches_per_step": tr.get("launches_per_step"), "source": tr["source"]}
+            "ratio": tr["hbm_bytes"] / alg_bytes, "launches_per_step": tr.get("launches_per_step"), "source": tr["source"],
+            "traffic_source": traffic_source}
+        if cfg4 is not None:
+            res["cfg4"] = cfg4
+        if world == 1 and a.model == "combsub" and not a.no_also:
+            res["also"] = also_lines(a, device, B, F, n, want_live)
         if gather_ms is not None:
             res["gather_ms"] = gather_ms
             res["gather_bytes_per_rank"] = 4.0 * B * T

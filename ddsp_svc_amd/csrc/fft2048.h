@@ -44,6 +44,44 @@ __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
   return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-b.y, b.x}, t);
 #endif
 }
+// the two halves of a * b apart, so that independent products can be issued between them (an instruction that consumes its
+// predecessor's result waits ~3 cycles for it, and behind a packed producer the compiler adds an s_nop on top -- about the
+// issue time of one more instruction each, tools/probes/valu_probe2.hip)
+__device__ __forceinline__ f32x2 cmul_lo(f32x2 a, f32x2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 t;
+  DDSP_PK2(t, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]", a, b);                                     // (ax bx, ax by)
+  return t;
+#else
+  return f32x2{a.x, a.x} * b;
+#endif
+}
+__device__ __forceinline__ f32x2 cmul_hi(f32x2 a, f32x2 b, f32x2 t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK3(r, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", a, b, t);  // + (-ay by, ay bx)
+  return r;
+#else
+  return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-b.y, b.x}, t);
+#endif
+}
+// v[k] *= w[k], k = 1..7, for one array / for two arrays against the same factors: up to four products in flight
+__device__ __forceinline__ void twiddle7(f32x2* v, const f32x2* w) {
+  f32x2 t1 = cmul_lo(v[1], w[1]), t2 = cmul_lo(v[2], w[2]), t3 = cmul_lo(v[3], w[3]), t4 = cmul_lo(v[4], w[4]);
+  v[1] = cmul_hi(v[1], w[1], t1); v[2] = cmul_hi(v[2], w[2], t2); v[3] = cmul_hi(v[3], w[3], t3); v[4] = cmul_hi(v[4], w[4], t4);
+  t1 = cmul_lo(v[5], w[5]); t2 = cmul_lo(v[6], w[6]); t3 = cmul_lo(v[7], w[7]);
+  v[5] = cmul_hi(v[5], w[5], t1); v[6] = cmul_hi(v[6], w[6], t2); v[7] = cmul_hi(v[7], w[7], t3);
+}
+__device__ __forceinline__ void twiddle7x2(f32x2* u, const f32x2* wu, f32x2* v, const f32x2* wv) {
+#pragma unroll
+  for (int k = 1; k < 7; k += 2) {
+    const f32x2 t1 = cmul_lo(u[k], wu[k]), t2 = cmul_lo(v[k], wv[k]), t3 = cmul_lo(u[k + 1], wu[k + 1]), t4 = cmul_lo(v[k + 1], wv[k + 1]);
+    u[k] = cmul_hi(u[k], wu[k], t1); v[k] = cmul_hi(v[k], wv[k], t2);
+    u[k + 1] = cmul_hi(u[k + 1], wu[k + 1], t3); v[k + 1] = cmul_hi(v[k + 1], wv[k + 1], t4);
+  }
+  const f32x2 t1 = cmul_lo(u[7], wu[7]), t2 = cmul_lo(v[7], wv[7]);
+  u[7] = cmul_hi(u[7], wu[7], t1); v[7] = cmul_hi(v[7], wv[7], t2);
+}
 // t + (-i) d
 __device__ __forceinline__ f32x2 add_mi(f32x2 t, f32x2 d) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -91,6 +129,16 @@ __device__ __forceinline__ f32x2 swap_scale(f32x2 p, f32x2 q) {
   return r;
 #else
   return f32x2{p.y * q.x, p.x * q.y};
+#endif
+}
+// (p.y * q.x + a.x, p.x * q.y + a.y): the same plus an addend
+__device__ __forceinline__ f32x2 swap_scale_add(f32x2 p, f32x2 q, f32x2 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK3(r, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]", p, q, a);
+  return r;
+#else
+  return f32x2{fmaf(p.y, q.x, a.x), fmaf(p.x, q.y, a.y)};
 #endif
 }
 // (v.x - g.y, -v.y - g.x) = conj(v) - i conj(g)

@@ -48,8 +48,7 @@ struct Plan {
   // A must be free of readers on entry; on return A may still be read by slower waves (pass 4), B is free.
   static __device__ __forceinline__ void forward(f32x2 (&v)[8], const Tw& tw, f32x2* A, f32x2* B, int tid) {
     dft8(v);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+    twiddle7(v, tw.w1);
     // R = 2: a row of the second pass is 16 words, so the two rows k1, k1 + 1 that a 32-lane read touches would start in
     // the same banks; odd rows are stored with their 16-blocks swapped in pairs (R = 4: 32-word rows, nothing to do)
     constexpr int SW = R == 2 ? C : 0;
@@ -61,8 +60,7 @@ struct Plan {
 #pragma unroll
       for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + (R == 2 ? (n2 ^ (k1 & 1)) : n2) * C + c];
       dft8(v);
-#pragma unroll
-      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      twiddle7(v, tw.w2);
       const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) B[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];   // [n3][k2][k1 ^ n3][n4]
@@ -72,8 +70,7 @@ struct Plan {
 #pragma unroll
       for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];          // tid = n4 + R k1 + 8R k2
       dft8(v);
-#pragma unroll
-      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
+      twiddle7(v, tw.w3);
 #pragma unroll
       for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + tid] = v[k3];                       // [k3][k2][k1][n4]
     }
@@ -118,27 +115,55 @@ struct Plan {
   // Where bin k is parked for the mirrored read Z[-k]: lane pairs hold k and k + 512 -- the same banks -- so the upper
   // half is stored with bits 3 and 4 flipped (conflict-free 16-lane stores and, but for two lanes, 32-lane loads).
   static __device__ __forceinline__ int parked(int k) { return k ^ (((k >> 9) & 1) * 24); }
-  // DFT_2 over the low lane bit: even lane a0 + a1, odd lane a0 - a1
+  // DFT_2 over the low lane bit: even lane a0 + a1, odd lane a0 - a1.
+  // FLIP: one instruction per value instead of two -- "mine + sigma * neighbour's" with the DPP operand as the multiplicand
+  // of a v_fmac_f32 (sigma = +1 on even, -1 on odd lanes): even lanes a0 + a1, odd lanes a1 - a0, i.e. the odd lanes hold
+  // the NEGATED result.  That is layout S-: bin k of thread tid carries the factor sigma(tid) = (-1)^k4.  A pointwise
+  // product of two S- spectra is a plain layout-S spectrum (sigma^2 = 1), and the transposed factorisation never mixes
+  // the two lane parities again (n4 = tid & 1 stays a passive time-index digit), so transposed<FLIP> returns natural
+  // time order with the samples of odd threads negated -- a sign the caller folds into its next multiply-add.
+  template <bool FLIP = false>
   static __device__ __forceinline__ void lane_pair_dft2(f32x2 (&v)[8], int tid) {
     const float sgn = (tid & 1) ? -1.0f : 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (FLIP) {
+      // sixteen v_fmac_f32 with a DPP multiplicand in one block (VOP2: the compiler's own form of this expression is two
+      // v_mov_b32_dpp and one packed multiply-add per complex value).  The block opens with the two wait states a DPP
+      // read needs behind the vector instruction that wrote its source; inside it no instruction reads another's result.
+      float r[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r[2 * k] = v[k].x; r[2 * k + 1] = v[k].y; }
+#define DDSP_FD(i) "v_fmac_f32_dpp %" #i ", %" #i ", %16 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      asm("s_nop 1\n" DDSP_FD(0) DDSP_FD(1) DDSP_FD(2) DDSP_FD(3) DDSP_FD(4) DDSP_FD(5) DDSP_FD(6) DDSP_FD(7)
+          DDSP_FD(8) DDSP_FD(9) DDSP_FD(10) DDSP_FD(11) DDSP_FD(12) DDSP_FD(13) DDSP_FD(14) DDSP_FD(15)
+          : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+            "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+          : "v"(sgn));
+#undef DDSP_FD
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = f32x2{r[2 * k], r[2 * k + 1]};
+      return;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       // mov_dpp (no "old" operand: every lane of a quad_perm has a valid source, so the destination needs no initial value)
       const float px = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[k].x), 0xB1, 0xF, 0xF, true));
       const float py = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[k].y), 0xB1, 0xF, 0xF, true));
-      v[k] = f32x2{fmaf(sgn, v[k].x, px), fmaf(sgn, v[k].y, py)};        // quad_perm [1,0,3,2]: the neighbour's value
+      if (FLIP) v[k] = f32x2{fmaf(px, sgn, v[k].x), fmaf(py, sgn, v[k].y)};
+      else v[k] = f32x2{fmaf(sgn, v[k].x, px), fmaf(sgn, v[k].y, py)};  // quad_perm [1,0,3,2]: the neighbour's value
     }
   }
   // v[n1] = z[P n1 + tid] -> v[k3] = Z[s_index(tid, k3)].  X must be free of readers on entry; on return X is free
   // and Y may still be read by slower waves.
   // HI_ZERO: v[4..7] are zero on entry (input zero-padded from 512 to 1024 points)
-  template <bool HI_ZERO = false>
+  // FLIP: layout S- (lane_pair_dft2 above)
+  template <bool HI_ZERO = false, bool FLIP = false>
   static __device__ __forceinline__ void forward_s(f32x2 (&v)[8], const Tw& tw, f32x2* X, f32x2* Y, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
     if (HI_ZERO) dft8_lo4(v);
     else dft8(v);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+    twiddle7(v, tw.w1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) X[k * P + (tid ^ ((k & 1) * C))] = v[k];             // odd rows: 16-blocks swapped in pairs
     __syncthreads();
@@ -147,8 +172,7 @@ struct Plan {
 #pragma unroll
       for (int n2 = 0; n2 < 8; ++n2) v[n2] = X[k1 * P + (n2 ^ (k1 & 1)) * C + c];    // rows k1, k1 + 1 of a 32-lane read: other banks
       dft8(v);
-#pragma unroll
-      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      twiddle7(v, tw.w2);
       const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) Y[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];
@@ -157,21 +181,19 @@ struct Plan {
 #pragma unroll
     for (int n3 = 0; n3 < 8; ++n3) v[n3] = Y[n3 * P + (tid ^ (n3 * R))];
     dft8(v);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
-    lane_pair_dft2(v, tid);
+    twiddle7(v, tw.w3);
+    lane_pair_dft2<FLIP>(v, tid);
   }
   // Two independent transforms in lockstep (u through X0 / Y0, v through X1 / Y1): the same passes as forward_s, but
   // each barrier serves both, and between two barriers a wave has the other transform's arithmetic to issue while one
   // transform's LDS round trip is in flight -- half the barriers, twice the independent work per interval.
-  template <bool HI_ZERO = false>
+  template <bool HI_ZERO = false, bool FLIP = false>
   static __device__ __forceinline__ void forward_s2(f32x2 (&u)[8], f32x2 (&v)[8], const Tw& tw, f32x2* X0, f32x2* Y0,
                                                     f32x2* X1, f32x2* Y1, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
     if (HI_ZERO) { dft8_lo4(u); dft8_lo4(v); }
     else { dft8(u); dft8(v); }
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w1[k]); v[k] = cmul(v[k], tw.w1[k]); }
+    twiddle7x2(u, tw.w1, v, tw.w1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { X0[k * P + (tid ^ ((k & 1) * C))] = u[k]; X1[k * P + (tid ^ ((k & 1) * C))] = v[k]; }
     __syncthreads();
@@ -184,8 +206,7 @@ struct Plan {
       }
       dft8(u);
       dft8(v);
-#pragma unroll
-      for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w2[k]); v[k] = cmul(v[k], tw.w2[k]); }
+      twiddle7x2(u, tw.w2, v, tw.w2);
       const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
@@ -199,19 +220,18 @@ struct Plan {
     for (int n3 = 0; n3 < 8; ++n3) { u[n3] = Y0[n3 * P + (tid ^ (n3 * R))]; v[n3] = Y1[n3 * P + (tid ^ (n3 * R))]; }
     dft8(u);
     dft8(v);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { u[k] = cmul(u[k], tw.w3[k]); v[k] = cmul(v[k], tw.w3[k]); }
-    lane_pair_dft2(u, tid);
-    lane_pair_dft2(v, tid);
+    twiddle7x2(u, tw.w3, v, tw.w3);
+    lane_pair_dft2<FLIP>(u, tid);
+    lane_pair_dft2<FLIP>(v, tid);
   }
   // v[k3] = Z[s_index(tid, k3)] -> v[m] = sum_k Z[k] W_N^(k (P m + tid)).  Y must be free of readers on entry; X
   // becomes free at the first barrier (its last readers are whoever used it before this call); on return Y is
   // free and X may still be read by slower waves.
+  template <bool FLIP = false>
   static __device__ __forceinline__ void transposed(f32x2 (&v)[8], const Tw& tw, f32x2* Y, f32x2* X, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
-    lane_pair_dft2(v, tid);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w3[k]);
+    lane_pair_dft2<FLIP>(v, tid);
+    twiddle7(v, tw.w3);
     dft8(v);
     const int ts = tid ^ (((tid / R) & 1) * C);                  // tid = n4 + R k1 + 8R k2: odd k1 sit in the neighbouring 16-block
 #pragma unroll
@@ -222,8 +242,7 @@ struct Plan {
       const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) v[k2] = Y[n3 * P + (((k2 ^ (k1 & 1)) * C + k1 * R + n4) ^ (n3 * R))];   // rows k1, k1 + 1: other banks
-#pragma unroll
-      for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w2[k]);
+      twiddle7(v, tw.w2);
       dft8(v);
 #pragma unroll
       for (int n2 = 0; n2 < 8; ++n2) X[k1 * P + n2 * C + c] = v[n2];
@@ -231,8 +250,7 @@ struct Plan {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = X[k * P + tid];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.w1[k]);
+    twiddle7(v, tw.w1);
     dft8(v);
   }
   // transposed(v) and forward_s<true>(u) in lockstep: an inverse transform (layout S -> natural order) beside the forward
@@ -240,13 +258,13 @@ struct Plan {
   // columns each, in opposite order, so every barrier serves both and each wave has the other transform's arithmetic to
   // issue while one's LDS round trip is in flight.  Four distinct buffers: Yv and Xu must be free of readers on entry,
   // Xv and Yu become free at the first barrier; on return Yv and Xu are free, Xv and Yu may still be read by slower waves.
+  template <bool FLIP = false>
   static __device__ __forceinline__ void transposed_and_forward_s(f32x2 (&v)[8], f32x2 (&u)[8], const Tw& tw, f32x2* Yv,
                                                                   f32x2* Xv, f32x2* Xu, f32x2* Yu, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
-    lane_pair_dft2(v, tid);
+    lane_pair_dft2<FLIP>(v, tid);
     dft8_lo4(u);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w3[k]); u[k] = cmul(u[k], tw.w1[k]); }
+    twiddle7x2(v, tw.w3, u, tw.w1);
     dft8(v);
     const int ts = tid ^ (((tid / R) & 1) * C);
 #pragma unroll
@@ -264,8 +282,7 @@ struct Plan {
         u[k] = Xu[k1 * P + (k ^ (k1 & 1)) * C + c];
       }
       dft8(u);
-#pragma unroll
-      for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w2[k]); u[k] = cmul(u[k], tw.w2[k]); }
+      twiddle7x2(v, tw.w2, u, tw.w2);
       dft8(v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -277,10 +294,9 @@ struct Plan {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { v[k] = Xv[k * P + tid]; u[k] = Yu[k * P + (tid ^ (k * R))]; }
     dft8(u);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { v[k] = cmul(v[k], tw.w1[k]); u[k] = cmul(u[k], tw.w3[k]); }
+    twiddle7x2(v, tw.w1, u, tw.w3);
     dft8(v);
-    lane_pair_dft2(u, tid);
+    lane_pair_dft2<FLIP>(u, tid);
   }
 };
 

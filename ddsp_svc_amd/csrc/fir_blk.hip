@@ -7,11 +7,17 @@
 // with the result of block b placed at output position b hop - N/2 (last tap row held,
 // core.py:167).  With hop = 512 and N <= 512 every one of these linear convolutions (<= 1023 samples) fits a
 // 1024-point transform, so per hop block the work is
-//     Zx = FFT(x_b (1-lambda) + i x_b lambda)      -> X1, X2          one transform per block
-//     Zh = FFT(taps'_j + i taps'_j+1)              -> H_j, H_j+1      half a transform per block
-//     y_b + i y_b+1 = IFFT(Y_b + i Y_b+1),  Y_b = X1 H_b + X2 H_b+1   half a transform per block
+//     Z_b = FFT(x_b (1-lambda) + i x_b lambda)                        one transform per block
+//     T   = FFT(taps'_j + i taps'_j+1)  -> H_j, H_j+1                 half a transform per block
+//     y_b = Re IFFT(Z_b G_b),  G_b = H_b - i H_b+1                    half a transform per block (two blocks per inverse)
 // = two 1024-point complex FFTs per 512 output samples, against 1.5 2048-point ones in k_fir_fft (fir_fft.hip):
-// 40 % fewer flops and a third less LDS exchange traffic.
+// 40 % fewer flops and a third less LDS exchange traffic.  The product needs no separation of the packed block
+// transform: (x1 + i x2) * (h_b - i h_b+1) has x1 * h_b + x2 * h_b+1 as its real part, so W_b = Z_b G_b is ONE complex
+// product per bin, and taking real parts of two blocks at once is the Hermitian split of the PRODUCTS,
+//     V = Y_b + i Y_b+1 = (A[k] + conj B[-k]) / 2,    A = W_b + i W_b+1,  B = W_b - i W_b+1,
+// one parked array and one mirrored read per pair (round 2 separated X1, X2 of both blocks first: 15 instead of 7 packed
+// instructions per bin pair, two parked arrays).  Of the tap transform, G_j = conj T[-k] comes straight out of the
+// mirrored read; G_j-1 = H_j-1 - i H_j takes the carried H_j-1.
 //
 // A 128-thread workgroup (2 waves, fft_r.h with R = 2) walks a run of consecutive block pairs of one utterance
 // and keeps the spectra of three tap rows in registers.  The taps enter the transform shifted by 256 - N/2: they
@@ -55,7 +61,9 @@ struct FirBlkGeom {
 };
 
 // RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
-template <int WPS, bool RNG = false>
+// ADD / PLAIN: an addend is added to the stored result / the result is also stored without it (the options of a step's last
+// filter) -- compile-time, so the emission of a pair is one basic block
+template <int WPS, bool RNG = false, bool ADD = false, bool PLAIN = false>
 __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ x, int x_is_u01,
                                                      const float* __restrict__ taps,
                                                      const float* __restrict__ addend, float* __restrict__ out,
@@ -82,20 +90,22 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   const float* tb = taps + (long)bu * g.F * g.N;
   const long ob = (long)bu * g.T;
   const BufF32 out_buf = BufF32::make(out + ob, g.T);
-  const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
-  const BufF32 add_buf = BufF32::make(addend ? addend + ob : out + ob, addend ? g.T : 0);
-  const bool has_addend = addend != nullptr, has_plain = out_plain != nullptr;   // workgroup-uniform: scalar branches
+  const BufF32 plain_buf = BufF32::make(PLAIN ? out_plain + ob : out + ob, PLAIN ? g.T : 0);
+  const BufF32 add_buf = BufF32::make(ADD ? addend + ob : out + ob, ADD ? g.T : 0);
   const float inv_hop = 1.0f / (float)FB_HOP;
   const int tid4 = 4 * tid;
 
   BLK_STAMP(0);
   BLK_STAMP_WHERE(31);
-  // Overlap-add ring: 1024 samples, of which a thread only ever touches the 8 congruent to its id -- they live in
-  // registers.  Transform index n = 128 m + tid of block bb is time (bb - 1/2) hop + n, i.e. ring slot (4 bb - 2 + m) mod 8:
-  // a pair advances the ring by exactly one revolution, so every slot index below is a compile-time constant.
-  float ring[S];
+  // Overlap-add ring: 1024 samples, of which a thread only ever touches the 8 congruent to its id.  Transform index
+  // n = 128 m + tid of block bb is time (bb - 1/2) hop + n, i.e. ring slot (4 bb - 2 + m) mod 8: a pair advances the ring by
+  // exactly one revolution and every slot receives exactly two contributions -- the upper half (m >= 4) of one block's result,
+  // then the lower half of the next block's, which completes it.  So nothing is accumulated in place: the first
+  // contribution just stays where the transform left it (within a pair: the registers of V; across pairs: the four values
+  // carried in `tail`), and a sample is formed when its second contribution arrives.
+  float tail[4];                                                // -sigma times the upper half of the previous pair's second block
 #pragma unroll
-  for (int m = 0; m < S; ++m) ring[m] = 0.f;
+  for (int m = 0; m < 4; ++m) tail[m] = 0.f;
   // Global loads are issued at the top of a pair: the blocks of the NEXT pair, and the tap rows whose transform rides
   // beside this pair's inverse (see the loop).
   // One tap row, shifted: the value at transform index n = 128 m + tid is taps[row][n - SH]; only m < 4 can be live.
@@ -151,31 +161,64 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
   };
   // Every spectral array of this kernel lives in the scrambled layout S of fft_r.h (slot m of thread tid holds bin
-  // kS0 + 64 m); for the mirrored read Z[-k] a transform's bins are parked in LDS by (swizzled) bin index.
+  // kS0 + 64 m) -- the transforms' outputs in its sign-carrying form S- (odd threads hold the negated bin, fft_r.h
+  // lane_pair_dft2<FLIP>: one instruction per value for the lane-pair step).  Block spectra Z and filter spectra G both
+  // carry that sign, so their product W is plain layout S; for the mirrored read [-k] an array is parked in LDS by
+  // (swizzled) bin index.
   const int kS0 = PL::s_index(tid, 0);
   const int kP0 = PL::parked(kS0);                              // where slot 0 is parked (bits 3, 4, 9 are not touched by 64 m)
-  auto park = [&](const f32x2 (&z)[S], f32x2* X) {
-#pragma unroll
-    for (int m = 0; m < S; ++m) X[kP0 + 64 * m] = z[m];
-  };
   auto mirrored = [&](const f32x2* X, int m) -> f32x2 { return X[PL::parked((NF - (kS0 + 64 * m)) & (NF - 1))]; };
-  const float ch = 0.25f / (float)NF;                          // the 1/2 of both splits and the 1/N of the inverse
-  // Ga = ch * H_j, Gb = ch * H_j+1 from Z = FFT(h_j + i h_j+1) (in z, and parked in Zp):  H_j = (Z[k] + conj Z[-k]) / 2,
-  // H_j+1 = (Z[k] - conj Z[-k]) / 2i
-  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Ga)[S], f32x2 (&Gb)[S]) {
+  const float sg = (tid & 1) ? -1.0f : 1.0f;                   // the sign layout S- puts on this thread's bins / samples
+  const float nsg = -sg;
+  // A tap transform T' (S-) is parked as it is, except bins 0 and 512 -- slot 0 of threads 0, 1 --, which are their own
+  // mirror images: every other bin's mirror image lives on a thread of the OTHER parity and so comes back with the
+  // opposite sign, and negating these two makes the split below one formula for all bins.
+  const float self_mirror = tid < 2 ? -1.0f : 1.0f;
+  auto park_taps = [&](const f32x2 (&z)[S], f32x2* X) {
+    X[kP0] = z[0] * f32x2{self_mirror, self_mirror};
 #pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const f32x2 zneg = mirrored(Zp, m);
-      const f32x2 p = fft::add_conj(z[m], zneg);                // 2 H_j
-      const f32x2 d = fft::sub_conj(z[m], zneg);                // 2i H_j+1
-      Ga[m] = p * ch;
-      Gb[m] = f32x2{d.y * ch, -d.x * ch};                      // d / i
+    for (int m = 1; m < S; ++m) X[kP0 + 64 * m] = z[m];
+  };
+  // From T = FFT(h_j + i h_j+1) (z in S-, parked in Zp; Tn = the parked mirror image, sign opposite to z's) and the carried
+  // Hc = c H_j-1, with c = 1 / 2N (the 1/2 of the Hermitian split of the products and the 1/N of the inverse):
+  //     G1 = c (H_j - i H_j+1)   = c conj T[-k]                 -> - c conj Tn
+  //     G0 = c (H_j-1 - i H_j)   = Hc - i (c/2) (T + conj T[-k])  -> Hc - i (c/2) (z - conj Tn)
+  //     Hc' = c H_j+1            = (c/2) (T - conj T[-k]) / i     -> -i (c/2) (z + conj Tn)
+  const float ch = 0.5f / (float)NF;
+  const f32x2 kG1 = {-ch, ch};
+  const f32x2 kMi = {0.5f * ch, -0.5f * ch};                   // times (-i) after the half swap of swap_scale
+  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Hc)[S], f32x2 (&G0)[S], f32x2 (&G1)[S]) {
+#pragma unroll
+    for (int m = 0; m < S; m += 2) {                            // two bins interleaved: no instruction consumes its predecessor's result
+      const f32x2 tn0 = mirrored(Zp, m), tn1 = mirrored(Zp, m + 1);
+      const f32x2 p0 = fft::sub_conj(z[m], tn0), p1 = fft::sub_conj(z[m + 1], tn1);
+      const f32x2 d0 = fft::add_conj(z[m], tn0), d1 = fft::add_conj(z[m + 1], tn1);
+      G1[m] = tn0 * kG1;
+      G1[m + 1] = tn1 * kG1;
+      G0[m] = fft::swap_scale_add(p0, kMi, Hc[m]);
+      G0[m + 1] = fft::swap_scale_add(p1, kMi, Hc[m + 1]);
+      Hc[m] = fft::swap_scale(d0, kMi);
+      Hc[m + 1] = fft::swap_scale(d1, kMi);
     }
   };
-  // Y = X1 H_b + X2 H_b+1 = p G_b - i d G_b+1 with p = 2 X1, d = 2i X2 from the packed block transform (z, parked in Zp)
-  auto filtered = [&](f32x2 zm, const f32x2* Zp, int m, f32x2 G0, f32x2 G1) -> f32x2 {
-    const f32x2 zn = mirrored(Zp, m);
-    return fft::add_mi(cmul(fft::add_conj(zm, zn), G0), cmul(fft::sub_conj(zm, zn), G1));
+  // W0 = Z0 G0, W1 = Z1 G1 (plain layout S);  A = W0 + i W1 stays in a, B = W0 - i W1 is parked for the mirrored read
+  auto products = [&](const f32x2 (&za)[S], const f32x2 (&zb)[S], const f32x2 (&G0)[S], const f32x2 (&G1)[S], f32x2 (&a)[S], f32x2* Bp) {
+#pragma unroll
+    for (int m = 0; m < S; m += 2) {                            // four products in flight
+      const f32x2 t0 = fft::cmul_lo(za[m], G0[m]), t1 = fft::cmul_lo(zb[m], G1[m]);
+      const f32x2 t2 = fft::cmul_lo(za[m + 1], G0[m + 1]), t3 = fft::cmul_lo(zb[m + 1], G1[m + 1]);
+      const f32x2 w0 = fft::cmul_hi(za[m], G0[m], t0), w1 = fft::cmul_hi(zb[m], G1[m], t1);
+      const f32x2 w2 = fft::cmul_hi(za[m + 1], G0[m + 1], t2), w3 = fft::cmul_hi(zb[m + 1], G1[m + 1], t3);
+      a[m] = fft::sub_mi(w0, w1);
+      a[m + 1] = fft::sub_mi(w2, w3);
+      Bp[kP0 + 64 * m] = fft::add_mi(w0, w1);
+      Bp[kP0 + 64 * (m + 1)] = fft::add_mi(w2, w3);
+    }
+  };
+  // conj V = conj(Y_b + i Y_b+1) = B[-k] + conj A[k]  (the scale is in G), conjugated for the inverse-by-forward trick
+  auto hermitian = [&](f32x2 (&a)[S], const f32x2* Bp) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) a[m] = fft::add_conj(mirrored(Bp, m), a[m]);
   };
 
   // The four exchange buffers have fixed roles.  A pair is two lockstep stages (fft_r.h), three barriers each:
@@ -189,11 +232,11 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   f32x2* const bC = ex[2];
   f32x2* const bD = ex[3];
 
-  // Prologue.  The loop wants the spectra of its first pair's three tap rows (Gc, Ga, Gb) and the predecessor's tail in
+  // Prologue.  The loop wants the filter spectra of its first pair (G0, G1, and Hc for the pair after) and the predecessor's tail in
   // the ring.  Of the pair before the run only its SECOND block b_w = 2 q_first - 1 reaches into the run's first emitted
   // sample (the result of block b ends before (b + 3/2) hop), so the warm-up is that one block, and it has the shape of
   // a loop pass: [rows b_w, b_w+1 | block b_w] in lockstep, product, then [inverse | rows of the first pair] in lockstep.
-  // An utterance's first run has no predecessor: a zero block, and row 0 twice (Gc = H_0).
+  // An utterance's first run has no predecessor: a zero block, and row 0 twice (Hc = c H_0).
   // What the first transform needs is fetched first.
   const int bw = 2 * q_first - 1;
   const TapRow pa = load_taps(bw > 0 ? bw : 0), pb = load_taps(bw + 1);
@@ -203,28 +246,28 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   typename PL::Tw tw;                                           // the twiddles are formed while those loads are in flight
   tw.init(tid);
   BLK_STAMP(1);
-  f32x2 Ga[S], Gb[S], Gc[S];
+  f32x2 Hc[S], G0[S], G1[S];
   {
-    f32x2 zt[S], zx[S];
+    f32x2 zt[S], zx[S], zero[S];
     pack_taps(pa, pb, zt);
     pack_blk(px, bw >= 0, zx);
-    PL::template forward_s2<true>(zt, zx, tw, bA, bC, bB, bD, tid);
-    park(zt, bA);
-    park(zx, bB);
-    __syncthreads();
-    f32x2 G1[S];
-    split_taps(zt, bA, G1, Gc);                                 // H_b_w, H_b_w+1 -- the second is the loop's first Gc
 #pragma unroll
-    for (int m = 0; m < S; ++m)                                 // the odd block of a pair rides in the imaginary part
-      zx[m] = fft::conj_minus_i_conj(f32x2{0.f, 0.f}, filtered(zx[m], bB, m, G1[m], Gc[m]));
+    for (int m = 0; m < S; ++m) { zero[m] = f32x2{0.f, 0.f}; Hc[m] = f32x2{0.f, 0.f}; }
+    PL::template forward_s2<true, true>(zt, zx, tw, bA, bC, bB, bD, tid);
+    park_taps(zt, bA);
+    __syncthreads();
+    split_taps(zt, bA, Hc, G0, G1);                             // G1 = c (H_b_w - i H_b_w+1), Hc = c H_b_w+1 -- the loop's first
+    products(zero, zx, G1, G1, zx, bB);                         // the odd block of a pair rides in the imaginary part
+    __syncthreads();
+    hermitian(zx, bB);
     pack_taps(t1, t2, zt);
-    PL::transposed_and_forward_s(zx, zt, tw, bC, bA, bD, bB, tid);
-    park(zt, bC);
+    PL::template transposed_and_forward_s<true>(zx, zt, tw, bC, bA, bD, bB, tid);
+    park_taps(zt, bC);
     __syncthreads();
-    split_taps(zt, bC, Ga, Gb);
-    // block b_w sits where the second block of a pair does: slots (2 + m) & 7; its first four belong to the predecessor
+    split_taps(zt, bC, Hc, G0, G1);
+    // block b_w sits where the second block of a pair does; the lower half of its result belongs to the predecessor
 #pragma unroll
-    for (int m = 4; m < S; ++m) ring[(2 + m) & 7] = -zx[m].y;
+    for (int m = 0; m < 4; ++m) tail[m] = zx[4 + m].y;
   }
 
   BLK_STAMP(2);
@@ -247,18 +290,12 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     t2 = load_taps(b0 + 4);
     x0 = load_blk(b0 + 2);
     x1 = load_blk(b0 + 3);
-    PL::template forward_s2<true>(z0, z1, tw, bA, bC, bB, bD, tid);
-    park(z0, bA);
-    park(z1, bB);
+    PL::template forward_s2<true, true>(z0, z1, tw, bA, bC, bB, bD, tid);
+    f32x2 V[S];
+    products(z0, z1, G0, G1, V, bA);
     __syncthreads();
     if (stamp_it) BLK_STAMP_CYC(25);
-    f32x2 V[S];
-#pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const f32x2 y0 = filtered(z0[m], bA, m, Gc[m], Ga[m]);
-      const f32x2 y1 = filtered(z1[m], bB, m, Ga[m], Gb[m]);
-      V[m] = fft::conj_minus_i_conj(y0, y1);                    // V = Y_b0 + i Y_b0+1, conjugated for the inverse-by-forward trick
-    }
+    hermitian(V, bA);                                           // V = conj(Y_b0 + i Y_b0+1)
     // the addend of the 1024 samples this pair emits is fetched now and lands during the inverse transform.  Emitted times
     // of this thread: t = e0 + 128 i, i = 0..7 (and 8..11 for the flush).  e0 >= -256, and negative times are exactly
     // i = 0, 1 of an utterance's first pair -- for every lane -- so those two take a base that a scalar select turns into
@@ -270,52 +307,40 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     auto t_off = [&](int i) -> int { return i < 2 ? off_a + 4 * P * i : off_b + 4 * P * (i - 2); };
     float add[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) add[i] = 0.f;
-    if (has_addend) {
-#pragma unroll
-      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));
-    }
+    for (int i = 0; i < S; ++i) add[i] = ADD ? add_buf.ld(t_off(i)) : 0.f;
     if (stamp_it) BLK_STAMP_CYC(26);
     // back to time order (the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid),
     // beside the transform of the next pair's tap rows b0 + 3, b0 + 4
     f32x2 zt[S];
     pack_taps(t1, t2, zt);
-    PL::transposed_and_forward_s(V, zt, tw, bC, bA, bD, bB, tid);
-    park(zt, bC);
+    PL::template transposed_and_forward_s<true>(V, zt, tw, bC, bA, bD, bB, tid);
+    park_taps(zt, bC);
     __syncthreads();
     if (stamp_it) BLK_STAMP_CYC(27);
-    // the spectrum of tap row b0 + 2 moves on to the next pair as its first
-#pragma unroll
-    for (int m = 0; m < S; ++m) Gc[m] = Gb[m];
-    split_taps(zt, bC, Ga, Gb);
+    split_taps(zt, bC, Hc, G0, G1);                             // the spectrum of tap row b0 + 2 moves on in Hc
     if (stamp_it) BLK_STAMP_CYC(28);
-    // ifft = conj(FFT(conj V)): y_b0 = Re, y_b0+1 = -Im.  Transform index n of block bb is time (bb - 1/2) hop + n.
+    // ifft = conj(FFT(conj V)): y_b0 = sigma Re V, y_b0+1 = -sigma Im V (sigma: this thread's sign, layout S- through the
+    // transposed factorisation).  Emitted sample i of the pair, time e0 + 128 i:
+    //     i = 0..3   lower half of block b0 on top of the previous pair's tail:      sigma (Re V[i] - tail[i])
+    //     i = 4..7   lower half of block b0 + 1 on top of the upper half of b0:      sigma (Re V[i] - Im V[i - 4])
+    // times below (bb + 1/2) hop are final once block bb is in; stores outside [0, T) are dropped by the descriptor
     const bool last = q == g.pairs - 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      constexpr int kRot[2] = {6, 2};                           // ring slot of transform index 128 m: (4 h - 2 + m) & 7
-#pragma unroll
-      for (int m = 0; m < S; ++m) ring[(kRot[h] + m) & 7] += h == 0 ? V[m].x : -V[m].y;
-      // times below (bb + 1/2) hop are final once block bb is in (the next block's result starts there): emit indices
-      // 128 m, m = 0..3, i.e. emitted sample i = 4 h + m of the pair; stores outside [0, T) are dropped by the descriptor
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int ri = (kRot[h] + m) & 7;
-        const float v = ring[ri];
-        ring[ri] = 0.f;
-        const int off = t_off(4 * h + m);
-        if (has_plain) plain_buf.st(v, off);
-        out_buf.st(v + add[4 * h + m], off);
-      }
+    for (int i = 0; i < S; ++i) {
+      const float d = i < 4 ? V[i].x - tail[i] : V[i].x - V[i - 4].y;
+      const int off = t_off(i);
+      if (PLAIN) plain_buf.st(sg * d, off);
+      out_buf.st(ADD ? fmaf(sg, d, add[i]) : sg * d, off);
     }
-    if (last) {                                                 // the last pair also flushes what is left of the ring
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tail[m] = V[4 + m].y;
+    if (last) {                                                 // the last pair also emits the upper half of its second block
 #pragma unroll
       for (int m = 4; m < S; ++m) {
-        const int ri = (2 + m) & 7;
         const int off = t_off(4 + m);                           // t = (b0 + 1/2) hop + 128 m + tid
-        const float v = ring[ri];
-        if (has_plain) plain_buf.st(v, off);
-        out_buf.st(v + (has_addend ? add_buf.ld(off) : 0.f), off);
+        const float v = nsg * V[m].y;
+        if (PLAIN) plain_buf.st(v, off);
+        out_buf.st(v + (ADD ? add_buf.ld(off) : 0.f), off);
       }
     }
     if (stamp_it) BLK_STAMP_CYC(29);
@@ -369,23 +394,24 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
+  // the four emission variants (addend / second plain output) are compile-time: one basic block per pair
+#define DDSP_BLK_LAUNCH(W, R, LDS, XU)                                                                                            \
+  do {                                                                                                                            \
+    if (addend && out_plain) hipLaunchKernelGGL((k_fir_blk<W, R, true, true>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);       \
+    else if (addend) hipLaunchKernelGGL((k_fir_blk<W, R, true, false>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);            \
+    else if (out_plain) hipLaunchKernelGGL((k_fir_blk<W, R, false, true>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);         \
+    else hipLaunchKernelGGL((k_fir_blk<W, R, false, false>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);                        \
+  } while (0)
   if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
     rng = *noise_gen;
-    hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+    DDSP_BLK_LAUNCH(2, true, 0, 0);
     return 5;
   }
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
-  if (pad > 0) {
-    hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
-    return 5;
-  }
-  if (wps >= 4)
-    hipLaunchKernelGGL((k_fir_blk<4, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
-  else if (wps == 3)
-    hipLaunchKernelGGL((k_fir_blk<3, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
-  else
-    hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
+  if (wps >= 3 && pad == 0) DDSP_BLK_LAUNCH(3, false, 0, x_is_u01);
+  else DDSP_BLK_LAUNCH(2, false, pad, x_is_u01);
+#undef DDSP_BLK_LAUNCH
   return 5;
 }
 

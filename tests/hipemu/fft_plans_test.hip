@@ -12,6 +12,8 @@ using ddsp::fft::Plan;
 // mode 3: Plan<2>::transposed              in[k] is read into layout S, out natural = DFT of in
 // mode 4: Plan<2>::forward_s2<true>        two inputs (in, in2) -> (out, out2), both as mode 2
 // mode 5: Plan<2>::transposed_and_forward_s   in -> out as mode 3, in2 -> out2 as mode 2
+// modes 6..9: modes 2..5 in the sign-carrying layout S- (FLIP = true): what odd threads hold is written out negated
+//             again, so the expected values are those of modes 2..5
 template <int R>
 __global__ void k_plan(int mode, const f32x2* in, const f32x2* in2, f32x2* out, f32x2* out2) {
   using PL = Plan<R>;
@@ -44,6 +46,24 @@ __global__ void k_plan(int mode, const f32x2* in, const f32x2* in2, f32x2* out, 
       for (int m = 0; m < 8; ++m) { v[m] = in[PL::s_index(tid, m)]; u[m] = in2[P * m + tid]; }
       PL::transposed_and_forward_s(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
       for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m]; out2[PL::s_index(tid, m)] = u[m]; }
+    }
+    const float sg = (tid & 1) ? -1.0f : 1.0f;
+    if (mode == 6) {
+      for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
+      PL::template forward_s<true, true>(v, tw, ex[0], ex[1], tid);
+      for (int m = 0; m < 8; ++m) out[PL::s_index(tid, m)] = v[m] * sg;
+    } else if (mode == 7) {
+      for (int m = 0; m < 8; ++m) v[m] = in[PL::s_index(tid, m)];
+      PL::template transposed<true>(v, tw, ex[0], ex[1], tid);
+      for (int m = 0; m < 8; ++m) out[P * m + tid] = v[m] * sg;
+    } else if (mode == 8) {
+      for (int m = 0; m < 8; ++m) { v[m] = in[P * m + tid]; u[m] = in2[P * m + tid]; }
+      PL::template forward_s2<true, true>(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+      for (int m = 0; m < 8; ++m) { out[PL::s_index(tid, m)] = v[m] * sg; out2[PL::s_index(tid, m)] = u[m] * sg; }
+    } else if (mode == 9) {
+      for (int m = 0; m < 8; ++m) { v[m] = in[PL::s_index(tid, m)]; u[m] = in2[P * m + tid]; }
+      PL::template transposed_and_forward_s<true>(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+      for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m] * sg; out2[PL::s_index(tid, m)] = u[m] * sg; }
     }
   }
 }

@@ -79,6 +79,19 @@ def test_lockstep_forms_equal_their_parts(plans):
     assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, one_b)
 
 
+def test_sign_carrying_layout(plans):
+    """layout S- (one v_fmac_f32 with a DPP operand per value in the lane-pair step; odd threads hold negated values): with the
+    sign undone the transforms are those of the plain layout -- the lane-pair step computes a0 - a1 as -(a1 - a0), exactly"""
+    a, b = _rand(1024, 30, half=True), _rand(1024, 31, half=True)
+    v = _rand(1024, 32)
+    assert np.array_equal(plans(2, 6, a)[0], plans(2, 2, a)[0])
+    assert np.array_equal(plans(2, 7, v)[0], plans(2, 3, v)[0])
+    two_a, two_b = plans(2, 8, a, b)
+    assert np.array_equal(two_a, plans(2, 2, a)[0]) and np.array_equal(two_b, plans(2, 2, b)[0])
+    inv, fwd = plans(2, 9, v, b)
+    assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, plans(2, 2, b)[0])
+
+
 def test_emulator_selftest():
     """the emulator's own kernels (LDS reversal across a barrier, a wave scan through shuffles, one f32 MFMA, work-items
     that leave before a barrier): tests/hipemu/selftest.hip"""

@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
 V=${V:-ab3}
 timeout 900 python -m pytest tests/test_parity.py tests/test_parity_fast.py tests/test_mel.py tests/test_fullsize_gpu.py tests/test_fuzz.py tests/test_backward_fir.py tests/test_backward_fast.py -m gpu -x -q 2>&1 | tail -4 | tee "$O/${V}_pytest_subset.log"
-B="python bench.py --no-cpu-baseline --no-module-mode"
+B="python bench.py --no-cpu-baseline --no-module-mode --no-live-traffic --no-also"
 run() { tag=$1; shift; env "$@" timeout 300 $B 2>&1 | tail -1 > "$O/${V}_bench_$tag.json"; }
 for rep in 1 2; do
   run prev_$rep DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_prev.so
@@ -13,8 +13,8 @@ for rep in 1 2; do
   run cur_one_$rep DDSP_HIP_ONE_STREAM=1
 done
 for m in sins combsubsuperfast combsubfast mel; do
-  env timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_${m}_cur.json"
-  env DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_prev.so timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_${m}_prev.json"
+  env timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_${m}_cur.json"
+  env DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_prev.so timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_${m}_prev.json"
 done
 cd /tmp
 DDSP_HIP_ONE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_ab3" -o ab -- python "$R/bench.py" --only-steps --steps 20 --warmup 3 > "$O/prof_ab3.log" 2>&1

@@ -6,8 +6,8 @@ V=${V:-abf}
 timeout 600 python -m pytest tests/test_parity_fast.py tests/test_mel.py tests/test_backward_fast.py -m gpu -x -q 2>&1 | tail -3 | tee "$O/${V}_pytest_subset.log"
 for rep in 1 2; do
   for m in ${MODELS:-combsubfast combsubsuperfast mel}; do
-    env timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_${m}_cur_$rep.json"
-    env DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_prev.so timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_${m}_prev_$rep.json"
+    env timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_${m}_cur_$rep.json"
+    env DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_prev.so timeout 300 python bench.py --model $m --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_${m}_prev_$rep.json"
   done
 done
 python - <<'PY'

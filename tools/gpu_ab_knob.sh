@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
 V=${V:-ab5}; KNOB=${KNOB:-DDSP_HIP_PFA_TR}; VALUES=${VALUES:-"8 2"}
 timeout 900 python -m pytest tests/test_parity.py tests/test_baseline_shapes.py -m gpu -x -q -k "prime_factor or impulse or tail or cfg1 or filters" 2>&1 | tail -3 | tee "$O/${V}_pytest_subset.log"
-B="python bench.py --model ${MODEL:-combsub} --no-cpu-baseline --no-module-mode"
+B="python bench.py --model ${MODEL:-combsub} --no-cpu-baseline --no-module-mode --no-live-traffic --no-also"
 for rep in 1 2; do
   for v in $VALUES; do
     env $KNOB=$v DDSP_HIP_ONE_STREAM=1 timeout 300 $B 2>&1 | tail -1 > "$O/${V}_bench_${v}_one_$rep.json"

@@ -6,7 +6,7 @@ V=${V:-abl}
 for rep in 1 2; do
   for tag in ${TAGS:-cur}; do
     if [ $tag = cur ]; then lib=""; else lib="DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_$tag.so"; fi
-    env $lib timeout 300 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_${tag}_$rep.json"
+    env $lib timeout 300 python bench.py --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_${tag}_$rep.json"
   done
 done
 python - <<'PY'

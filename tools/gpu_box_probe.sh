@@ -12,7 +12,7 @@ V=${V:-box}
   echo "== kernel params"; cat /proc/cmdline; cat /sys/module/amdgpu/parameters/noretry /sys/module/amdgpu/parameters/vm_fragment_size /sys/module/amdgpu/parameters/sched_policy 2>&1 | tr '\n' ' '; echo
   cat /sys/kernel/mm/transparent_hugepage/enabled 2>&1
   echo "== under load"
-  (python bench.py --no-cpu-baseline --no-module-mode --steps 20000 > "$O/${V}_bench_long.json" 2>&1 &)
+  (python bench.py --no-cpu-baseline --no-module-mode --no-live-traffic --no-also --steps 20000 > "$O/${V}_bench_long.json" 2>&1 &)
   sleep 8
   rocm-smi --showclocks --showpower 2>&1 | grep -v "^$" | head -30
   wait

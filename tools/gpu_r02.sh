@@ -12,10 +12,10 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 timeout 600 python bench.py 2>&1 | tail -1 > "$O/${V}_bench_combsub.json"
 timeout 600 python bench.py --model sins 2>&1 | tail -1 > "$O/${V}_bench_sins.json"
-timeout 300 python bench.py --gather --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_combsub_gather_1rank.json"
+timeout 300 python bench.py --gather --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_combsub_gather_1rank.json"
 timeout 300 python bench.py --gpus 2 --no-cpu-baseline > "$O/${V}_bench_gpus2_on_1gpu.log" 2>&1; echo "exit $?" >> "$O/${V}_bench_gpus2_on_1gpu.log"
 timeout 600 python bench.py --model cascade_seam --batch-per-gpu 64 2>&1 | tail -1 > "$O/${V}_bench_cascade_seam.json"
-DDSP_HIP_ONE_STREAM=1 timeout 300 python bench.py --no-cpu-baseline --no-module-mode 2>&1 | tail -1 > "$O/${V}_bench_combsub_one_stream.json"
+DDSP_HIP_ONE_STREAM=1 timeout 300 python bench.py --no-cpu-baseline --no-module-mode --no-live-traffic --no-also 2>&1 | tail -1 > "$O/${V}_bench_combsub_one_stream.json"
 if [ "${ALL_MODELS:-0}" = "1" ]; then
   for m in combsubfast combsubsuperfast mel sinesrc rssloss; do
     timeout 300 python bench.py --model $m --no-cpu-baseline 2>&1 | tail -1 > "$O/${V}_bench_$m.json"
