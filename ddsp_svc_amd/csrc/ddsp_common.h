@@ -73,6 +73,13 @@ struct Upsampler {
     }
     return at3(r, (long)r.f * hop + j);
   }
+  // the same when the caller knows at compile time that the shift form applies (hop a power of two, F hop <= 2^24): the
+  // general path is not even compiled in -- it is most of the code of the small phase kernels, and code that is not there
+  // is not fetched ("instruction cache")
+  __device__ __forceinline__ float at3_pow2(const Row3& r, int j) const {
+    const float l1 = (float)j * scale;
+    return fmaf(1.0f - l1, r.b, l1 * r.c);
+  }
   __device__ __forceinline__ float at(const float* __restrict__ row, long stride, long t) const {
     int i0, i1;
     float l0, l1;

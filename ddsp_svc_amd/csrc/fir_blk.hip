@@ -61,9 +61,10 @@ struct FirBlkGeom {
 };
 
 // RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
-// ADD / PLAIN: an addend is added to the stored result / the result is also stored without it (the options of a step's last
-// filter) -- compile-time, so the emission of a pair is one basic block
-template <int WPS, bool RNG = false, bool ADD = false, bool PLAIN = false>
+// An addend added to the stored result and a second, plain output (the options of a step's last filter) are run-time,
+// workgroup-uniform switches: ONE code object serves every filter of a step, so that it stays in the instruction cache
+// from one launch to the next
+template <int WPS, bool RNG = false>
 __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ x, int x_is_u01,
                                                      const float* __restrict__ taps,
                                                      const float* __restrict__ addend, float* __restrict__ out,
@@ -90,8 +91,8 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   const float* tb = taps + (long)bu * g.F * g.N;
   const long ob = (long)bu * g.T;
   const BufF32 out_buf = BufF32::make(out + ob, g.T);
-  const BufF32 plain_buf = BufF32::make(PLAIN ? out_plain + ob : out + ob, PLAIN ? g.T : 0);
-  const BufF32 add_buf = BufF32::make(ADD ? addend + ob : out + ob, ADD ? g.T : 0);
+  const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
+  const BufF32 add_buf = BufF32::make(addend ? addend + ob : out + ob, addend ? g.T : 0);
   const float inv_hop = 1.0f / (float)FB_HOP;
   const int tid4 = 4 * tid;
 
@@ -232,65 +233,60 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   f32x2* const bC = ex[2];
   f32x2* const bD = ex[3];
 
-  // Prologue.  The loop wants the filter spectra of its first pair (G0, G1, and Hc for the pair after) and the predecessor's tail in
-  // the ring.  Of the pair before the run only its SECOND block b_w = 2 q_first - 1 reaches into the run's first emitted
-  // sample (the result of block b ends before (b + 3/2) hop), so the warm-up is that one block, and it has the shape of
-  // a loop pass: [rows b_w, b_w+1 | block b_w] in lockstep, product, then [inverse | rows of the first pair] in lockstep.
-  // An utterance's first run has no predecessor: a zero block, and row 0 twice (Hc = c H_0).
-  // What the first transform needs is fetched first.
+  // One loop body serves the warm-up and the run (the code of a pass exists once: 12 KB instead of 24 -- on part of the
+  // pool an instruction fetch that misses the 64 KB instruction cache is slow enough to cost a cold launch 35 us,
+  // DESIGN.md).  The run's passes want the filter spectra of their pair (G0, G1, and Hc for the pair after) and the
+  // predecessor's tail.  Of the pair before the run only its SECOND block b_w = 2 q_first - 1 reaches into the run's first
+  // emitted sample (the result of block b ends before (b + 3/2) hop), so the warm-up pass q = q_first - 1 transforms
+  // [rows b_w, b_w+1 | block b_w] where a pass of the run has its two blocks, splits those rows at once, filters the one
+  // block (it rides in the imaginary part, where the odd block of a pair does) and emits nothing; everything else --
+  // the loads for the next pass, [inverse | next rows], the split -- is what every pass does.  An utterance's first run
+  // has no predecessor: a zero block, and row 0 twice (Hc = c H_0).
   const int bw = 2 * q_first - 1;
   const TapRow pa = load_taps(bw > 0 ? bw : 0), pb = load_taps(bw + 1);
-  const Blk px = load_blk(bw >= 0 ? bw : g.F);
-  TapRow t1 = load_taps(2 * q_first + 1), t2 = load_taps(2 * q_first + 2);
-  Blk x0 = load_blk(2 * q_first), x1 = load_blk(2 * q_first + 1);
+  Blk x0 = load_blk(bw >= 0 ? bw : g.F), x1 = x0;               // the warm-up pass reads x0 only
+  TapRow t1 = pa, t2 = pb;
   typename PL::Tw tw;                                           // the twiddles are formed while those loads are in flight
   tw.init(tid);
   BLK_STAMP(1);
   f32x2 Hc[S], G0[S], G1[S];
-  {
-    f32x2 zt[S], zx[S], zero[S];
-    pack_taps(pa, pb, zt);
-    pack_blk(px, bw >= 0, zx);
 #pragma unroll
-    for (int m = 0; m < S; ++m) { zero[m] = f32x2{0.f, 0.f}; Hc[m] = f32x2{0.f, 0.f}; }
-    PL::template forward_s2<true, true>(zt, zx, tw, bA, bC, bB, bD, tid);
-    park_taps(zt, bA);
-    __syncthreads();
-    split_taps(zt, bA, Hc, G0, G1);                             // G1 = c (H_b_w - i H_b_w+1), Hc = c H_b_w+1 -- the loop's first
-    products(zero, zx, G1, G1, zx, bB);                         // the odd block of a pair rides in the imaginary part
-    __syncthreads();
-    hermitian(zx, bB);
-    pack_taps(t1, t2, zt);
-    PL::template transposed_and_forward_s<true>(zx, zt, tw, bC, bA, bD, bB, tid);
-    park_taps(zt, bC);
-    __syncthreads();
-    split_taps(zt, bC, Hc, G0, G1);
-    // block b_w sits where the second block of a pair does; the lower half of its result belongs to the predecessor
-#pragma unroll
-    for (int m = 0; m < 4; ++m) tail[m] = zx[4 + m].y;
-  }
+  for (int m = 0; m < S; ++m) { Hc[m] = f32x2{0.f, 0.f}; G0[m] = f32x2{0.f, 0.f}; G1[m] = f32x2{0.f, 0.f}; }
+  const bool has_add = addend != nullptr, has_plain = out_plain != nullptr;   // workgroup-uniform: scalar branches
 
-  BLK_STAMP(2);
   // The two waves that share a SIMD belong to different workgroups, and its arbiter serves the older one first: left
   // alone, one workgroup of each such pair runs ahead and finishes early, and its partner does the rest of its run at
   // single-wave throughput (tools/fir_blk_timeline.py: lifetimes of 83 / 105 us inside one CU).  The waves take turns
   // instead: priority 1 on alternate pairs, the phase taken from the wave slot.
   const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
-  for (int q = q_first; q < q_last; ++q) {
+  for (int q = q_first - 1; q < q_last; ++q) {
+    const bool warm = q < q_first;                              // workgroup-uniform
     if (g.turns && ((q + turn) & 1)) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     const int b0 = 2 * q;
     const bool stamp_it = q - q_first == 5;
     if (stamp_it) BLK_STAMP_CYC(24);
     f32x2 z0[S], z1[S];
-    pack_blk(x0, b0 < g.F, z0);
-    pack_blk(x1, b0 + 1 < g.F, z1);
-    // fetched now: the tap rows of the next pair (their transform rides beside this pair's inverse) and its blocks
+    if (warm) {
+      pack_taps(t1, t2, z0);                                    // rows b_w, b_w + 1
+      pack_blk(x0, bw >= 0, z1);                                // block b_w
+    } else {
+      pack_blk(x0, b0 < g.F, z0);
+      pack_blk(x1, b0 + 1 < g.F, z1);
+    }
+    // fetched now: the tap rows of the next pass (their transform rides beside this pass's inverse) and its blocks
     t1 = load_taps(b0 + 3);
     t2 = load_taps(b0 + 4);
     x0 = load_blk(b0 + 2);
     x1 = load_blk(b0 + 3);
     PL::template forward_s2<true, true>(z0, z1, tw, bA, bC, bB, bD, tid);
+    if (warm) {
+      park_taps(z0, bB);
+      __syncthreads();
+      split_taps(z0, bB, Hc, G0, G1);                           // G1 = c (H_b_w - i H_b_w+1), Hc = c H_b_w+1; G0 is not used:
+#pragma unroll
+      for (int m = 0; m < S; ++m) z0[m] = f32x2{0.f, 0.f};     // the even block of this pass is absent
+    }
     f32x2 V[S];
     products(z0, z1, G0, G1, V, bA);
     __syncthreads();
@@ -307,10 +303,14 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     auto t_off = [&](int i) -> int { return i < 2 ? off_a + 4 * P * i : off_b + 4 * P * (i - 2); };
     float add[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) add[i] = ADD ? add_buf.ld(t_off(i)) : 0.f;
+    for (int i = 0; i < S; ++i) add[i] = 0.f;
+    if (has_add && !warm) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));
+    }
     if (stamp_it) BLK_STAMP_CYC(26);
     // back to time order (the transposed factorisation takes layout S and leaves slot m, lane tid = sample 128 m + tid),
-    // beside the transform of the next pair's tap rows b0 + 3, b0 + 4
+    // beside the transform of the next pass's tap rows b0 + 3, b0 + 4
     f32x2 zt[S];
     pack_taps(t1, t2, zt);
     PL::template transposed_and_forward_s<true>(V, zt, tw, bC, bA, bD, bB, tid);
@@ -324,25 +324,28 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     //     i = 0..3   lower half of block b0 on top of the previous pair's tail:      sigma (Re V[i] - tail[i])
     //     i = 4..7   lower half of block b0 + 1 on top of the upper half of b0:      sigma (Re V[i] - Im V[i - 4])
     // times below (bb + 1/2) hop are final once block bb is in; stores outside [0, T) are dropped by the descriptor
-    const bool last = q == g.pairs - 1;
+    if (!warm) {
+      float d[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-      const float d = i < 4 ? V[i].x - tail[i] : V[i].x - V[i - 4].y;
-      const int off = t_off(i);
-      if (PLAIN) plain_buf.st(sg * d, off);
-      out_buf.st(ADD ? fmaf(sg, d, add[i]) : sg * d, off);
+      for (int i = 0; i < S; ++i) d[i] = i < 4 ? V[i].x - tail[i] : V[i].x - V[i - 4].y;
+      if (has_plain) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) plain_buf.st(sg * d[i], t_off(i));
+      }
+#pragma unroll
+      for (int i = 0; i < S; ++i) out_buf.st(fmaf(sg, d[i], add[i]), t_off(i));   // no addend: + 0
+      if (q == g.pairs - 1) {                                   // the last pair also emits the upper half of its second block
+#pragma unroll
+        for (int m = 4; m < S; ++m) {
+          const int off = t_off(4 + m);                         // t = (b0 + 1/2) hop + 128 m + tid
+          const float v = nsg * V[m].y;
+          if (has_plain) plain_buf.st(v, off);
+          out_buf.st(v + (has_add ? add_buf.ld(off) : 0.f), off);
+        }
+      }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) tail[m] = V[4 + m].y;
-    if (last) {                                                 // the last pair also emits the upper half of its second block
-#pragma unroll
-      for (int m = 4; m < S; ++m) {
-        const int off = t_off(4 + m);                           // t = (b0 + 1/2) hop + 128 m + tid
-        const float v = nsg * V[m].y;
-        if (PLAIN) plain_buf.st(v, off);
-        out_buf.st(v + (ADD ? add_buf.ld(off) : 0.f), off);
-      }
-    }
     if (stamp_it) BLK_STAMP_CYC(29);
     BLK_STAMP(3 + q - q_first);
   }
@@ -394,24 +397,17 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
-  // the four emission variants (addend / second plain output) are compile-time: one basic block per pair
-#define DDSP_BLK_LAUNCH(W, R, LDS, XU)                                                                                            \
-  do {                                                                                                                            \
-    if (addend && out_plain) hipLaunchKernelGGL((k_fir_blk<W, R, true, true>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);       \
-    else if (addend) hipLaunchKernelGGL((k_fir_blk<W, R, true, false>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);            \
-    else if (out_plain) hipLaunchKernelGGL((k_fir_blk<W, R, false, true>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);         \
-    else hipLaunchKernelGGL((k_fir_blk<W, R, false, false>), dim3((unsigned)wgs), dim3(128), LDS, st, x, XU, taps, addend, out, out_plain, g, rng);                        \
-  } while (0)
   if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
     rng = *noise_gen;
-    DDSP_BLK_LAUNCH(2, true, 0, 0);
+    hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
     return 5;
   }
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
-  if (wps >= 3 && pad == 0) DDSP_BLK_LAUNCH(3, false, 0, x_is_u01);
-  else DDSP_BLK_LAUNCH(2, false, pad, x_is_u01);
-#undef DDSP_BLK_LAUNCH
+  if (wps >= 3 && pad == 0)
+    hipLaunchKernelGGL((k_fir_blk<3, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
+  else
+    hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   return 5;
 }
 

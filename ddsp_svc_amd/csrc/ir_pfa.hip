@@ -180,8 +180,12 @@ static_assert(U_FLOATS >= 2 * W_WORDS && U_FLOATS >= HW_AT + 2 * ROWS, "union re
 
 }  // namespace pfa
 
-template <int KIND, int ACT, int MODE>
-__global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict__ a_re, long ld_re,
+// KIND / ACT / MODE are kernel ARGUMENTS, not template parameters: the three tap syntheses of a step (all-pass, dynamic
+// window, Hann) are then ONE code object of ~20 KB that stays in the 64 KB instruction cache from launch to launch,
+// instead of three of 11-17 KB that evict each other and the filter kernel -- on the part of the pool where an
+// instruction fetch past that cache is slow, a cold launch of this kernel takes 44-62 us against 28-38 warm (DESIGN.md,
+// "instruction cache").  Every switch on them is workgroup-uniform (scalar branches).
+__global__ void __launch_bounds__(256, 4) k_taps_pfa510(int KIND, int ACT, int MODE, const float* __restrict__ a_re, long ld_re,
                                                      const float* __restrict__ a_im, long ld_im, float scale,
                                                      const float* __restrict__ hann, const float* __restrict__ half_width,
                                                      float hw_sr, long rows, float* __restrict__ taps) {
@@ -202,21 +206,25 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     // bins; float64 scan reduced to revolutions before the float cosine / sine, as k_allpass_response (ir.hip)
     const int wave = tid >> 6, lane = tid & 63;
     const double inv_2pi = 0.15915494309189533577;
-    float4 cv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                           // the four rows' loads are in flight together
+    // a ROLLED loop over the wave's four rows (the body holds 4 tanhf, a float64 wave scan and 8 sine / cosine: unrolled
+    // it was a quarter of the kernel's code), the next row's load in flight while a row is activated
+    auto load_row = [&](int q) -> float4 {
       const long gr = row0 + wave * 4 + q;
-      cv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < rows) {
         const float* src = a_re + gr * ld_re + 4 * lane;
-        cv[q].x = src[0]; cv[q].y = src[1]; cv[q].z = src[2]; cv[q].w = src[3];
+        c.x = src[0]; c.y = src[1]; c.z = src[2]; c.w = src[3];
       }
-    }
-#pragma unroll
+      return c;
+    };
+    float4 nxt = load_row(0);
+#pragma unroll 1
     for (int q = 0; q < 4; ++q) {
+      const float4 cv = nxt;
+      if (q < 3) nxt = load_row(q + 1);
       const int r = wave * 4 + q;
       const bool live = row0 + r < rows;
-      const float g[4] = {kPiF * tanhf(cv[q].x), kPiF * tanhf(cv[q].y), kPiF * tanhf(cv[q].z), kPiF * tanhf(cv[q].w)};
+      const float g[4] = {kPiF * tanhf(cv.x), kPiF * tanhf(cv.y), kPiF * tanhf(cv.z), kPiF * tanhf(cv.w)};
       const double local = (((double)g[0] + (double)g[1]) + (double)g[2]) + (double)g[3];
       double run = wave_excl_scan(local, lane);
       float co[4], si[4];
@@ -255,12 +263,18 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
         }
       }
     }
+    if (ACT == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][e] = exp_hw(v[q][e]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = c4 + 64 * q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[q][e] = live ? (ACT == 1 ? exp_hw(v[q][e]) * sc : v[q][e] * sc) : 0.f;
+        v[q][e] = live ? v[q][e] * sc : 0.f;
         w[q][e] = live ? w[q][e] * sc : 0.f;
       }
       if (KIND == KIND_COMPLEX) {
@@ -285,18 +299,24 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
       const float* ia = im_s + (2 * t) * NB;
       const float* ib = ia + NB;
       int k = 17 * n2;                                     // < 510
+      if (KIND == KIND_REAL) {
 #pragma unroll
-      for (int n1 = 0; n1 < 17; ++n1) {
-        const bool mir = k > HALF;
-        const int kk = mir ? NT - k : k;
-        if (KIND == KIND_REAL) {
+        for (int n1 = 0; n1 < 17; ++n1) {
+          const int kk = k > HALF ? NT - k : k;
           z[n1] = f32x2{ra[kk], rb[kk]};
-        } else {
+          k += 30;
+          if (k >= NT) k -= NT;
+        }
+      } else {
+#pragma unroll
+        for (int n1 = 0; n1 < 17; ++n1) {
+          const bool mir = k > HALF;
+          const int kk = mir ? NT - k : k;
           const float sg = mir ? -1.0f : 1.0f;
           z[n1] = f32x2{fmaf(-sg, ib[kk], ra[kk]), fmaf(sg, ia[kk], rb[kk])};
+          k += 30;
+          if (k >= NT) k -= NT;
         }
-        k += 30;
-        if (k >= NT) k -= NT;
       }
     }
     __syncthreads();                                       // every thread holds its inputs: the rows may be overwritten
@@ -364,8 +384,26 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
     jj[it] = c ? j - NT : j;
     rr[it] = r0 + 2 * it + (c ? 1 : 0);
   }
-  float2 wa[GROUPS], wb[GROUPS];
+  auto fetch = [&](int it, float (&ov)[4]) -> bool {       // false: this thread has no group `it` (only the last one is partial)
+    const int i4 = tid + 256 * it;
+    if (it == GROUPS - 1 && i4 >= ROWS * NT / 4) return false;
+    const float4 o = *reinterpret_cast<const float4*>(O + 4 * i4);
+    ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+    return true;
+  };
+  auto put = [&](int it, const float (&ov)[4]) {
+    const int i = 4 * (tid + 256 * it);
+    if (i + 3 < total) {
+      *reinterpret_cast<float4*>(dst + i) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i + e < total) dst[i + e] = ov[e];
+    }
+  };
+  // one loop per window mode (the mode is workgroup-uniform: one scalar branch, not one per group)
   if (MODE == MODE_HANN) {
+    float2 wa[GROUPS], wb[GROUPS];
 #pragma unroll
     for (int it = 0; it < GROUPS; ++it) {
       const int j = jj[it];
@@ -373,18 +411,22 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
       wa[it] = *reinterpret_cast<const float2*>(hann + j);
       wb[it] = *reinterpret_cast<const float2*>(hann + j2);
     }
-  }
 #pragma unroll
-  for (int it = 0; it < GROUPS; ++it) {
-    const int i4 = tid + 256 * it;
-    if (it == GROUPS - 1 && i4 >= ROWS * NT / 4) break;
-    const int i = 4 * i4, j = jj[it], r = rr[it];
-    const float4 o = *reinterpret_cast<const float4*>(O + i);
-    float ov[4] = {o.x, o.y, o.z, o.w};
-    const bool wrap = j + 3 >= NT;
-    if (MODE == MODE_HANN) {
+    for (int it = 0; it < GROUPS; ++it) {
+      float ov[4];
+      if (!fetch(it, ov)) break;
       ov[0] *= wa[it].x; ov[1] *= wa[it].y; ov[2] *= wb[it].x; ov[3] *= wb[it].y;
-    } else if (MODE == MODE_DYNAMIC) {
+      put(it, ov);
+    }
+  } else if (MODE == MODE_DYNAMIC) {
+    // rolled: the body (four divisions by the row's half width with their exact fallback, four cosines) is the bulk of this
+    // mode's code, everything it reads is in LDS
+    int j = j0, r = r0;
+#pragma unroll 1
+    for (int it = 0; it < GROUPS; ++it) {
+      float ov[4];
+      if (!fetch(it, ov)) break;
+      const bool wrap = j + 3 >= NT;
       const int r1 = wrap ? r + 1 : r;                      // (a straddling group never reaches row 16: it would start past the batch)
       const float hv[2] = {U[HW_AT + r], U[HW_AT + r1]};
       const float rb[2] = {U[HW_AT + ROWS + r], U[HW_AT + ROWS + r1]};
@@ -396,13 +438,17 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(const float* __restrict_
         if (u > 1.0f) u = 0.0f;                                          // core.py:245 -- only the upper side is clamped
         ov[e] *= (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                  // core.py:246
       }
+      put(it, ov);
+      j += 4;                                               // the next group: 1024 floats on = two rows and four taps
+      r += 2;
+      if (j >= NT) { j -= NT; r += 1; }
     }
-    if (i + 3 < total) {
-      *reinterpret_cast<float4*>(dst + i) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (i + e < total) dst[i + e] = ov[e];
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < GROUPS; ++it) {
+      float ov[4];
+      if (!fetch(it, ov)) break;
+      put(it, ov);
     }
   }
   PFA_STAMP(4);
@@ -417,27 +463,17 @@ int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld
   const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
   const float* hann = table + 2 * KP * NP;                 // the periodic Hann of the basis table (k_ir_table, ir.hip)
   dim3 grid((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), block(256);
-#define DDSP_PFA_LAUNCH(KIND_, ACT_, MODE_)                                                                     \
-  hipLaunchKernelGGL((k_taps_pfa510<KIND_, ACT_, MODE_>), grid, block, 0, st, a_re, ld_re, a_im, ld_im, scale, \
-                     hann, half_width, hw_from_f0_sr, rows, taps)
-#define DDSP_PFA_MODES(KIND_, ACT_)                                     \
-  do {                                                                  \
-    if (mode == pfa::MODE_HANN) DDSP_PFA_LAUNCH(KIND_, ACT_, 1);        \
-    else if (mode == pfa::MODE_DYNAMIC) DDSP_PFA_LAUNCH(KIND_, ACT_, 2); \
-    else DDSP_PFA_LAUNCH(KIND_, ACT_, 0);                               \
-  } while (0)
+  int kind = pfa::KIND_REAL;
   if (allpass_from_control) {
-    DDSP_PFA_MODES(pfa::KIND_ALLPASS, 0);
+    kind = pfa::KIND_ALLPASS;
+    act = 0;
   } else if (a_im) {
     if (act != 0) return -1;
-    DDSP_PFA_MODES(pfa::KIND_COMPLEX, 0);
-  } else if (act == 1) {
-    DDSP_PFA_MODES(pfa::KIND_REAL, 1);
-  } else {
-    DDSP_PFA_MODES(pfa::KIND_REAL, 0);
+    kind = pfa::KIND_COMPLEX;
   }
-#undef DDSP_PFA_MODES
-#undef DDSP_PFA_LAUNCH
+  const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
+  hipLaunchKernelGGL(k_taps_pfa510, grid, block, 0, st, kind, act == 1 ? 1 : 0, m, a_re, ld_re, a_im, ld_im, scale, hann, half_width,
+                     hw_from_f0_sr, rows, taps);
   return 0;
 }
 

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_remove_above_fmax(const float* __restri
 // ------------------------------------------------------------------------------------------------
 constexpr int PH_FRAMES_PER_WAVE = 4;                // consecutive frames a wave walks: amortises the launch of tiny workgroups
 
-template <int SPL>
+template <int SPL, bool POW2>
 __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restrict__ f0_frames, long n_frames, int F,
                                                           int hop, Upsampler up, PhaseCfg cfg,
                                                           double* __restrict__ sums) {
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
   const unsigned fr0 = ((unsigned)blockIdx.x * 4 + wave) * PH_FRAMES_PER_WAVE;
   unsigned b = fr0 / (unsigned)F;
   int f = (int)(fr0 - b * (unsigned)F);
-#pragma unroll
+#pragma unroll 1
   for (int q = 0; q < PH_FRAMES_PER_WAVE; ++q, ++f) {
     const long fr = (long)fr0 + q;
     if (fr >= n_frames) return;                     // wave-uniform
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
 #pragma unroll
     for (int r = 0; r < SPL; ++r) {
       int j = lane * SPL + r;
-      if (j < hop) acc += cfg.term(up.at3_in_frame(rows, j, hop));
+      if (j < hop) acc += cfg.term(POW2 ? up.at3_pow2(rows, j) : up.at3_in_frame(rows, j, hop));
     }
     acc = wave_sum(acc);
     if (lane == 0) sums[fr] = acc;
@@ -212,11 +212,12 @@ int launch_phase(const float* f0_frames, const float* initial_phase, int B, int 
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
   const dim3 sgrid((unsigned)((n_frames + 4 * PH_FRAMES_PER_WAVE - 1) / (4 * PH_FRAMES_PER_WAVE)));
   if (spl == 8)
-    hipLaunchKernelGGL(k_phase_frame_sums<8>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    if (up.shift > 0) hipLaunchKernelGGL((k_phase_frame_sums<8, true>), sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    else hipLaunchKernelGGL((k_phase_frame_sums<8, false>), sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   else if (spl == 16)
-    hipLaunchKernelGGL(k_phase_frame_sums<16>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    hipLaunchKernelGGL((k_phase_frame_sums<16, false>), sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   else
-    hipLaunchKernelGGL(k_phase_frame_sums<32>, sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
+    hipLaunchKernelGGL((k_phase_frame_sums<32, false>), sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);
   hipLaunchKernelGGL(k_phase_frame_scan, dim3((unsigned)B), dim3(256), 0, st, f0_frames, initial_phase, F, hop, up, cfg,
                      (const double*)frame_sums, phase0, phase_frames);
   if (x_or_null) {

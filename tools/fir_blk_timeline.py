@@ -14,7 +14,7 @@ import torch
 
 from ddsp_svc_amd import _ffi, build
 
-so = os.path.join(ROOT, "tools", "ab", "libddsp_hip_tl.so")      # git-ignored; travels with gpurun's snapshot
+so = os.environ.get("DDSP_TL_LIB") or os.path.join(ROOT, "tools", "ab", "libddsp_hip_tl.so")      # git-ignored; travels with gpurun's snapshot
 if "--build" in sys.argv or not os.path.exists(so):
     out = "/tmp/ddsp_timeline"
     os.makedirs(out, exist_ok=True)

@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 c = sqlite3.connect(sys.argv[1])
-first = sys.argv[2] if len(sys.argv) > 2 else "k_phase_frame"
+first = sys.argv[2] if len(sys.argv) > 2 else "k_phase_frame_sums"
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if first in r[0]]
 if len(idx) < 3:
