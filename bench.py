@@ -283,14 +283,14 @@ def also_lines(a, device, B, F, n, want_traffic):
     bank_bytes = (4.0 + 4.0 * n / HOP) * B * T                 # amplitude controls in, exciter out
     alg = (8.0 + 4.0 * (sum(inp["sizes"]) + 1) / HOP) * B * T
     live = live_traffic("sins") if want_traffic else None
-    kt, stt, src = traffic_of("k_sins_bank2", "sins", live) if (B, F, n) == (32, 862, 256) else (None, None, None)
+    kt, stt, src = traffic_of("k_sins_bank3", "sins", live) if (B, F, n) == (32, 862, 256) else (None, None, None)
     ms = el / steps * 1e3
     out["sins"] = {
         "metric": "audio samples/sec, Sins 44.1kHz 256-harm hop512", "value": B * T * steps / el, "unit": "samples/s",
         "steps": steps, "warmup": warm, "ms_per_step": ms, "ms_per_step_events": ev_ms, "dtype": "f32",
         "config": {"workload": "sins B=%d x %.0f s utterances (F=%d, T=%d), %d harmonics, n_mag %d/%d, DSP path from resident "
                                "f0 / raw controls / uniform noise, signal only (BASELINE cfg 3)" % (B, a.seconds, F, T, n, n, n)},
-        "roofline": {"kernel": "k_sins_bank2", "bound": "hbm", "achieved": bank_bytes / (bank_ms * 1e-3) / 1e9, "peak": 8000.0,
+        "roofline": {"kernel": "k_sins_bank3", "bound": "hbm", "achieved": bank_bytes / (bank_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": bank_bytes / (bank_ms * 1e-3) / 1e9 / 8000.0,
                      "traffic": kt["bytes"] if kt else None, "traffic_source": src,
                      "algorithmic_bytes_per_launch": bank_bytes, "avg_ms": bank_ms, "launches_per_step": 1,

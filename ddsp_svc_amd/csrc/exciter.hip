@@ -19,7 +19,8 @@ struct FramePhase {
 };
 
 // x[t] and f0[t] for the SPL samples this lane owns in frame fr (all 64 lanes of the wave must call)
-template <int SPL>
+// POW2: the caller (launcher) has checked up.shift > 0, so only the shift form of the interpolation is compiled in
+template <int SPL, bool POW2 = false>
 __device__ __forceinline__ void frame_phase(const float* __restrict__ f0_row, int f, int hop, const Upsampler& up,
                                             const PhaseCfg& cfg, double phase0, float ip, int lane,
                                             FramePhase<SPL>& o) {
@@ -31,7 +32,7 @@ __device__ __forceinline__ void frame_phase(const float* __restrict__ f0_row, in
     int j = lane * SPL + r;
     float v = 0.f;
     if (j < hop) {
-      v = up.at3_in_frame(rows, j, hop);
+      v = POW2 ? up.at3_pow2(rows, j) : up.at3_in_frame(rows, j, hop);
       acc += cfg.term(v);
     }
     o.f0u[r] = v;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void store_frame(float* __restrict__ dst, int hop, in
 // ------------------------------------------------------------------------------------------------
 // combtooth = sinc(sr * x / (f0 + 1e-3)); one wave per frame
 // ------------------------------------------------------------------------------------------------
-template <int SPL>
+template <int SPL, bool POW2 = false>
 __global__ void __launch_bounds__(256) k_combtooth(const float* __restrict__ f0_frames,
                                                    const float* __restrict__ initial_phase, long n_frames, int F,
                                                    int hop, Upsampler up, PhaseCfg cfg,
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) k_combtooth(const float* __restrict__ f0_
   int f = (int)((unsigned)fr - bu * (unsigned)F);
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   FramePhase<SPL> ph;
-  frame_phase<SPL>(f0_frames + b * F, f, hop, up, cfg, phase0[fr], ip, lane, ph);
+  frame_phase<SPL, POW2>(f0_frames + b * F, f, hop, up, cfg, phase0[fr], ip, lane, ph);
   float v[SPL];
 #pragma unroll
   for (int r = 0; r < SPL; ++r) {
@@ -185,6 +186,17 @@ __device__ __forceinline__ void cis_product(float k, float theta, float& co, flo
   si = __builtin_amdgcn_sinf(r);
 }
 
+// (lam.x ad.y + ad.x, lam.y ad.y + ad.x): both halves of the result take A from the low and dA from the high half of `ad`
+__device__ __forceinline__ f32x2 lerp_pair(f32x2 lam, f32x2 ad) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(lam), "v"(ad));
+  return r;
+#else
+  return f32x2{fmaf(lam.x, ad.y, ad.x), fmaf(lam.y, ad.y, ad.x)};
+#endif
+}
+
 __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0_frames,
                                                     const float* __restrict__ initial_phase,
                                                     const float* __restrict__ c_amp, long ld_amp, int F, int H,
@@ -217,8 +229,8 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
   const Upsampler::Row3 rows = up.load3(f0_row, f);
   const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
   const long t0 = (long)f * HOP + 2 * tid;
-  const double q0 = cfg.term(up.at3_in_frame(rows, 2 * tid, HOP));
-  const double q1 = cfg.term(up.at3_in_frame(rows, 2 * tid + 1, HOP));
+  const double q0 = cfg.term(up.at3_pow2(rows, 2 * tid));       // the launcher has checked up.shift > 0 (hop 512, F hop <= 2^24)
+  const double q1 = cfg.term(up.at3_pow2(rows, 2 * tid + 1));
   const double mine = q0 + q1;
   const double excl = wave_excl_scan(mine, lane);
   if (lane == 63) wsum[wave] = excl + mine;
@@ -241,16 +253,9 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
       ts[j] = __builtin_elementwise_fma(ts[j - 1], tc[0], tc[j - 1] * ts[0]);
     }
   }
-  // interpolation weight of the thread's two samples (core.py:66-70: lambda = j / hop towards frame f + 1)
-  f32x2 lam;
-  {
-    int i0, i1;
-    float w0, w1;
-    up.locate(t0, i0, i1, w0, w1);
-    lam.x = w1;
-    up.locate(t0 + 1, i0, i1, w0, w1);
-    lam.y = w1;
-  }
+  // interpolation weight of the thread's two samples (core.py:66-70: lambda = j / hop towards frame f + 1; exact in the
+  // shift form)
+  const f32x2 lam = {(float)(2 * tid) * up.scale, (float)(2 * tid + 1) * up.scale};
   // sum_k sin(k theta) A_k(t) block by block:  sin((16 b + j) theta) = Cb sin(j theta) + Sb cos(j theta), so a block
   // contributes Cb P + Sb Q with P = sum_j sin(j theta) A_j(t), Q = sum_j cos(j theta) A_j(t): three packed
   // multiply-adds per harmonic and sample pair (amplitude interpolation, P, Q)
@@ -276,8 +281,10 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const float4 q = ap[jj];
-      const f32x2 a = __builtin_elementwise_fma(lam, f32x2{q.y, q.y}, f32x2{q.x, q.x});
-      const f32x2 b = __builtin_elementwise_fma(lam, f32x2{q.w, q.w}, f32x2{q.z, q.z});
+      // amplitude of the two samples: A + lambda dA with (A, dA) taken from the halves of ONE register pair (the compiler's
+      // own form of the second harmonic's interpolation copies dA into a fresh pair first: 8 v_mov per block)
+      const f32x2 a = lerp_pair(lam, f32x2{q.x, q.y});
+      const f32x2 b = lerp_pair(lam, f32x2{q.z, q.w});
       P = __builtin_elementwise_fma(ts[2 * jj], a, P);
       Q = __builtin_elementwise_fma(tc[2 * jj], a, Q);
       P = __builtin_elementwise_fma(ts[2 * jj + 1], b, P);
@@ -285,6 +292,155 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
     }
     S = __builtin_elementwise_fma(Cb, P, S);
     S = __builtin_elementwise_fma(Sb, Q, S);
+  }
+  const float r[2] = {S.x, S.y};
+  float* dst = out + b * (long)F * HOP + t0;
+  if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
+  else { dst[0] = r[0]; dst[1] = r[1]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sinusoid bank, mirrored-pair form (hop = 512; the default): blocks of 17 harmonics AROUND a centre c,
+//     a+ sin((c + j) theta) + a- sin((c - j) theta)  =  sin(c theta) cos(j theta) (a+ + a-)  +  cos(c theta) sin(j theta) (a+ - a-),
+// so with the frame's sums sigma_j = a(c+j) + a(c-j) and differences delta_j = a(c+j) - a(c-j) staged in LDS (they are
+// linear in the amplitudes, hence interpolate between the two frames exactly as the amplitudes do), a PAIR of harmonics
+// costs two interpolations and two multiply-adds: 2 packed instructions per harmonic and sample pair instead of the 3 of
+// k_sins_bank2 (amplitude interpolation, P, Q), and the table cis(j theta) has 8 entries instead of 16.  Block b has centre
+// c = 9 + 17 b and contributes  sin(c theta) (a_c + sum_j cos(j theta) sigma_j) + cos(c theta) sum_j sin(j theta) delta_j.
+// k_sins_bank2 was measured at 100 % vector-ALU occupancy (SQ_ACTIVE_INST_VALU = kernel cycles) and power-limited clocks:
+// only fewer multiply-adds make this kernel faster.  Harmonics beyond 17 * (H / 17) go into one more, zero-padded block,
+// or -- one or two of them -- are evaluated on their own.  Same numerics as k_sins_bank2 (sin(k theta) for the float32
+// theta without the reference's rounding of k * theta; accurate seeds every fourth block, rotations in between).
+// ------------------------------------------------------------------------------------------------
+constexpr int SB3_J = 8;                              // pairs per block
+constexpr int SB3_W = 2 * SB3_J + 1;                  // harmonics per block: 17
+constexpr int SB3_LD = 4 + 4 * SB3_J;                 // floats per block in LDS: (A_c, dA_c, 0, 0), then (sigma, dsigma, delta, ddelta) x 8
+
+__global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0_frames,
+                                                    const float* __restrict__ initial_phase,
+                                                    const float* __restrict__ c_amp, long ld_amp, int F, int H, int nblk,
+                                                    int nsingle, Upsampler up, PhaseCfg cfg,
+                                                    const double* __restrict__ phase0, float* __restrict__ out) {
+  constexpr int HOP = 512;
+  HIP_DYNAMIC_SHARED(float, amp)                    // [nblk][SB3_LD], then [nsingle][2]
+  __shared__ double wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long fr = blockIdx.x;
+  const long b = fr / F;
+  const int f = (int)(fr - b * F);
+  const float* f0_row = f0_frames + b * F;
+  const float nyq = cfg.sr_f / 2.0f;
+  const int f1 = f + 1 < F ? f + 1 : F - 1;           // last frame held (core.py:68)
+  const float* row0 = c_amp + (b * F + f) * ld_amp;
+  const float* row1 = c_amp + (b * F + f1) * ld_amp;
+  const float fa = f0_row[f], fb = f0_row[f1];
+  // activated, masked amplitude of harmonic k (1-based) in the two frames; zero outside 1..H
+  auto amp2 = [&](int k, float& a0, float& a1) {
+    a0 = 0.f;
+    a1 = 0.f;
+    if (k >= 1 && k <= H) {
+      const float kk = (float)k;
+      a0 = (expf(row0[k - 1]) / 128.0f) * ((fa * kk < nyq ? 1.0f : 0.0f) + 1e-7f);   // vocoder.py:580, core.py:75-76
+      a1 = (expf(row1[k - 1]) / 128.0f) * ((fb * kk < nyq ? 1.0f : 0.0f) + 1e-7f);
+    }
+  };
+  // one staging item per (block, j), j = 0 the centre, j = 1..8 a mirrored pair; the frame-to-frame steps are kept beside
+  // the values: upsample(A)[t] = A[f] + lambda (A[f+1] - A[f]) (core.py:66-70)
+  for (int i = tid; i < nblk * (SB3_J + 1) + nsingle; i += 256) {
+    if (i < nblk * (SB3_J + 1)) {
+      const int blk = i / (SB3_J + 1), j = i - blk * (SB3_J + 1);
+      const int c = SB3_J + 1 + SB3_W * blk;
+      float* dst = amp + blk * SB3_LD;
+      float p0, p1;
+      amp2(c + j, p0, p1);
+      if (j == 0) {
+        dst[0] = p0; dst[1] = p1 - p0; dst[2] = 0.f; dst[3] = 0.f;
+      } else {
+        float m0, m1;
+        amp2(c - j, m0, m1);
+        const float s0 = p0 + m0, s1 = p1 + m1, d0 = p0 - m0, d1 = p1 - m1;
+        dst[4 * j] = s0; dst[4 * j + 1] = s1 - s0; dst[4 * j + 2] = d0; dst[4 * j + 3] = d1 - d0;
+      }
+    } else {
+      const int q = i - nblk * (SB3_J + 1);
+      float p0, p1;
+      amp2(SB3_W * nblk + 1 + q, p0, p1);
+      amp[nblk * SB3_LD + 2 * q] = p0;
+      amp[nblk * SB3_LD + 2 * q + 1] = p1 - p0;
+    }
+  }
+  // wrapped phase of this thread's two samples (vocoder.py:564-572): float64 terms, block-wide exclusive scan
+  const Upsampler::Row3 rows = up.load3(f0_row, f);
+  const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
+  const long t0 = (long)f * HOP + 2 * tid;
+  const double q0 = cfg.term(up.at3_pow2(rows, 2 * tid));       // the launcher has checked up.shift > 0 (hop 512, F hop <= 2^24)
+  const double q1 = cfg.term(up.at3_pow2(rows, 2 * tid + 1));
+  const double mine = q0 + q1;
+  const double excl = wave_excl_scan(mine, lane);
+  if (lane == 63) wsum[wave] = excl + mine;
+  __syncthreads();                                  // also publishes amp[]
+  double base = phase0[fr] + excl;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const float xa = cfg.wrap(base + q0, ip), xb = cfg.wrap(base + q0 + q1, ip);
+  const f32x2 theta = {kTwoPiF * xa, kTwoPiF * xb};                       // vocoder.py:574
+  // table cis(j theta), j = 1..8, as (cos_A, cos_B) / (sin_A, sin_B) pairs; the block-to-block rotation cis(17 theta)
+  f32x2 tc[SB3_J], ts[SB3_J];
+  f32x2 rc, rs;
+  {
+    float c0, s0, c1, s1;
+    cis_product(1.0f, theta.x, c0, s0);
+    cis_product(1.0f, theta.y, c1, s1);
+    tc[0] = f32x2{c0, c1};
+    ts[0] = f32x2{s0, s1};
+#pragma unroll
+    for (int j = 1; j < SB3_J; ++j) {
+      tc[j] = __builtin_elementwise_fma(tc[j - 1], tc[0], -(ts[j - 1] * ts[0]));
+      ts[j] = __builtin_elementwise_fma(ts[j - 1], tc[0], tc[j - 1] * ts[0]);
+    }
+    const f32x2 c16 = __builtin_elementwise_fma(tc[7], tc[7], -(ts[7] * ts[7]));
+    const f32x2 s16 = (ts[7] * tc[7]) * f32x2{2.f, 2.f};
+    rc = __builtin_elementwise_fma(c16, tc[0], -(s16 * ts[0]));
+    rs = __builtin_elementwise_fma(s16, tc[0], c16 * ts[0]);
+  }
+  // interpolation weight of the thread's two samples (lambda = j / hop towards frame f + 1; exact in the shift form)
+  const f32x2 lam = {(float)(2 * tid) * up.scale, (float)(2 * tid + 1) * up.scale};
+  f32x2 S = {0.f, 0.f};
+  f32x2 Cb = {1.f, 1.f}, Sb = {0.f, 0.f};            // cis(c theta) of the block
+  for (int blk = 0; blk < nblk; ++blk) {
+    if ((blk & 3) == 0) {                           // accurate seed
+      const float c = (float)(SB3_J + 1 + SB3_W * blk);
+      float c0, s0, c1, s1;
+      cis_product(c, theta.x, c0, s0);
+      cis_product(c, theta.y, c1, s1);
+      Cb = f32x2{c0, c1};
+      Sb = f32x2{s0, s1};
+    } else {                                        // rotate by cis(17 theta)
+      const f32x2 cn = __builtin_elementwise_fma(Cb, rc, -(Sb * rs));
+      Sb = __builtin_elementwise_fma(Sb, rc, Cb * rs);
+      Cb = cn;
+    }
+    const float4* ap = reinterpret_cast<const float4*>(amp + blk * SB3_LD);
+    const float4 ctr = ap[0];
+    f32x2 Q = lerp_pair(lam, f32x2{ctr.x, ctr.y});  // the centre harmonic: cos(0) a_c
+    f32x2 P = {0.f, 0.f};
+#pragma unroll
+    for (int j = 1; j <= SB3_J; ++j) {
+      const float4 q = ap[j];
+      const f32x2 sg = lerp_pair(lam, f32x2{q.x, q.y});
+      const f32x2 dl = lerp_pair(lam, f32x2{q.z, q.w});
+      Q = __builtin_elementwise_fma(tc[j - 1], sg, Q);
+      P = __builtin_elementwise_fma(ts[j - 1], dl, P);
+    }
+    S = __builtin_elementwise_fma(Sb, Q, S);
+    S = __builtin_elementwise_fma(Cb, P, S);
+  }
+  for (int q = 0; q < nsingle; ++q) {               // one or two harmonics beyond the last whole block
+    const float k = (float)(SB3_W * nblk + 1 + q);
+    float c0, s0, c1, s1;
+    cis_product(k, theta.x, c0, s0);
+    cis_product(k, theta.y, c1, s1);
+    const float2 ad = *reinterpret_cast<const float2*>(amp + nblk * SB3_LD + 2 * q);
+    S = __builtin_elementwise_fma(f32x2{s0, s1}, lerp_pair(lam, f32x2{ad.x, ad.y}), S);
   }
   const float r[2] = {S.x, S.y};
   float* dst = out + b * (long)F * HOP + t0;
@@ -431,7 +587,9 @@ int launch_combtooth(const float* f0_frames, const float* initial_phase, int B, 
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
-  if (spl == 8)
+  if (spl == 8 && up.shift > 0)
+    hipLaunchKernelGGL((k_combtooth<8, true>), grid, block, 0, st, f0_frames, initial_phase, n_frames, F, hop, up, cfg, phase0, out);
+  else if (spl == 8)
     hipLaunchKernelGGL(k_combtooth<8>, grid, block, 0, st, f0_frames, initial_phase, n_frames, F, hop, up, cfg, phase0, out);
   else if (spl == 16)
     hipLaunchKernelGGL(k_combtooth<16>, grid, block, 0, st, f0_frames, initial_phase, n_frames, F, hop, up, cfg, phase0, out);
@@ -448,11 +606,20 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
   if ((long)B * F == 0) return 0;
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
-  if (hop == 512 && (long)B * F <= 0x7fffffffL && !knob(KNOB_SINS_V1)) {
-    // block angle-addition form: one workgroup per frame
-    const size_t sh2 = (size_t)2 * ((H + 15) & ~15) * sizeof(float);
-    hipLaunchKernelGGL(k_sins_bank2, dim3((unsigned)((long)B * F)), dim3(256), sh2, st, f0_frames, initial_phase, c_amp,
-                       ld_amp, F, H, up, cfg, phase0, out);
+  if (hop == 512 && up.shift > 0 && (long)B * F <= 0x7fffffffL && knob(KNOB_SINS_V1) != 1) {
+    // block angle-addition forms: one workgroup per frame
+    if (knob(KNOB_SINS_V1) == 2) {                  // the 16-harmonic blocks of round 1 / 2 (tests, same-box A/B)
+      const size_t sh2 = (size_t)2 * ((H + 15) & ~15) * sizeof(float);
+      hipLaunchKernelGGL(k_sins_bank2, dim3((unsigned)((long)B * F)), dim3(256), sh2, st, f0_frames, initial_phase, c_amp,
+                         ld_amp, F, H, up, cfg, phase0, out);
+      return 0;
+    }
+    // mirrored pairs around a centre, 17 harmonics per block; a remainder of one or two harmonics is evaluated on its own
+    const int rem = H % SB3_W;
+    const int nblk = H / SB3_W + (rem > 2 ? 1 : 0), nsingle = rem > 2 ? 0 : rem;
+    const size_t sh3 = ((size_t)nblk * SB3_LD + 2 * (size_t)nsingle + 4) * sizeof(float);
+    hipLaunchKernelGGL(k_sins_bank3, dim3((unsigned)((long)B * F)), dim3(256), sh3, st, f0_frames, initial_phase, c_amp,
+                       ld_amp, F, H, nblk, nsingle, up, cfg, phase0, out);
     return 0;
   }
   const int groups = (F + 3) / 4;

@@ -119,7 +119,7 @@ def test_combtooth(dev):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("H,F", [(40, 6), (256, 5), (1, 3)])
+@pytest.mark.parametrize("H,F", [(40, 6), (256, 5), (1, 3), (17, 3), (34, 4), (36, 4)])   # 17-harmonic blocks: padded remainder, one / two extra harmonics, none
 def test_sinusoid_bank(dev, H, F):
     from ddsp_svc_amd import synth
     B = 2
