@@ -114,8 +114,22 @@ def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
 
-_AUX = {}
-_ONE_STREAM = bool(os.environ.get("DDSP_HIP_ONE_STREAM"))      # read once, at import: never hand the tails a second stream
+import collections
+
+_AUX = collections.OrderedDict()                              # (device, raw handle of the caller's stream) -> second stream, LRU
+_AUX_MAX = 16                                                  # callers that create short-lived streams do not grow it without bound
+
+
+def _env_flag(name):
+    """integer environment switch: unset, empty or 0 = off"""
+    v = os.environ.get(name, "").strip()
+    try:
+        return int(v) != 0 if v else False
+    except ValueError:
+        return True
+
+
+_ONE_STREAM = _env_flag("DDSP_HIP_ONE_STREAM")                 # read ONCE, at import: never hand the tails a second stream
 
 
 def set_tuning(name, value):
@@ -132,12 +146,14 @@ def aux_torch_stream(t, rows):
     if torch.cuda.current_device() != t.device.index:      # the library's fork / join events belong to the current device
         return None
     key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
-    s = _AUX.get(key)
-    if s is None:
-        with _LOCK:
-            s = _AUX.get(key)
-            if s is None:
-                s = _AUX[key] = torch.cuda.Stream(device=t.device)
+    with _LOCK:
+        s = _AUX.get(key)
+        if s is None:
+            s = _AUX[key] = torch.cuda.Stream(device=t.device)
+            while len(_AUX) > _AUX_MAX:                    # least recently used first; a dropped stream is destroyed by torch
+                _AUX.popitem(last=False)                   # once the work already enqueued on it has finished
+        else:
+            _AUX.move_to_end(key)
     return s
 
 

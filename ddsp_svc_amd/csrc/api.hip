@@ -131,10 +131,20 @@ struct Branch {
   }
 };
 
+// Whether this call uses the dense contraction at 256 bins too (knob TAPS_GEMM): read ONCE per entry point into this
+// thread-local, so that the stream layout and every tap synthesis of one call agree even if another thread changes
+// the knob meanwhile (a disagreement would let the fallback stage the all-pass response in a buffer the layout has
+// already given to the exciter).
+thread_local bool t_taps_gemm = false;
+struct TapsFormScope {
+  TapsFormScope() { t_taps_gemm = knob(KNOB_TAPS_GEMM) != 0; }
+};
+
 // tap synthesis of one filter: the prime-factor form when the shape is its (n_mag = 256), else the dense contraction
 void synth_taps(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale, const float* table,
                 int mode, const float* half_width, long rows, int n, float* taps, hipStream_t st, float hw_sr = 0.f) {
-  if (launch_taps_pfa510(a_re, ld_re, a_im, ld_im, 0, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr) == 0)
+  if (!t_taps_gemm &&
+      launch_taps_pfa510(a_re, ld_re, a_im, ld_im, 0, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr) == 0)
     return;
   launch_ir_gemm(a_re, ld_re, a_im, ld_im, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr);
 }
@@ -143,8 +153,8 @@ void synth_taps(const float* a_re, long ld_re, const float* a_im, long ld_im, in
 // response (re, im scratch of rows * n floats each) + dense contraction
 void synth_allpass_taps(const float* c_gd, long ld_gd, const float* table, long rows, int n, float* re, float* im,
                         float* taps, hipStream_t st) {
-  if (launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n,
-                         taps, st) == 0)
+  if (!t_taps_gemm && launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr,
+                                         rows, n, taps, st) == 0)
     return;
   launch_allpass_response(c_gd, ld_gd, rows, n, re, im, st);
   launch_ir_gemm(re, n, im, n, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n, taps, st);
@@ -244,6 +254,7 @@ int ddsp_hip_impulse_response(const float* resp_re, long ld_re, const float* res
   if (rows == 0) return 0;
   if (!resp_re || !table || !taps) return DDSP_HIP_EINVAL;
   if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
+  const TapsFormScope form;
   synth_taps(resp_re, ld_re, resp_im, ld_im, act, scale, table, mode, half_width, rows, n_mag, taps, S(stream));
   return finish();
 }
@@ -261,6 +272,7 @@ int ddsp_hip_allpass_taps(const float* c, long ld, long rows, int n_mag, const f
   if (scratch_bytes < ddsp_hip_allpass_taps_scratch_bytes(rows, n_mag)) return DDSP_HIP_EWS;
   float* re = static_cast<float*>(scratch);
   float* im = reinterpret_cast<float*>(static_cast<char*>(scratch) + align_up((size_t)rows * n_mag * sizeof(float), 256));
+  const TapsFormScope form;
   synth_allpass_taps(c, ld, table, rows, n_mag, re, im, taps, S(stream));
   return finish();
 }
@@ -332,6 +344,7 @@ int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_
   if (ws_bytes < ddsp_hip_frequency_filter_workspace_bytes(B, F, n_mag)) return DDSP_HIP_EWS;
   float* taps = static_cast<float*>(ws);
   const long R = (long)B * F;
+  const TapsFormScope form;
   synth_taps(resp_re, ld_re, resp_im, ld_im, DDSP_HIP_ACT_NONE, 1.0f, table, mode, half_width, R, n_mag, taps, S(stream));
   if (launch_fir(audio, 0, taps, nullptr, out, nullptr, B, F, hop, 2 * (n_mag - 1), DDSP_HIP_FIR_AUTO, S(stream)) < 0)
     return DDSP_HIP_ESHAPE;
@@ -404,6 +417,9 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (B == 0) return 0;
   if (!f0_frames || !phase0 || !c_amp || !c_gd || !c_nz || !table_ap || !table_nz || !signal)
     return DDSP_HIP_EINVAL;
+  // the stream layout below is chosen from "the prime-factor tap synthesis takes these calls", and that kernel stores
+  // 16 bytes at a time: the taps carved out of ws must be 16-byte aligned (ddsp_hip.h states the contract)
+  if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return DDSP_HIP_EINVAL;
   // noise == NULL: the uniform draw happens inside the noise filter (philox.h) from (noise_seed, noise_offset)
   const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};
   if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
@@ -419,7 +435,8 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
   // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
   // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
-  const bool ap_ahead = n_ap == 256 && !knob(KNOB_TAPS_GEMM) && knob(KNOB_STREAM_LAYOUT) != 1;
+  const TapsFormScope form;
+  const bool ap_ahead = n_ap == 256 && !t_taps_gemm && knob(KNOB_STREAM_LAYOUT) != 1;
   if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
   synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
              n_nz, w.taps_nz, br.aux);
@@ -449,6 +466,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (B == 0) return 0;
   if (!f0_frames || !phase0 || !c_gd || !c_harm || !c_nz || !table_ap || !table_harm || !table_nz || !signal)
     return DDSP_HIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return DDSP_HIP_EINVAL;      // as ddsp_hip_sins_synth
   const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};   // noise == NULL: drawn inside the noise filter (philox.h)
   if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   int n_max = n_ap > n_nz ? n_ap : n_nz;
@@ -468,7 +486,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   // lost (all taps ahead on the second stream, 0.424; the second harmonic filter's taps there too, 0.403; the harmonic
   // chain's front on the second stream, 0.439 against 0.422) are in DESIGN.md section 7 and no longer in the code.
   long layout = knob(KNOB_STREAM_LAYOUT);
-  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !knob(KNOB_TAPS_GEMM);
+  const TapsFormScope form;
+  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
   if (layout != 1) layout = 4;
   if (!all256) layout = 1;
   float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;

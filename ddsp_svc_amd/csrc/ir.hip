@@ -360,7 +360,11 @@ __global__ void __launch_bounds__(256) k_window_taps(const float* __restrict__ i
     if (src < 0) src += N;
     float w = 1.0f;
     if (mode == IR_MODE_HANN) {
-      w = (float)(0.5 - 0.5 * cospi(2.0 * (double)j / (double)N));
+      // the reference rolls the window by N/2, multiplies, and rolls the product by N/2 again (core.py:209-235): the tap that
+      // lands at j carries hann[(j - 2 (N/2)) mod N] -- hann[j] for even N, hann[(j + 1) mod N] for odd N
+      int wi = j - 2 * half;
+      if (wi < 0) wi += N;
+      w = (float)(0.5 - 0.5 * cospi(2.0 * (double)wi / (double)N));
     } else if (mode == IR_MODE_DYNAMIC) {
       float u = (float)(j - half) / half_width[r];
       if (u > 1.0f) u = 0.0f;

@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(int KIND, int ACT, int M
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
                        hipStream_t st, float hw_from_f0_sr) {
-  if (n != pfa::NB || rows <= 0 || knob(KNOB_TAPS_GEMM)) return -1;
+  if (n != pfa::NB || rows <= 0) return -1;                 // (knob TAPS_GEMM is the caller's decision: read once per API call)
   if ((reinterpret_cast<uintptr_t>(taps) & 15) != 0) return -1;
   const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
   const float* hann = table + 2 * KP * NP;                 // the periodic Hann of the basis table (k_ir_table, ir.hip)

@@ -113,15 +113,22 @@ def uniform_noise(B, T, seed, offset, device):
     return out
 
 
+def _need_seed(noise, noise_seed):
+    """``noise=None`` asks for the counter-based draw, which is keyed by ``(noise_seed, noise_offset)``: checked once, at the
+    top of the tails, so that every path (inference, training composition) raises the same documented error"""
+    if noise is None and noise_seed is None:
+        raise ValueError("noise=None needs noise_seed (the in-kernel draw is keyed by (noise_seed, noise_offset))")
+
+
 def _noise_arg(noise, noise_seed, noise_offset, noise_is_u01, B, T, hop, n_nz, fir_impl, device):
     """(tensor | None, is_u01, seed, offset) for the C call: ``noise=None`` asks for the in-kernel draw from
     ``(noise_seed, noise_offset)``; where the noise filter's shape is outside the kernel that can draw (hop 512,
     n_mag_noise <= 257) the same numbers are written out first."""
     if noise is not None:
         return _f32c(noise.reshape(B, T)), noise_is_u01, 0, 0
-    if noise_seed is None:
-        raise ValueError("noise=None needs noise_seed (the in-kernel draw is keyed by (noise_seed, noise_offset))")
-    if hop == 512 and n_nz <= 257 and fir_impl in (_ffi.FIR_AUTO, _ffi.FIR_BLK):
+    _need_seed(noise, noise_seed)
+    # (the hop-block filter takes utterances below 2^28 samples: launch_fir_blk; longer ones get the same numbers written out)
+    if hop == 512 and n_nz <= 257 and T < 2 ** 28 and fir_impl in (_ffi.FIR_AUTO, _ffi.FIR_BLK):
         return None, False, int(noise_seed), int(noise_offset)
     return uniform_noise(B, T, noise_seed, noise_offset, device), True, 0, 0
 
@@ -135,6 +142,7 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
     Returns ``(signal, harmonic|None, noise|None)``.  With gradients enabled and a control that requires grad the
     differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, amplitudes, group_delay, noise_magnitude, noise, state.phase0)
+    _need_seed(noise, noise_seed)
     if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
         noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
                                             f0_frames.device), True
@@ -306,6 +314,7 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
     inside the noise filter from ``(noise_seed, noise_offset)`` (see ``sins_synth``).  With gradients enabled and a control
     that requires grad the differentiable composition is used (hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, state.phase0)
+    _need_seed(noise, noise_seed)
     if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):
         noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
                                             f0_frames.device), True

@@ -178,7 +178,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
  * 3-6 % per step at B = 32 x 10 s.  Results are bit-identical to the one-stream order.  The two events this needs are
  * created once per host thread and device and kept (the only objects the library creates). */
 
-/* workspace the two synth entry points need (bytes); n_max = largest n_mag among the filters */
+/* workspace the two synth entry points need (bytes); n_max = largest n_mag among the filters.  `ws` must be 16-byte
+ * aligned (the tap arrays carved out of it are written 16 bytes at a time); an unaligned pointer is DDSP_HIP_EINVAL. */
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
 
 /* exciters on their own (used by tests and by callers that want the intermediate):

@@ -42,6 +42,22 @@ def test_window_helpers_golden(dev, golden_dir, n_mag):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("n", [129, 128, 7])
+def test_hann_window_odd_size(dev, n):
+    """odd tap counts in Hann mode: the reference rolls the window by N//2, multiplies, and rolls the product by N//2 again
+    (core.py:209-235), so for odd N the tap that lands at j carries hann[(j + 1) mod N], not hann[j]"""
+    from ddsp_svc_amd import core
+    g = torch.Generator().manual_seed(11)
+    ir = torch.randn(2, 3, n, generator=g)
+
+    def ref(x):                                                     # the reference's op chain, padding == 0 branch
+        w = torch.hann_window(n).roll(n // 2, -1)
+        return (x * w.unsqueeze(0)).roll(n // 2, -1)
+    got = core.apply_window_to_impulse_response(ir.to(dev))
+    assert rms(N_(got) - ref(ir).numpy()) <= 2e-6 * rms(ref(ir).numpy())
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_dynamic_window_odd_size_and_grad(dev):
     """odd tap count (the reference allows 2*n_mag-1, core.py:240) and the differentiable composition"""
     from ddsp_svc_amd import core

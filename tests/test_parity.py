@@ -361,13 +361,19 @@ def test_fft_convolve_errors(dev):
         core.crop_and_compensate_delay(a, 10, 4, padding="bogus")
 
 
-def _check_tail(out, g, rel=1e-5):
+def _check_tail(out, g, rel=1e-5, frac_above=0.0):
+    """relative and absolute RMS bars, plus the fraction of SAMPLES that may be off by more than 1e-4 (the north star's
+    absolute bar, per sample): none in inference mode; in train mode (float32 running sum of the phase, vocoder.py:568) a
+    rounding flip of the wrapped phase moves single exciter samples by up to ~1e-4, so a small counted fraction is allowed"""
     sig, harm, nz = out
     for got, key in ((sig, "signal"), (harm, "harmonic"), (nz, "noise_out")):
         ref = g[key]
         err = rms(N_(got) - ref)
         assert err <= rel * rms(ref), (key, err, rms(ref))
         assert err <= 1e-4, (key, err)
+        bar = 1e-4 * max(1.0, float(np.abs(ref).max()))              # 1e-4 absolute; relative to the peak for signals above 1
+        frac = float((np.abs(N_(got) - ref) > bar).mean())
+        assert frac <= frac_above, (key, "fraction of samples off by more than %g" % bar, frac)
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
@@ -382,7 +388,7 @@ def test_sins_tail_golden(dev, golden_dir, name, infer):
     sizes = [int(s) for s in g["sizes"]]
     a, gd, nzc = torch.split(cat, sizes, dim=-1)
     out = synth.sins_synth(f0, st, a, gd, nzc, T_(g["noise"], dev), SR, HOP)
-    _check_tail(out, g, rel=1e-5 if infer else 3e-5)
+    _check_tail(out, g, rel=1e-5 if infer else 3e-5, frac_above=0.0 if infer else 1e-3)
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
@@ -396,7 +402,7 @@ def test_combsub_tail_golden(dev, golden_dir, name, infer):
     sizes = [int(s) for s in g["sizes"]]
     gd, hm, nzc = torch.split(cat, sizes, dim=-1)
     out = synth.combsub_synth(f0, st, gd, hm, nzc, T_(g["noise"], dev), SR, HOP)
-    _check_tail(out, g, rel=1e-5 if infer else 2e-3)
+    _check_tail(out, g, rel=1e-5 if infer else 2e-3, frac_above=0.0 if infer else 1e-3)
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
