@@ -65,6 +65,17 @@ __device__ __forceinline__ f32x2 cmul_hi(f32x2 a, f32x2 b, f32x2 t) {
   return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-b.y, b.x}, t);
 #endif
 }
+// conj(a) * b in the same two halves: (ax bx, ax by) + ay (by, -bx)
+__device__ __forceinline__ f32x2 cmulc_hi(f32x2 a, f32x2 b, f32x2 t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 r;
+  DDSP_PK3(r, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]", a, b, t);  // + (ay by, -ay bx)
+  return r;
+#else
+  return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{b.y, -b.x}, t);
+#endif
+}
+__device__ __forceinline__ f32x2 cmulc(f32x2 a, f32x2 b) { return cmulc_hi(a, b, cmul_lo(a, b)); }
 // v[k] *= w[k], k = 1..7, for one array / for two arrays against the same factors: up to four products in flight
 __device__ __forceinline__ void twiddle7(f32x2* v, const f32x2* w) {
   f32x2 t1 = cmul_lo(v[1], w[1]), t2 = cmul_lo(v[2], w[2]), t3 = cmul_lo(v[3], w[3]), t4 = cmul_lo(v[4], w[4]);

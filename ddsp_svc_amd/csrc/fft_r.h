@@ -258,12 +258,14 @@ struct Plan {
   // columns each, in opposite order, so every barrier serves both and each wave has the other transform's arithmetic to
   // issue while one's LDS round trip is in flight.  Four distinct buffers: Yv and Xu must be free of readers on entry,
   // Xv and Yu become free at the first barrier; on return Yv and Xu are free, Xv and Yu may still be read by slower waves.
-  template <bool FLIP = false>
+  // U_PRUNED: u[4..7] are zero on entry (a zero-padded input, as forward_s<true>); false: a full 1024-point input
+  template <bool FLIP = false, bool U_PRUNED = true>
   static __device__ __forceinline__ void transposed_and_forward_s(f32x2 (&v)[8], f32x2 (&u)[8], const Tw& tw, f32x2* Yv,
                                                                   f32x2* Xv, f32x2* Xu, f32x2* Yu, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
     lane_pair_dft2<FLIP>(v, tid);
-    dft8_lo4(u);
+    if (U_PRUNED) dft8_lo4(u);
+    else dft8(u);
     twiddle7x2(v, tw.w3, u, tw.w1);
     dft8(v);
     const int ts = tid ^ (((tid / R) & 1) * C);

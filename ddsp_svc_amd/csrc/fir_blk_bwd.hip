@@ -1,25 +1,32 @@
 // Adjoints of the time-varying FIR (what autograd returns for ddsp/core.py:120-182 fft_convolve): gradients w.r.t.
-// the tap rows and, optionally, the input signal, in the hop-block form of fir_blk.hip.
+// the tap rows and, optionally, the input signal, in the hop-block form and with the geometry of fir_blk.hip.
 //
-// Forward, per hop block b (1024-point circular, alias-free):  r_b = x1_b (*) h'_b + x2_b (*) h'_min(b+1,F-1),
-//   x1_b = x_b (1 - lambda), x2_b = x_b lambda, h'_j = tap row j circularly shifted by 512 - N/2, and r_b[n] is added
-//   to the output at time (b-1) hop + u, u = n for n >= 512 - N/2 and n + 1024 for the wrapped head.  With
-//   seg_b[n] = grad_out[(b-1) hop + u(n)] (zero outside the signal and outside the support):
-//     d h'_b           += x1_b (star) seg_b      <->  conj(X1_b) S_b        (circular cross-correlation)
-//     d h'_min(b+1,..) += x2_b (star) seg_b      <->  conj(X2_b) S_b
-//     d x_b[s] = (1 - lambda_s) (h'_b (star) seg_b)[s] + lambda_s (h'_b+1 (star) seg_b)[s]   <->  conj(H) S_b
-// Per pair of blocks: one transform for the two cotangent segments, one per block for (x1, x2), one inverse for the
-// two finished tap-gradient rows (4 transforms per 1024 samples); with the input gradient also one for the tap
-// spectra and one inverse per block (7).  A tap row collects from two consecutive blocks, so the second block's
-// x2-term is carried in registers to the next pair; a run starts one pair early to rebuild that carry.  No
-// overlap-add: every tap row and every input block is written by exactly one workgroup.
+// Forward, per hop block b (1024-point circular, alias-free):  r_b = Re IFFT(Z_b G_b),
+//   Z_b = FFT(x_b (1 - lambda) + i x_b lambda),  G_b = H_b - i H_b+1  (H_j: tap row min(j, F-1) shifted by 256 - N/2),
+//   and r_b[n] is added to the output at time (b - 1/2) hop + n.  With seg_b[n] = grad_out[(b - 1/2) hop + n] (zero
+//   outside the signal; no masking to the block's support is needed: for a tap position inside its row and an input
+//   position inside its block the circular correlations below never wrap) and S_b = FFT(seg_b):
+//     U_b = conj(Z_b) S_b   <->  u_b = (x1_b star seg_b) - i (x2_b star seg_b):   d h_b += Re u_b,  d h_min(b+1,F-1) -= Im u_b
+//     D_b = conj(G_b) S_b   <->  (h_b star seg_b) + i (h_b+1 star seg_b):         d x_b[s] = (1 - lambda_s) Re + lambda_s Im
+//   -- ONE complex product per bin each, no separation of the packed block transform (round 2 separated X1, X2 of both
+//   blocks and formed four conjugate products per bin with scalar arithmetic: 256 registers, 84 spilled dwords, 0.43 ms).
+// Tap rows j, j + 1 of a pair come out of ONE inverse, V = R_j + i R_j+1 with the Hermitian spectra
+//     R_j = (U_j + ~U_j) / 2 + i (B_j - ~B_j) / 2,   ~X[k] = conj X[-k],   B_j = U_j-1 (+ U_j on the last row, which also
+//     takes its own block's second term: core.py:167 holds the last row),
+//   which is V[k] = N[k] + conj M[-k],  N = (U_j - B_j+1) / 2 + i (B_j + U_j+1) / 2,  M = (U_j + B_j+1) / 2 + i (B_j - U_j+1) / 2:
+//   one parked array and one mirrored read per pair, as in the forward kernel.  The cotangent segments of the two blocks
+//   ride in one transform C = FFT(seg_b0 + i seg_b0+1) and are split (S_b0, S_b0+1) like a pair of tap rows there.
+// Per pair of blocks: [Z_b0 | Z_b0+1] in lockstep, then [inverse of V | C of the NEXT pair] in lockstep -- four
+//   transforms, two stages, six barriers, the forward kernel's shape.  With the input gradient: [inverse of D_b0 | tap rows
+//   of the next pair] and the inverse of D_b0+1 in between (seven transforms).  U_b0+1 is carried to the next pair; a run
+//   starts one pair early to rebuild it (and the tap / cotangent spectra), storing nothing.  No overlap-add, no atomics:
+//   every tap row and every input block is written by exactly one workgroup.  Spectra live in the sign-carrying layout S-
+//   of fft_r.h; products of two of them are plain layout S.
 #include "fft_r.h"
 #include "kernels.h"
 #include <stdlib.h>
 
 namespace ddsp {
-
-using fft::cmul;
 
 constexpr int FBW_HOP = 512;
 
@@ -29,13 +36,6 @@ struct FirBwdGeom {
   int run, runs_per_utt;
 };
 
-// conj(a) * b
-__device__ __forceinline__ f32x2 cmulc(f32x2 a, f32x2 b) {
-  return f32x2{fmaf(a.x, b.x, a.y * b.y), fmaf(a.x, b.y, -(a.y * b.x))};
-}
-__device__ __forceinline__ f32x2 mul_i(f32x2 a) { return f32x2{-a.y, a.x}; }
-__device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }
-
 template <bool WITH_DX>
 __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict__ x, int x_is_u01,
                                                        const float* __restrict__ taps,
@@ -43,203 +43,281 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
                                                        float* __restrict__ d_taps, FirBwdGeom g) {
   using PL = fft::Plan<2>;
   constexpr int NF = PL::N, P = PL::P, S = 8;
-  __shared__ __attribute__((aligned(16))) f32x2 ex[2][NF];
+  __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];
+  f32x2* const bA = ex[0];
+  f32x2* const bB = ex[1];
+  f32x2* const bC = ex[2];
+  f32x2* const bD = ex[3];
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / g.runs_per_utt;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / g.runs_per_utt);
   const int run_no = blockIdx.x - b * g.runs_per_utt;
   const int q_first = run_no * g.run;
   int q_last = q_first + g.run;
   if (q_last > g.pairs) q_last = g.pairs;
-  const int SH = FBW_HOP - (g.N >> 1);
+  const int SH = FBW_HOP / 2 - (g.N >> 1);                     // tap shift of fir_blk.hip: row centred on transform index 256
   const float* xb = x + (long)b * g.T;
   const float* tb = taps + (long)b * g.F * g.N;
-  const float* gb = grad_out + (long)b * g.T;
   float* dtb = d_taps + (long)b * g.F * g.N;
+  const BufF32 g_buf = BufF32::make(grad_out + (long)b * g.T, g.T);
   const float inv_hop = 1.0f / (float)FBW_HOP;
-  const float cs = 0.25f / (float)NF;                          // the 1/2 of both splits and the 1/N of the inverse
+  const float sg = (tid & 1) ? -1.0f : 1.0f;                   // the sign layout S- puts on this thread's bins / samples
+  const int tid4 = 4 * tid;
 
-  typename PL::Tw tw;
-  tw.init(tid);
-  // Transforms as in fir_blk.hip: forward into the scrambled bin layout S of fft_r.h (all spectra of this kernel live
-  // in S; the products are pointwise), the transposed factorisation back to time order, two LDS exchanges each.
-  // ex[cur] is the buffer no wave reads any more.
-  int cur = 0;
-  const int kS0 = PL::s_index(tid, 0);                          // slot m holds bin kS0 + 64 m
-  const f32x2* mir = ex[0];                                     // where the last transform parked its bins by index
-  auto transform = [&](f32x2 (&z)[S]) {
-    f32x2* X = ex[cur];
-    PL::forward_s(z, tw, X, ex[cur ^ 1], tid);
+  // ---- loads (buffer descriptors: whatever lies outside a row, a block or the signal reads zero / is not stored) ----
+  struct Four { float v[4]; };
+  int tap_off[4];
 #pragma unroll
-    for (int m = 0; m < S; ++m) X[kS0 + 64 * m] = z[m];
-    __syncthreads();
-    mir = X;
-    cur ^= 1;
+  for (int m = 0; m < 4; ++m) {
+    const int i = P * m + tid - SH;
+    tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+  }
+  auto load_taps = [&](int j) -> Four {                          // row min(j, F-1), clamped below at 0; only m < 4 can be live
+    Four r;
+    const int row = j < 0 ? 0 : (j < g.F ? j : g.F - 1);
+    const BufF32 tr = BufF32::make(tb + (long)row * g.N, g.N);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
+    return r;
   };
-  // p = Z[k] + conj Z[-k], d = Z[k] - conj Z[-k] for the thread's 8 bins
-  auto split = [&](const f32x2 (&z)[S], f32x2 (&p)[S], f32x2 (&d)[S]) {
+  auto load_blk = [&](int bi) -> Four {
+    Four r;
+    const bool live = bi >= 0 && bi < g.F;
+    const BufF32 xr = BufF32::make(xb + (long)(live ? bi : 0) * FBW_HOP, live ? FBW_HOP : 0);
 #pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const int k = kS0 + 64 * m;
-      const f32x2 zneg = mir[(NF - k) & (NF - 1)];
-      p[m] = fft::add_conj(z[m], zneg);
-      d[m] = fft::sub_conj(z[m], zneg);
+    for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
+    return r;
+  };
+  // the cotangent of pair qn: twelve values L[i] = grad_out[(2 qn - 1/2) hop + 128 i + tid]; block 2 qn takes i = 0..7, block
+  // 2 qn + 1 takes i = 4..11.  The sign of a time is the same for every lane (multiples of 128 plus tid), so times before
+  // the signal get the out-of-range constant from a scalar select.
+  struct Seg { float v[12]; };
+  auto load_seg = [&](int qn) -> Seg {
+    Seg r;
+    const int t0 = 2 * qn * FBW_HOP - FBW_HOP / 2;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int t = t0 + P * i;
+      r.v[i] = g_buf.ld(t >= 0 ? 4 * (t + tid) : BufF32::kOutOfRange);
     }
+    return r;
   };
-  // inverse of V = Va + i Vb (both Hermitian) by conj / transform / conj: re -> ra, im -> rb, in time order
-  auto inverse_pair = [&](const f32x2 (&Va)[S], const f32x2 (&Vb)[S], float (&ra)[S], float (&rb)[S]) {
-    f32x2 v[S];
+  auto pack_seg = [&](const Seg& s, f32x2 (&z)[S]) {
 #pragma unroll
-    for (int m = 0; m < S; ++m) v[m] = fft::conj_minus_i_conj(Va[m], Vb[m]);
-    PL::transposed(v, tw, ex[cur], ex[cur ^ 1], tid);           // leaves ex[cur] free again
-#pragma unroll
-    for (int m = 0; m < S; ++m) { ra[m] = v[m].x; rb[m] = -v[m].y; }
+    for (int m = 0; m < S; ++m) z[m] = f32x2{s.v[m], s.v[m + 4]};
   };
-  // (x1, x2) of block bi packed in one transform -> p = 2 X1, d = 2i X2
-  auto block_spectra = [&](int bi, f32x2 (&p)[S], f32x2 (&d)[S]) {
-    f32x2 z[S];
-    const float* src = xb + (long)(bi < g.F ? bi : g.F - 1) * FBW_HOP + tid;
-    float raw[4];
+  auto pack_taps = [&](const Four& ta, const Four& tb2, f32x2 (&z)[S]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) raw[m] = src[P * m];
+    for (int m = 0; m < 4; ++m) z[m] = f32x2{ta.v[m], tb2.v[m]};
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
+  };
+  auto pack_blk = [&](const Four& cx, bool live, f32x2 (&z)[S]) {
+    const float ua = x_is_u01 ? 2.0f : 1.0f, ub = (x_is_u01 && live) ? -1.0f : 0.0f;   // noise = rand * 2 - 1, uniform
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      float xv = raw[m];
-      if (x_is_u01) xv = fmaf(2.0f, xv, -1.0f);
-      if (bi >= g.F) xv = 0.f;
+      const float xv = fmaf(ua, cx.v[m], ub);
       const float lam = (float)(P * m + tid) * inv_hop;
       z[m] = f32x2{(1.0f - lam) * xv, lam * xv};
     }
 #pragma unroll
     for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
-    transform(z);
-    split(z, p, d);
-  };
-  // cotangent segments of blocks b0, b0 + 1 packed in one transform.  The forward result of block bb occupies the
-  // unwrapped indices u in [SH, SH + hop + N - 2] of its circular buffer (time (bb-1) hop + u); transform index n
-  // holds u = n for n >= SH and u = n + 1024 for the wrapped head.  ps = cs (Z + conj Z-), ms = cs (Z - conj Z-).
-  auto cotangent = [&](int b0, f32x2 (&ps)[S], f32x2 (&ms)[S]) {
-    f32x2 z[S];
-    float r0[S], r1[S];
-    const int u_max = SH + FBW_HOP + g.N - 2;
-#pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const int n = P * m + tid;
-      const int u = n >= SH ? n : n + NF;
-      const int t0 = (b0 - 1) * FBW_HOP + u, t1 = t0 + FBW_HOP;
-      r0[m] = gb[t0 < 0 ? 0 : (t0 >= g.T ? g.T - 1 : t0)];
-      r1[m] = gb[t1 < 0 ? 0 : (t1 >= g.T ? g.T - 1 : t1)];
-    }
-#pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const int n = P * m + tid;
-      const int u = n >= SH ? n : n + NF;
-      const int t0 = (b0 - 1) * FBW_HOP + u, t1 = t0 + FBW_HOP;
-      const bool in = u <= u_max;
-      z[m] = f32x2{(in && t0 >= 0 && t0 < g.T) ? r0[m] : 0.f, (in && t1 >= 0 && t1 < g.T) ? r1[m] : 0.f};
-    }
-    transform(z);
-    split(z, ps, ms);
-#pragma unroll
-    for (int m = 0; m < S; ++m) { ps[m] = ps[m] * cs; ms[m] = ms[m] * cs; }
-  };
-  // tap rows j, j + 1 (shifted) packed -> h0 = 2 H_j, h1 = 2 H_j+1
-  auto tap_spectra = [&](int j, f32x2 (&h0)[S], f32x2 (&h1)[S]) {
-    f32x2 z[S];
-    float ra[6], rb[6];
-    const float* tr0 = tb + (long)(j < g.F ? j : g.F - 1) * g.N;
-    const float* tr1 = tb + (long)(j + 1 < g.F ? j + 1 : g.F - 1) * g.N;
-#pragma unroll
-    for (int m = 2; m < S; ++m) {
-      int i = P * m + tid - SH;
-      i = i < 0 ? 0 : (i >= g.N ? g.N - 1 : i);
-      ra[m - 2] = tr0[i];
-      rb[m - 2] = tr1[i];
-    }
-    z[0] = z[1] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int m = 2; m < S; ++m) {
-      const int i = P * m + tid - SH;
-      const bool ok = i >= 0 && i < g.N;
-      z[m] = f32x2{ok ? ra[m - 2] : 0.f, ok ? rb[m - 2] : 0.f};
-    }
-    transform(z);
-    f32x2 d[S];
-    split(z, h0, d);
-#pragma unroll
-    for (int m = 0; m < S; ++m) h1[m] = mul_mi(d[m]);          // d / i
   };
 
-  f32x2 carry[S];
+  // ---- spectra (layout S-, fft_r.h; parking and the self-mirrored bins as in fir_blk.hip) ----
+  const int kS0 = PL::s_index(tid, 0);
+  const int kP0 = PL::parked(kS0);
+  auto mirrored = [&](const f32x2* X, int m) -> f32x2 { return X[PL::parked((NF - (kS0 + 64 * m)) & (NF - 1))]; };
+  const float self_mirror = tid < 2 ? -1.0f : 1.0f;
+  auto park_pair = [&](const f32x2 (&z)[S], f32x2* X) {          // a packed transform of two real sequences, to be split
+    X[kP0] = z[0] * f32x2{self_mirror, self_mirror};
 #pragma unroll
-  for (int m = 0; m < S; ++m) carry[m] = f32x2{0.f, 0.f};
-  f32x2 Hc[S];                                                 // 2 H_b0 (input gradient only)
-  const int q0 = q_first > 0 ? q_first - 1 : 0;
-  if (WITH_DX) {
-    f32x2 hdrop[S];
-    tap_spectra(2 * q_first, Hc, hdrop);
-  }
-  for (int q = q0; q < q_last; ++q) {
-    const int b0 = 2 * q;
-    const bool own = q >= q_first;
-    f32x2 ps[S], ms[S];
-    cotangent(b0, ps, ms);                                     // cs * 2 S_b0,  cs * 2i S_b0+1
-    f32x2 p0[S], d0[S], p1[S], d1[S];
-    block_spectra(b0, p0, d0);
-    block_spectra(b0 + 1, p1, d1);
-    // tap-gradient spectra (header): conj(X1) S and conj(X2) S of both blocks
-    f32x2 DH0[S], DH1[S];
+    for (int m = 1; m < S; ++m) X[kP0 + 64 * m] = z[m];
+  };
+  // From P = FFT(a + i b) (z in S-, parked in Zp): Sa = c FFT(a), Sb = c FFT(b), both in S-
+  const float cs = 0.5f / (float)NF;                           // the 1/2 of the Hermitian combination N + conj M and the 1/N of the inverse
+  const f32x2 kHa = {0.5f * cs, 0.5f * cs};
+  const f32x2 kMi = {0.5f * cs, -0.5f * cs};                   // times (-i) after the half swap of swap_scale
+  auto split_pair = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Sa)[S], f32x2 (&Sb)[S]) {
 #pragma unroll
-    for (int m = 0; m < S; ++m) {
-      const f32x2 a0 = cmulc(p0[m], ps[m]);                    // conj(X1_b0) S_b0 / NF
-      const f32x2 c0 = mul_i(cmulc(d0[m], ps[m]));             // conj(X2_b0) S_b0 / NF
-      const f32x2 a1 = mul_mi(cmulc(p1[m], ms[m]));            // conj(X1_b1) S_b1 / NF
-      const f32x2 c1 = cmulc(d1[m], ms[m]);                    // conj(X2_b1) S_b1 / NF
-      DH0[m] = carry[m] + a0;
-      DH1[m] = c0 + a1;
-      if (b0 == g.F - 1) DH0[m] = DH0[m] + c0;                 // the last row also takes its own block's x2 term
-      if (b0 + 1 == g.F - 1) DH1[m] = DH1[m] + c1;
-      carry[m] = c1;
+    for (int m = 0; m < S; m += 2) {
+      const f32x2 n0 = mirrored(Zp, m), n1 = mirrored(Zp, m + 1);
+      const f32x2 p0 = fft::sub_conj(z[m], n0), p1 = fft::sub_conj(z[m + 1], n1);     // 2 sigma FFT(a)
+      const f32x2 d0 = fft::add_conj(z[m], n0), d1 = fft::add_conj(z[m + 1], n1);     // 2 i sigma FFT(b)
+      Sa[m] = p0 * kHa;
+      Sa[m + 1] = p1 * kHa;
+      Sb[m] = fft::swap_scale(d0, kMi);
+      Sb[m + 1] = fft::swap_scale(d1, kMi);
     }
-    if (own) {
-      float r0[S], r1[S];
-      inverse_pair(DH0, DH1, r0, r1);
-      // d_taps[j][i] = d h'_j[i + SH]
+  };
+  // tap rows: G1 = c (H_j - i H_j+1) = c conj T[-k], G0 = c (H_j-1 - i H_j), Hc' = c H_j+1 (fir_blk.hip, split_taps); c = 2:
+  // the input gradient's inverse has no Hermitian combination, and the cotangent spectra it meets carry 1 / 2N
+  const float ct = 2.0f;
+  const f32x2 kG1 = {-ct, ct};
+  const f32x2 kTi = {0.5f * ct, -0.5f * ct};
+  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Hc)[S], f32x2 (&G0)[S], f32x2 (&G1)[S]) {
 #pragma unroll
-      for (int m = 2; m < S; ++m) {
-        const int i = P * m + tid - SH;
-        if (i >= 0 && i < g.N) {
-          dtb[(long)b0 * g.N + i] = r0[m];
-          if (b0 + 1 < g.F) dtb[(long)(b0 + 1) * g.N + i] = r1[m];
-        }
+    for (int m = 0; m < S; m += 2) {
+      const f32x2 n0 = mirrored(Zp, m), n1 = mirrored(Zp, m + 1);
+      const f32x2 p0 = fft::sub_conj(z[m], n0), p1 = fft::sub_conj(z[m + 1], n1);
+      const f32x2 d0 = fft::add_conj(z[m], n0), d1 = fft::add_conj(z[m + 1], n1);
+      G1[m] = n0 * kG1;
+      G1[m + 1] = n1 * kG1;
+      G0[m] = fft::swap_scale_add(p0, kTi, Hc[m]);
+      G0[m + 1] = fft::swap_scale_add(p1, kTi, Hc[m + 1]);
+      Hc[m] = fft::swap_scale(d0, kTi);
+      Hc[m + 1] = fft::swap_scale(d1, kTi);
+    }
+  };
+
+  // ---- preamble: what the warm-up pass q_first - 1 needs -- the cotangent spectra of its pair and (input gradient) the
+  // spectrum of tap row 2 q_first - 2 ... see the loop; an utterance's first run warms up on blocks and times before the
+  // signal, which read zero ----
+  typename PL::Tw tw;
+  Seg sgm = load_seg(q_first - 1);
+  Four t1 = load_taps(2 * q_first - 3), t2 = load_taps(2 * q_first - 2);
+  Four x0 = load_blk(2 * q_first - 2), x1 = load_blk(2 * q_first - 1);
+  tw.init(tid);
+  f32x2 S0[S], S1[S], Uc[S], Hc[S], G0[S], G1[S];
+#pragma unroll
+  for (int m = 0; m < S; ++m) {
+    Uc[m] = f32x2{0.f, 0.f};
+    Hc[m] = f32x2{0.f, 0.f};
+    G0[m] = f32x2{0.f, 0.f};
+    G1[m] = f32x2{0.f, 0.f};
+  }
+  {
+    f32x2 zc[S];
+    pack_seg(sgm, zc);
+    if (WITH_DX) {
+      f32x2 zt[S];
+      pack_taps(t1, t2, zt);                                     // rows 2 q_first - 3, 2 q_first - 2: leaves Hc = c H_(2 q_first - 2)
+      PL::template forward_s2<false, true>(zc, zt, tw, bA, bC, bB, bD, tid);
+      park_pair(zc, bA);
+      park_pair(zt, bB);
+      __syncthreads();
+      split_taps(zt, bB, Hc, G0, G1);
+    } else {
+      PL::template forward_s<false, true>(zc, tw, bA, bC, tid);
+      park_pair(zc, bA);
+      __syncthreads();
+    }
+    split_pair(zc, bA, S0, S1);
+  }
+  __syncthreads();                                              // every wave is done with bA / bB (the splits above) before they are written again
+  if (WITH_DX) {                                                // rows 2 q_first - 1, 2 q_first: G0, G1 of the warm-up pair
+    f32x2 zt[S];
+    const Four ta = load_taps(2 * q_first - 1), tb2 = load_taps(2 * q_first);
+    pack_taps(ta, tb2, zt);
+    PL::template forward_s<true, true>(zt, tw, bB, bD, tid);
+    park_pair(zt, bB);
+    __syncthreads();
+    split_taps(zt, bB, Hc, G0, G1);
+    __syncthreads();
+  }
+
+  for (int q = q_first - 1; q < q_last; ++q) {
+    const bool warm = q < q_first;                              // workgroup-uniform
+    const int b0 = 2 * q;
+    f32x2 z0[S], z1[S];
+    pack_blk(x0, b0 >= 0 && b0 < g.F, z0);
+    pack_blk(x1, b0 + 1 >= 0 && b0 + 1 < g.F, z1);
+    // fetched now: what the later stages of this pass transform (the next pair's cotangent, tap rows) and the next pass's
+    // blocks.  With the input gradient the register file is the limit (three more spectra are live through the first
+    // stage): there only the tap rows are fetched here, the rest behind the stage that frees the registers.
+    if (WITH_DX) {
+      t1 = load_taps(b0 + 3);
+      t2 = load_taps(b0 + 4);
+    } else {
+      x0 = load_blk(b0 + 2);
+      x1 = load_blk(b0 + 3);
+      sgm = load_seg(q + 1);
+    }
+    PL::template forward_s2<true, true>(z0, z1, tw, bA, bC, bB, bD, tid);
+    // U_b = conj(Z_b) S_b (plain layout S); the tap-gradient spectrum of rows b0, b0 + 1
+    f32x2 V[S];
+#pragma unroll
+    for (int m = 0; m < S; m += 2) {
+      const f32x2 l0 = fft::cmul_lo(z0[m], S0[m]), l1 = fft::cmul_lo(z1[m], S1[m]);
+      const f32x2 l2 = fft::cmul_lo(z0[m + 1], S0[m + 1]), l3 = fft::cmul_lo(z1[m + 1], S1[m + 1]);
+      z0[m] = fft::cmulc_hi(z0[m], S0[m], l0);
+      z1[m] = fft::cmulc_hi(z1[m], S1[m], l1);
+      z0[m + 1] = fft::cmulc_hi(z0[m + 1], S0[m + 1], l2);
+      z1[m + 1] = fft::cmulc_hi(z1[m + 1], S1[m + 1], l3);
+    }
+    if (WITH_DX) {
+      // conj D_b = G_b conj(S_b) (inverse by the forward transform; d x_b = sigma ((1 - lambda) Re - lambda Im)), formed at once
+      // and in place: the cotangent and filter spectra are dead from here on
+#pragma unroll
+      for (int m = 0; m < S; m += 2) {
+        const f32x2 l0 = fft::cmul_lo(S0[m], G0[m]), l1 = fft::cmul_lo(S1[m], G1[m]);
+        const f32x2 l2 = fft::cmul_lo(S0[m + 1], G0[m + 1]), l3 = fft::cmul_lo(S1[m + 1], G1[m + 1]);
+        S0[m] = fft::cmulc_hi(S0[m], G0[m], l0);
+        S1[m] = fft::cmulc_hi(S1[m], G1[m], l1);
+        S0[m + 1] = fft::cmulc_hi(S0[m + 1], G0[m + 1], l2);
+        S1[m + 1] = fft::cmulc_hi(S1[m + 1], G1[m + 1], l3);
       }
-      if (WITH_DX) {
-        f32x2 Ha[S], Hb[S];
-        tap_spectra(b0 + 1, Ha, Hb);                           // 2 H_b0+1, 2 H_b0+2 (rows clamp to F-1)
+      sgm = load_seg(q + 1);
+    }
+    {
+      const bool last0 = b0 == g.F - 1, last1 = b0 + 1 == g.F - 1;      // the held last row (core.py:167) also takes its own block's second term
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          f32x2 V1[S], V2[S];
+      for (int m = 0; m < S; ++m) {
+        const f32x2 Bj = last0 ? Uc[m] + z0[m] : Uc[m];
+        const f32x2 Bj1 = last1 ? z0[m] + z1[m] : z0[m];
+        const f32x2 Pp = Bj + z1[m], Qq = Bj - z1[m];
+        const f32x2 T1 = z0[m] - Bj1, T2 = z0[m] + Bj1;
+        V[m] = fft::sub_mi(T1, Pp);                              // N = (U_j - B_j+1) + i (B_j + U_j+1)   (the 1/2 is in S)
+        bA[kP0 + 64 * m] = fft::sub_mi(T2, Qq);                  // M = (U_j + B_j+1) + i (B_j - U_j+1), parked
+        Uc[m] = z1[m];                                           // carried: U of the pair's second block
+      }
+    }
+    __syncthreads();
 #pragma unroll
-          for (int m = 0; m < S; ++m) {
-            if (h == 0) {
-              V1[m] = cmulc(Hc[m], ps[m]);                     // conj(H_b0) S_b0 / NF
-              V2[m] = cmulc(Ha[m], ps[m]);
-            } else {
-              V1[m] = mul_mi(cmulc(Ha[m], ms[m]));             // conj(H_b1) S_b1 / NF
-              V2[m] = mul_mi(cmulc(Hb[m], ms[m]));
-            }
-          }
-          float dx1[S], dx2[S];
-          inverse_pair(V1, V2, dx1, dx2);
-          if (b0 + h < g.F) {
+    for (int m = 0; m < S; ++m) V[m] = fft::add_conj(mirrored(bA, m), V[m]);   // conj V = M[-k] + conj N[k]: inverse by the forward transform
+
+    if (WITH_DX) {
+      f32x2 zt[S];
+      pack_taps(t1, t2, zt);                                     // rows b0 + 3, b0 + 4: the next pair's
+      PL::template transposed_and_forward_s<true, true>(S0, zt, tw, bC, bA, bD, bB, tid);
+      park_pair(zt, bC);
+      __syncthreads();
+      split_taps(zt, bC, Hc, G0, G1);
+      x0 = load_blk(b0 + 2);
+      x1 = load_blk(b0 + 3);
+      auto store_dx = [&](const f32x2 (&W)[S], int bi) {
+        const bool live = !warm && bi < g.F;
+        const BufF32 dr = BufF32::make(d_x + (long)b * g.T + (long)(live ? bi : 0) * FBW_HOP, live ? FBW_HOP : 0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              const float lam = (float)(P * m + tid) * inv_hop;
-              d_x[(long)b * g.T + (long)(b0 + h) * FBW_HOP + P * m + tid] = fmaf(1.0f - lam, dx1[m], lam * dx2[m]);
-            }
-          }
+        for (int m = 0; m < 4; ++m) {
+          const float lam = (float)(P * m + tid) * inv_hop;
+          dr.st(sg * fmaf(1.0f - lam, W[m].x, -(lam * W[m].y)), tid4 + 4 * P * m);
         }
+      };
+      store_dx(S0, b0);
+      if (!warm) {
+        PL::template transposed<true>(S1, tw, bD, bA, tid);
+        store_dx(S1, b0 + 1);
+      } else {
+        __syncthreads();                                        // (the barriers of that transform also keep the next stage's writes to
+      }                                                         //  bC behind the split's reads of the parked tap spectrum)
+    }
+
+    // the tap rows' inverse beside the transform of the next pair's cotangent (a full 1024-point input)
+    f32x2 zc[S];
+    pack_seg(sgm, zc);
+    PL::template transposed_and_forward_s<true, false>(V, zc, tw, bC, bA, bD, bB, tid);
+    park_pair(zc, bC);
+    __syncthreads();
+    split_pair(zc, bC, S0, S1);
+    // d_taps[j][i] = d h_j[i + SH]: transform index n = 128 m + tid < 512; row b0 = sigma Re, row b0 + 1 = -sigma Im
+    {
+      const bool own0 = !warm && b0 < g.F, own1 = !warm && b0 + 1 < g.F;
+      const BufF32 r0 = BufF32::make(dtb + (long)(own0 ? b0 : 0) * g.N, own0 ? g.N : 0);
+      const BufF32 r1 = BufF32::make(dtb + (long)(own1 ? b0 + 1 : 0) * g.N, own1 ? g.N : 0);
 #pragma unroll
-        for (int m = 0; m < S; ++m) Hc[m] = Hb[m];
+      for (int m = 0; m < 4; ++m) {
+        r0.st(sg * V[m].x, tap_off[m]);
+        r1.st(-sg * V[m].y, tap_off[m]);
       }
     }
   }
@@ -247,7 +325,7 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
 
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st) {
-  if (hop != FBW_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 30)) return -1;
+  if (hop != FBW_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance below 2^30 bytes (buffer descriptors)
   FirBwdGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 1) / 2;

@@ -11,6 +11,8 @@ import torch
 import bench
 from ddsp_svc_amd import synth
 
+torch.autograd.set_multithreading_enabled(False)       # backward on the calling thread: under rocprofv3 the interpreter has been
+                                                        # seen to hang at exit with autograd's device worker thread alive
 dev = torch.device("cuda:0")
 B, F, n = 32, 862, 256
 kind = sys.argv[1] if len(sys.argv) > 1 else "combsub"
