@@ -554,6 +554,97 @@ __global__ void __launch_bounds__(256) k_sins_bank2_bwd(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same adjoint on the matrix pipe (hop = 512; the default).  R_r[k] = sum_t g[t] w_r[t] sin(k theta_t) is a reduction
+// over the 512 samples of the frame -- in k_sins_bank2_bwd every thread's products went through an LDS tile and two
+// barriers per 16 harmonics (0.79 ms against 0.22 ms forward).  With blocks of 33 harmonics around a centre c,
+//     sin((c +- j) theta) = sin(c theta) cos(j theta) +- cos(c theta) sin(j theta),   j = 1..16,
+// the sums are two small matrix products per frame,
+//     E[j][n] = sum_t cos(j theta_t) alpha_n[t],   O[j][n] = sum_t sin(j theta_t) beta_n[t],
+//     alpha_n = g w_r sin(c_b theta), beta_n = g w_r cos(c_b theta),   column n = (block b = n / 2, amplitude row r = n % 2),
+// 16 x 512 times 512 x 16 each (8 blocks x 2 rows cover 264 harmonics), and R_r[c +- j] = E[j][n] +- O[j][n],
+// R_r[c] = sum_t alpha_n[t].  One wave per frame: v_mfma_f32_16x16x4_f32 (exact float32 multiply-adds) takes four
+// samples per instruction and does the reduction over t in its accumulators -- no tables, no LDS tile, no barriers in
+// the loop; a lane evaluates cis((i + 1) theta) and cis(c theta) of ITS sample directly (exact float32 product split +
+// hardware sine / cosine, as the forward kernel's seeds).
+// ------------------------------------------------------------------------------------------------
+constexpr int SBM_J = 16;                             // pairs per block
+constexpr int SBM_W = 2 * SBM_J + 1;                  // harmonics per block: 33
+constexpr int SBM_G = 8;                              // blocks per pass of the sample loop (16 columns)
+
+__global__ void __launch_bounds__(64) k_sins_bank_bwd_mfma(const float* __restrict__ f0_frames,
+                                                           const float* __restrict__ initial_phase,
+                                                           const float* __restrict__ grad_out, int F, int H, int HP,
+                                                           Upsampler up, PhaseCfg cfg, const double* __restrict__ phase0,
+                                                           float* __restrict__ partial /* [B*F][HP][2] */) {
+  constexpr int HOP = 512, SPL = 8;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float s_theta[HOP], s_gw[2][HOP];
+  const int lane = threadIdx.x;
+  const long fr = blockIdx.x;
+  const long b = fr / F;
+  const int f = (int)(fr - b * F);
+  const float* f0_row = f0_frames + b * F;
+  {
+    // wrapped phase (vocoder.py:564-574) and weighted cotangent of the lane's eight consecutive samples
+    const Upsampler::Row3 rows = up.load3(f0_row, f);
+    const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
+    double pre[SPL];
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < SPL; ++r) {
+      acc += cfg.term(up.at3_pow2(rows, lane * SPL + r));       // the launcher has checked up.shift > 0
+      pre[r] = acc;
+    }
+    const double base = phase0[fr] + wave_excl_scan(acc, lane);
+    const float* gp = grad_out + b * (long)F * HOP + (long)f * HOP + lane * SPL;
+#pragma unroll
+    for (int r = 0; r < SPL; ++r) {
+      const int j = lane * SPL + r;
+      const float lam = (float)j * up.scale;                    // interpolation weight towards frame f + 1 (core.py:66-70)
+      const float gv = gp[r];
+      s_theta[j] = kTwoPiF * cfg.wrap(base + pre[r], ip);
+      s_gw[0][j] = gv * (1.0f - lam);
+      s_gw[1][j] = gv * lam;
+    }
+  }
+  __syncthreads();
+  const int k4 = lane >> 4, i = lane & 15;
+  const float jf = (float)(i + 1);                              // this lane's row of the cosine / sine matrices
+  const int r = i & 1;
+  const int ngroups = (H + SBM_W * SBM_G - 1) / (SBM_W * SBM_G);
+  for (int grp = 0; grp < ngroups; ++grp) {
+    const int c = SBM_J + 1 + SBM_W * (SBM_G * grp + (i >> 1));  // centre harmonic of this lane's column
+    const float cf = (float)c;
+    f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accO = {0.f, 0.f, 0.f, 0.f};
+    float centre = 0.f;
+#pragma unroll 2
+    for (int s = 0; s < HOP / 4; ++s) {
+      const int t = 4 * s + k4;
+      const float th = s_theta[t], w = s_gw[r][t];
+      float cj, sj, cc, sc;
+      cis_product(jf, th, cj, sj);
+      cis_product(cf, th, cc, sc);
+      const float alpha = w * sc, beta = w * cc;
+      accE = __builtin_amdgcn_mfma_f32_16x16x4f32(cj, alpha, accE, 0, 0, 0);
+      accO = __builtin_amdgcn_mfma_f32_16x16x4f32(sj, beta, accO, 0, 0, 0);
+      centre += alpha;
+    }
+    centre += __shfl_xor(centre, 16);
+    centre += __shfl_xor(centre, 32);
+    // lane holds E / O [j = 4 k4 + e + 1][n = i]
+    float* dst = partial + fr * (long)HP * 2 + r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * k4 + e + 1;
+      const int kp = c + j, km = c - j;
+      if (kp <= H) dst[2 * (kp - 1)] = accE[e] + accO[e];
+      if (km <= H) dst[2 * (km - 1)] = accE[e] - accO[e];      // km >= 1 always
+    }
+    if (k4 == 0 && c <= H) dst[2 * (c - 1)] = centre;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_sins_bank_bwd_combine(const float* __restrict__ f0_frames,
                                                                const float* __restrict__ c_amp, long ld_amp,
                                                                const float* __restrict__ partial, int F, int H, int HP,
@@ -644,8 +735,12 @@ int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, con
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   const int HP = (H + 15) & ~15;
-  hipLaunchKernelGGL(k_sins_bank2_bwd, dim3((unsigned)((long)B * F)), dim3(256), 0, st, f0_frames, initial_phase, grad_out, F,
-                     H, up, cfg, phase0, scratch);
+  if (up.shift > 0 && knob(KNOB_SINS_V1) == 0)                  // matrix-pipe form: one wave per frame
+    hipLaunchKernelGGL(k_sins_bank_bwd_mfma, dim3((unsigned)((long)B * F)), dim3(64), 0, st, f0_frames, initial_phase, grad_out,
+                       F, H, HP, up, cfg, phase0, scratch);
+  else
+    hipLaunchKernelGGL(k_sins_bank2_bwd, dim3((unsigned)((long)B * F)), dim3(256), 0, st, f0_frames, initial_phase, grad_out, F,
+                       H, up, cfg, phase0, scratch);
   const long total = (long)B * F * H;
   hipLaunchKernelGGL(k_sins_bank_bwd_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0_frames, c_amp,
                      ld_amp, scratch, F, H, HP, (float)sr / 2.0f, total, d_c);

@@ -139,7 +139,7 @@ def test_combsub_backward_golden(dev, golden_dir):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
-@pytest.mark.parametrize("H,F", [(40, 6), (256, 5), (1, 3), (17, 1)])
+@pytest.mark.parametrize("H,F", [(40, 6), (256, 5), (1, 3), (17, 1), (300, 2), (264, 2)])   # 33-harmonic blocks, 8 per pass: one / two passes
 def test_sinusoid_bank_backward(dev, H, F):
     """adjoint of the sinusoid bank w.r.t. the amplitude control: harmonic counts that are not a multiple of the
     16-harmonic block, a single frame (the held last row takes both parts), masked harmonics above Nyquist"""
