@@ -151,10 +151,13 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
   };
   auto pack_blk = [&](const Blk& cx, bool live, f32x2 (&z)[S]) {
+    // noise = rand * 2 - 1 (vocoder.py:603,854) as one multiply-add with workgroup-uniform coefficients: (2, -1) for a
+    // uniform draw inside the signal, (1, 0) otherwise (a block beyond the signal reads zeros and must stay zero)
+    const bool u01 = (RNG || x_is_u01) && live;
+    const float ua = u01 ? 2.0f : 1.0f, ub = u01 ? -1.0f : 0.0f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      float xv = cx.v[m];
-      if ((RNG || x_is_u01) && live) xv = fmaf(2.0f, xv, -1.0f);   // noise = rand*2-1 (vocoder.py:603,854); uniform condition
+      const float xv = fmaf(ua, cx.v[m], ub);
       const float lam = (float)(P * m + tid) * inv_hop;
       z[m] = f32x2{(1.0f - lam) * xv, lam * xv};
     }
@@ -259,9 +262,10 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   // single-wave throughput (tools/fir_blk_timeline.py: lifetimes of 83 / 105 us inside one CU).  The waves take turns
   // instead: priority 1 on alternate pairs, the phase taken from the wave slot.
   const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
+  const int turns_mask = g.turns ? 1 : 0;
   for (int q = q_first - 1; q < q_last; ++q) {
     const bool warm = q < q_first;                              // workgroup-uniform
-    if (g.turns && ((q + turn) & 1)) __builtin_amdgcn_s_setprio(1);
+    if ((q + turn) & turns_mask) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     const int b0 = 2 * q;
     const bool stamp_it = q - q_first == 5;

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export 
 V=${V:-r03_v20}
 echo "== host =="; nproc; lscpu | grep -m1 "Model name"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee "$O/${V}_pytest_gpu.log"
+  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee "$O/${V}_pytest_gpu.log"
   timeout 200 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$O/${V}_smoke.log"
 fi
 ( time timeout 400 python bench.py ) 2>&1 | tail -5 > "$O/${V}_bench_combsub.log"; grep '^{' "$O/${V}_bench_combsub.log" | tail -1 > "$O/${V}_bench_combsub.json"
