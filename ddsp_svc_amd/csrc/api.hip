@@ -286,8 +286,11 @@ int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, l
   if (act == DDSP_HIP_ACT_EXP && (!ctrl || ld_ctrl < n_mag)) return DDSP_HIP_EINVAL;
   if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
   if (d_im && act != DDSP_HIP_ACT_NONE) return DDSP_HIP_ESHAPE;
-  launch_ir_gemm_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
-                     S(stream));
+  const TapsFormScope form;
+  if (t_taps_gemm || launch_taps_pfa510_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag,
+                                            d_im != nullptr, d_re, d_im, S(stream)) != 0)
+    launch_ir_gemm_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
+                       S(stream));
   return finish();
 }
 

@@ -454,6 +454,167 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(int KIND, int ACT, int M
   PFA_STAMP(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the tap synthesis at 256 bins (what autograd returns for core.py:254-270 + the window helpers): d_taps
+// [rows, 510] -> gradient of the one-sided response (or of the raw control through the exp activation).  The forward is
+// window . roll . irfft, so the adjoint is a FORWARD real DFT of the windowed, un-rolled tap gradients,
+//     D[k] = sum_m dz[m] exp(-2 pi i k m / 510),   dz[m] = w[j] d_taps[j],  j = (m + 255) mod 510,
+//     d re_k = (c_k / N) Re D[k],   d im_k = (2 / N) Im D[k]  (0 at DC and Nyquist),
+// through the same prime-factor maps and the same small transforms as k_taps_pfa510: two rows ride in one complex
+// transform as conj(dz_a + i dz_b), Out = IDFT+(that) = conj(D_a + i D_b), and the two spectra are separated with
+// Out[510 - k].  Replaces the dense MFMA contraction k_ir_gemm_bwd at n_mag = 256 (0.10-0.13 ms per launch there).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(int ACT, int HAS_IM, int MODE, const float* __restrict__ d_taps,
+                                                         const float* __restrict__ ctrl, long ld_ctrl, float scale,
+                                                         const float* __restrict__ hann, const float* __restrict__ half_width,
+                                                         long rows, float* __restrict__ d_re, float* __restrict__ d_im) {
+  using namespace pfa;
+  __shared__ __attribute__((aligned(16))) float U[U_FLOATS + 2 * ROWS];
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * ROWS;
+  float* Zf = U;                                            // stage 0 -> A: Z[t][m] complex, (row 2t, -row 2t+1)
+  f32x2* W = reinterpret_cast<f32x2*>(U);                  // A -> B
+  f32x2* Out = reinterpret_cast<f32x2*>(U);                // B -> C: Out[t][k] complex
+  float* HW = U + U_FLOATS;                                 // the batch's half widths and their reciprocals
+  if (MODE == MODE_DYNAMIC && tid < ROWS) {
+    const long gr = row0 + tid;
+    const float x = gr < rows ? half_width[gr] : 1.0f;
+    HW[tid] = x;
+    HW[ROWS + tid] = 1.0f / x;
+  }
+  if (MODE == MODE_DYNAMIC) __syncthreads();
+
+  // ---- stage 0: windowed tap gradients -> Z, un-rolled: m = (j + 255) mod 510.  The batch's 16 x 510 gradients are one
+  // contiguous, 16-byte aligned stretch; a thread's groups of four are 1024 floats apart ----
+  {
+    const float* src = d_taps + row0 * NT;
+    const long total = rows * (long)NT - row0 * NT;
+    constexpr int GROUPS = (ROWS * NT / 4 + 255) / 256;     // 8; the last one is partial
+    int r = (4 * tid) / NT, j = 4 * tid - r * NT;
+#pragma unroll 2
+    for (int it = 0; it < GROUPS; ++it) {
+      const int i = 4 * (tid + 256 * it);
+      if (i >= ROWS * NT) break;
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i + 3 < total) gv = *reinterpret_cast<const float4*>(src + i);
+      else {
+        if (i < total) gv.x = src[i];
+        if (i + 1 < total) gv.y = src[i + 1];
+        if (i + 2 < total) gv.z = src[i + 2];
+      }
+      const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int je = j + e, re_ = r;
+        if (je >= NT) { je -= NT; re_ += 1; }
+        float w = 1.0f;
+        if (MODE == MODE_HANN) w = hann[je];
+        else if (MODE == MODE_DYNAMIC) {
+          float u = div_by_row((float)(je - HALF), HW[re_], HW[ROWS + re_]);      // core.py:244
+          if (u > 1.0f) u = 0.0f;                                                  // core.py:245
+          w = (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                               // core.py:246
+        }
+        int m = je + HALF;
+        if (m >= NT) m -= NT;
+        const float v = w * ge[e];
+        Zf[2 * ((re_ >> 1) * NT + m) + (re_ & 1)] = (re_ & 1) ? -v : v;
+      }
+      j += 4;
+      r += 2;
+      if (j >= NT) { j -= NT; r += 1; }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage A: DFT-17 over n1 of Z[(30 n1 + 17 n2) mod 510] ----
+  {
+    const bool act = tid < TR * 30;
+    const int t = act ? tid / 30 : 0, n2 = act ? tid - 30 * t : 0;
+    f32x2 z[17];
+    {
+      const f32x2* zr = reinterpret_cast<const f32x2*>(Zf) + t * NT;
+      int k = 17 * n2;
+#pragma unroll
+      for (int n1 = 0; n1 < 17; ++n1) {
+        z[n1] = zr[k];
+        k += 30;
+        if (k >= NT) k -= NT;
+      }
+    }
+    __syncthreads();                                       // every thread holds its inputs: the region may be overwritten
+    if (act) {
+      dft17(z);
+#pragma unroll
+      for (int k1 = 0; k1 < 17; ++k1) W[w_row(t * 17 + k1) + n2] = z[k1];
+    }
+  }
+  __syncthreads();
+
+  // ---- stage B: DFT-30 over n2; output bin k = (120 k1 + 391 k2) mod 510 ----
+  {
+    const bool act = tid < TR * 17;
+    const int t = act ? tid / 17 : 0, k1 = act ? tid - 17 * t : 0;
+    f32x2 v[30];
+    {
+      const f32x2* src = W + w_row(t * 17 + k1);
+#pragma unroll
+      for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
+    }
+    __syncthreads();                                       // W is in registers: the region becomes Out
+    if (act) {
+      dft30(v);
+      f32x2* o = Out + t * NT;
+      const int base = (120 * k1) % NT;
+#pragma unroll
+      for (int k2 = 0; k2 < 30; ++k2) {
+        int k = base + (391 * k2) % NT;                     // the second term is a compile-time constant
+        if (k >= NT) k -= NT;
+        o[k] = v[k2];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage C: separate the two rows of a transform, scale, activation derivative, coalesced stores (thread = bin) ----
+  {
+    const int k = tid;                                     // 0..255
+    const int kn = k == 0 ? 0 : NT - k;
+    const float inv_n = 1.0f / (float)NT;
+    const float ce = (k == 0 || k == NB - 1) ? 0.5f * inv_n : inv_n;     // c_k / 2N
+    const float ci = (k == 0 || k == NB - 1) ? 0.0f : inv_n;             // 2 / 2N, Im(DC) = Im(Nyquist) = 0
+#pragma unroll 2
+    for (int t = 0; t < TR; ++t) {
+      const f32x2 a = Out[t * NT + k], b = Out[t * NT + kn];
+      // D_a = (conj a + b) / 2, D_b = (conj a - b) / 2i
+      float gre[2] = {ce * (a.x + b.x), ce * (-a.y - b.y)};
+      const float gim[2] = {ci * (b.y - a.y), ci * (b.x - a.x)};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const long gr = row0 + 2 * t + s2;
+        if (gr >= rows) continue;
+        float g = gre[s2];
+        if (ACT == 1) g = g * (scale * expf(ctrl[gr * ld_ctrl + k]));
+        d_re[gr * NB + k] = g;
+        if (HAS_IM) d_im[gr * NB + k] = gim[s2];
+      }
+    }
+  }
+}
+
+// 0 = taken, -1 = not this kernel's shape (the caller uses the dense adjoint)
+int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
+                           int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
+                           hipStream_t st) {
+  if (n != pfa::NB || rows <= 0) return -1;
+  if ((reinterpret_cast<uintptr_t>(d_taps) & 15) != 0) return -1;
+  const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
+  const float* hann = table + 2 * KP * NP;
+  const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
+  hipLaunchKernelGGL(k_taps_pfa510_bwd, dim3((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), dim3(256), 0, st, act == 1 ? 1 : 0,
+                     has_im ? 1 : 0, m, d_taps, ctrl, ld_ctrl, scale, hann, half_width, rows, d_re, d_im);
+  return 0;
+}
+
 // returns 0 when the fast form took the call, -1 when the shape is not its (the caller then uses the dense contraction)
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,

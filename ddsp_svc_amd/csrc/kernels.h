@@ -33,6 +33,9 @@ void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, in
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
                        hipStream_t st, float hw_from_f0_sr = 0.f);
+int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
+                           int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
+                           hipStream_t st);
 void launch_window_taps(const float* in, int mode, const float* half_width, long rows, int N, float* out, hipStream_t st);
 void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
                              hipStream_t st);

@@ -460,6 +460,64 @@ def test_tail_golden_256_gpu(dev, golden_dir, name):
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("rows", [1, 16, 17, 50])
+def test_taps_adjoint_prime_factor_form(dev, rows, knobs):
+    """n_mag = 256: the adjoint of the tap synthesis as a forward prime-factor transform (k_taps_pfa510_bwd) against torch's
+    autograd through the reference's op chain (irfft -> roll -> window) AND against the dense contraction it replaces (knob
+    TAPS_GEMM): real response through the exp activation and complex response, every window mode, odd row counts and
+    partial batches of 16"""
+    from ddsp_svc_amd import _ffi, core
+    n, N = 256, 510
+    rng = np.random.default_rng(100 + rows)
+    c = rng.standard_normal((rows, n)).astype(np.float32)
+    im = rng.standard_normal((rows, n)).astype(np.float32)
+    hw = (rng.random(rows) * 300 + 20).astype(np.float32)
+    dt = rng.standard_normal((rows, N)).astype(np.float32)
+
+    def ref_grads(mode, complex_resp):
+        cc = torch.from_numpy(c).double().requires_grad_(True)
+        ii = torch.from_numpy(im).double().requires_grad_(True)
+        if complex_resp:
+            ir = torch.fft.irfft(torch.complex(cc, ii), n=N)
+        else:
+            ir = torch.fft.irfft(torch.complex(torch.exp(cc) / 128, torch.zeros_like(cc)), n=N)
+        ir = ir.roll(N // 2, -1)
+        j = torch.arange(N, dtype=torch.float64)
+        if mode == O.MODE_HANN:
+            ir = ir * (0.5 - 0.5 * torch.cos(2 * np.pi * j / N))
+        elif mode == O.MODE_DYNAMIC:
+            u = (j - N // 2)[None, :] / torch.from_numpy(hw).double()[:, None]
+            u = torch.where(u > 1, torch.zeros_like(u), u)
+            ir = ir * (1 + torch.cos(np.pi * u)) / 2
+        (ir * torch.from_numpy(dt).double()).sum().backward()
+        return cc.grad.numpy(), (ii.grad.numpy() if complex_resp else None)
+
+    got = {}
+    for path in ("pfa", "gemm"):
+        knobs("TAPS_GEMM", 1 if path == "gemm" else 0)
+        tab = core.ir_table(n, torch.device(dev))
+        for mode in (O.MODE_ROLL, O.MODE_HANN, O.MODE_DYNAMIC):
+            for complex_resp in (False, True):
+                d_re = torch.empty(rows, n, dtype=torch.float32, device=dev)
+                d_im = torch.empty(rows, n, dtype=torch.float32, device=dev) if complex_resp else None
+                ctrl = T_(c, dev)
+                hwt = T_(hw, dev)
+                _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(
+                    T_(dt, dev).data_ptr(), None if complex_resp else ctrl.data_ptr(), n,
+                    _ffi.ACT_NONE if complex_resp else _ffi.ACT_EXP, 1.0 if complex_resp else 1.0 / 128, mode,
+                    hwt.data_ptr() if mode == O.MODE_DYNAMIC else None, rows, n, tab.data_ptr(), d_re.data_ptr(),
+                    None if d_im is None else d_im.data_ptr(), _ffi.stream_of(d_re)))
+                want_re, want_im = ref_grads(mode, complex_resp)
+                got[path, mode, complex_resp] = (N_(d_re), None if d_im is None else N_(d_im))
+                assert rms(N_(d_re) - want_re) <= 2e-6 * rms(want_re), (path, mode, complex_resp)
+                if complex_resp:
+                    assert rms(N_(d_im) - want_im) <= 2e-6 * rms(want_im), (path, mode)
+    for key in [k for k in got if k[0] == "pfa"]:
+        a, b = got[key], got[("gemm",) + key[1:]]
+        assert rms(a[0] - b[0]) <= 2e-6 * rms(b[0]), key
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("rows", [1, 16, 17, 50])
 def test_taps_prime_factor_form(dev, rows, knobs):
     """n_mag = 256: the prime-factor tap synthesis (csrc/ir_pfa.hip: irfft-510 as 17 x 2 x 3 x 5 without twiddles, two
     frames per complex transform) against the oracle AND against the dense contraction it replaces (knob TAPS_GEMM), for
