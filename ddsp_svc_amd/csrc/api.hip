@@ -683,4 +683,52 @@ int ddsp_hip_spectral_loss_backward(const float* spec_true, const float* spec_pr
   return finish();
 }
 
+size_t ddsp_hip_stft_loss_table_bytes(int n_fft) { return czt_table_bytes(n_fft); }
+
+int ddsp_hip_stft_loss_tables(int n_fft, float* tables, void* stream) {
+  if (!czt_plan(n_fft)) return DDSP_HIP_ESHAPE;
+  if (!tables) return DDSP_HIP_EINVAL;
+  if (launch_czt_tables(n_fft, tables, S(stream)) != 0) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_stft_loss_frames(int T, int n_fft, int hop) {
+  if (n_fft < 1 || hop < 1 || T < n_fft) return 0;
+  return 1 + (T - n_fft) / hop;
+}
+
+size_t ddsp_hip_stft_loss_scratch_bytes(int B, int T, int n_fft, int hop) {
+  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, hop);
+  if (B < 1 || frames < 1 || !czt_plan(n_fft)) return 0;
+  return sss_wave_scratch_bytes(B, n_fft, frames);
+}
+
+int ddsp_hip_stft_loss(const float* x_true, const float* x_pred, int B, int T, long ld, int n_fft, int hop,
+                       const float* tables, float inv_window_norm, float eps, float alpha, void* scratch,
+                       size_t scratch_bytes, float* spec_true, float* spec_pred, float* norms, float* loss, void* stream) {
+  if (B < 1 || T < 1 || ld < T || !(inv_window_norm > 0.f)) return DDSP_HIP_EINVAL;
+  if (!x_true || !x_pred || !tables || !scratch || !spec_true || !spec_pred || !norms || !loss) return DDSP_HIP_EINVAL;
+  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, hop);
+  if (!czt_plan(n_fft) || frames < 1) return DDSP_HIP_ESHAPE;
+  if (scratch_bytes < sss_wave_scratch_bytes(B, n_fft, frames)) return DDSP_HIP_EWS;
+  if (launch_sss_wave(x_true, x_pred, B, ld, n_fft, hop, frames, tables, inv_window_norm, eps, alpha, (double*)scratch,
+                      spec_true, spec_pred, norms, loss, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft,
+                                const float* tables, const float* norms, float inv_window_norm, float eps, float alpha,
+                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate,
+                                void* stream) {
+  if (B < 1 || T < 1 || ld_dx < T || !(inv_window_norm > 0.f)) return DDSP_HIP_EINVAL;
+  if (!spec_true || !spec_pred || !tables || !norms || !grad_out || !d_x) return DDSP_HIP_EINVAL;
+  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, n_fft);
+  if (!czt_plan(n_fft) || frames < 1) return DDSP_HIP_ESHAPE;
+  if (launch_sss_wave_bwd(spec_true, spec_pred, B, T, n_fft, frames, tables, norms, inv_window_norm, eps, alpha, grad_out,
+                          wrt_true ? 1 : 0, d_x, ld_dx, accumulate ? 1 : 0, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 }  // extern "C"

@@ -1,4 +1,4 @@
-// Complex FFT of N = 512 R points (R = 2: 1024, R = 4: 2048) for one workgroup of P = 64 R threads, 8 points per
+// Complex FFT of N = 512 R points (R = 2: 1024, R = 4: 2048, R = 8: 4096) for one workgroup of P = 64 R threads, 8 points per
 // thread in registers, three LDS exchanges through two ping-pong buffers -- the generalisation of fft2048.h
 // (whose complex helpers and radix-4/8 butterflies it re-uses) that the short-time spectral filters of
 // CombSubFast (window 1024) and CombSubSuperFast (window 2048) are built on.
@@ -19,7 +19,7 @@ namespace fft {
 
 template <int R>
 struct Plan {
-  static_assert(R == 2 || R == 4, "N = 1024 or 2048");
+  static_assert(R == 2 || R == 4 || R == 8, "N = 1024, 2048 or 4096");
   static constexpr int N = 512 * R;
   static constexpr int P = 64 * R;          // threads
   static constexpr int SLOTS = 8;           // complex points per thread: k = P m + tid
@@ -46,8 +46,11 @@ struct Plan {
 
   // v[n1] = z[P n1 + tid]  ->  v[m] = Z[P m + tid].  A and B hold N complex words each.
   // A must be free of readers on entry; on return A may still be read by slower waves (pass 4), B is free.
+  // HI_ZERO: v[4..7] are zero on entry (an input zero-padded to twice its length) and need not be set.
+  template <bool HI_ZERO = false>
   static __device__ __forceinline__ void forward(f32x2 (&v)[8], const Tw& tw, f32x2* A, f32x2* B, int tid) {
-    dft8(v);
+    if (HI_ZERO) dft8_lo4(v);
+    else dft8(v);
     twiddle7(v, tw.w1);
     // R = 2: a row of the second pass is 16 words, so the two rows k1, k1 + 1 that a 32-lane read touches would start in
     // the same banks; odd rows are stored with their 16-blocks swapped in pairs (R = 4: 32-word rows, nothing to do)
@@ -79,7 +82,11 @@ struct Plan {
       const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
       const f32x2* src = A + k2 * C + k1 * R;
       f32x2 t[8];
-      if constexpr (R == 4) {
+      if constexpr (R == 8) {
+#pragma unroll
+        for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + n4];
+        dft8(t);                                                                    // k4 = 0..7 -> slot m = k4
+      } else if constexpr (R == 4) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           f32x2 a0 = src[(k3lo + 4 * s) * P + 0], a1 = src[(k3lo + 4 * s) * P + 1];

@@ -77,4 +77,16 @@ int launch_sss_loss(const float* xt, const float* xp, int B, long per_utt, float
                     double* scratch, float* norms, float* loss, hipStream_t st);
 int launch_sss_loss_bwd(const float* xt, const float* xp, int B, long per_utt, const float* norms, float inv_wn,
                         float eps, float alpha, const float* grad_out, int wrt_true, float* dx, hipStream_t st);
+void launch_sss_final(const double* scratch, int B, int chunks, long per_utt, float alpha, float* norms, float* loss,
+                      hipStream_t st);
+int czt_plan(int n);
+size_t czt_table_bytes(int n);
+int launch_czt_tables(int n, float* tab, hipStream_t st);
+size_t sss_wave_scratch_bytes(int B, int n, int frames);
+int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int hop, int frames, const float* tab,
+                    float inv_wn, float eps, float alpha, double* scratch, float* spec_t, float* spec_p, float* norms,
+                    float* loss, hipStream_t st);
+int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int frames, const float* tab,
+                        const float* norms, float inv_wn, float eps, float alpha, const float* grad_out, int wrt_true,
+                        float* dx, long ld_dx, int accumulate, hipStream_t st);
 }  // namespace ddsp

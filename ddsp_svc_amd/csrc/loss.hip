@@ -142,6 +142,12 @@ int sss_chunks(int B, long per_utt) {
 
 size_t sss_scratch_bytes(int B, long per_utt) { return (size_t)B * sss_chunks(B, per_utt) * 3 * sizeof(double); }
 
+void launch_sss_final(const double* scratch, int B, int chunks, long per_utt, float alpha, float* norms, float* loss,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_sss_final, dim3(1), dim3(SL_THREADS), 0, st, scratch, B, chunks, 1.0 / (double)B,
+                     1.0 / ((double)B * (double)per_utt), alpha, norms, loss);
+}
+
 int launch_sss_loss(const float* xt, const float* xp, int B, long per_utt, float inv_wn, float eps, float alpha,
                     double* scratch, float* norms, float* loss, hipStream_t st) {
   if (B < 1 || B > 65535 || per_utt < 1) return -1;
@@ -149,8 +155,7 @@ int launch_sss_loss(const float* xt, const float* xp, int B, long per_utt, float
   hipLaunchKernelGGL(k_sss_partial, dim3((unsigned)chunks, (unsigned)B), dim3(SL_THREADS), 0, st,
                      reinterpret_cast<const float2*>(xt), reinterpret_cast<const float2*>(xp), per_utt, chunks, inv_wn,
                      eps, scratch);
-  hipLaunchKernelGGL(k_sss_final, dim3(1), dim3(SL_THREADS), 0, st, (const double*)scratch, B, chunks, 1.0 / (double)B,
-                     1.0 / ((double)B * (double)per_utt), alpha, norms, loss);
+  launch_sss_final(scratch, B, chunks, per_utt, alpha, norms, loss, st);
   return 0;
 }
 

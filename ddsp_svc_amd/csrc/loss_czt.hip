@@ -1,0 +1,413 @@
+// Spectral loss of the training loop straight from the two waveforms (SURVEY.md 8-f #3b): ddsp/loss.py:9-32 with the
+// STFT of torchaudio's Spectrogram(n_fft, hop, power=1, normalized=True, center=False) (:20) inside the kernel.
+//
+// RSSLoss draws ARBITRARY transform sizes n in [fft_min, fft_max) (:47) -- most of them with large prime factors, where
+// a library FFT falls back to Bluestein's algorithm over several passes through HBM.  Here the whole chain of one frame
+// stays in one workgroup: the DFT of size n is the chirp-z identity
+//     X[k] = c[k] sum_j (x[j] w[j] c[j]) conj(c)[k - j],     c[j] = exp(-i pi j^2 / n),
+// a circular convolution of size N = 1024 / 2048 / 4096 >= 2n - 1 on the plans of fft_r.h (two transforms: the chirp
+// filter's spectrum is a table).  The two REAL signals of the loss ride in ONE complex transform, z = x_true + i x_pred,
+// and come apart through Z[k] and conj Z[n - k]; magnitudes, the three reductions of loss.hip and the stores of the two
+// spectra (the backward pass reads them) follow in registers.
+//   k_czt_tables  : c, w c and the filter spectrum for one n (float64 sums, once per size and device)
+//   k_sss_czt     : frames -> spectra + per (utterance, chunk) float64 partial sums; k_sss_final of loss.hip finishes
+//   k_sss_czt_bwd : d loss / d x for hop == n: the gradient of the spectrum (k_sss_grad's formula) of TWO frames,
+//                   Hermitian-extended, as one inverse chirp-z transform, times the window
+// Bound: arithmetic (per frame pair 2 transforms of N points); HBM sees 8 B per sample pair in and 16 B per bin pair out.
+#include "ddsp_common.h"
+#include "fft_r.h"
+#include "kernels.h"
+
+namespace ddsp {
+using fft::cconj;
+using fft::cmul;
+
+constexpr int CZ_TAB_THREADS = 256;
+
+int czt_plan(int n) {
+  if (n < 2) return 0;
+  if (2 * n - 1 <= 1024) return 2;
+  if (2 * n - 1 <= 2048) return 4;
+  if (2 * n - 1 <= 4096) return 8;
+  return 0;
+}
+
+size_t czt_table_bytes(int n) {
+  const int R = czt_plan(n);
+  return R ? (size_t)(2 * n + 512 * R) * sizeof(float2) : 0;
+}
+
+// tab: c[n] | w c[n] | bhat[N].  Blocks [0, N): one filter-spectrum bin each,
+//     bhat[q] = sum_{|m| < n} exp(+i pi m^2 / n) exp(-2 pi i q m / N) = 1 + 2 sum_{m = 1}^{n - 1} exp(i pi m^2 / n) cos(2 pi q m / N);
+// the blocks behind them fill the chirps.  Phases are reduced in integers, so the float64 arguments are exact.
+__global__ void __launch_bounds__(CZ_TAB_THREADS) k_czt_tables(int n, int N, float2* __restrict__ tab) {
+  __shared__ double red[2][CZ_TAB_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= N) {
+    const int j = ((int)blockIdx.x - N) * CZ_TAB_THREADS + tid;
+    if (j < n) {
+      double s, c;
+      sincospi((double)(((long)j * j) % (2 * n)) / (double)n, &s, &c);
+      const double w = 0.5 - 0.5 * cospi(2.0 * (double)j / (double)n);            // periodic Hann, torch.hann_window
+      tab[j] = float2{(float)c, (float)-s};
+      tab[n + j] = float2{(float)(w * c), (float)(-w * s)};
+    }
+    return;
+  }
+  const int q = blockIdx.x;
+  double re = 0.0, im = 0.0;
+  for (int m = 1 + tid; m < n; m += CZ_TAB_THREADS) {
+    double s, c;
+    sincospi((double)(((long)m * m) % (2 * n)) / (double)n, &s, &c);
+    const double cq = cospi(2.0 * (double)(((long)q * m) % N) / (double)N);
+    re += c * cq;
+    im += s * cq;
+  }
+  re = wave_sum(re);
+  im = wave_sum(im);
+  if (lane == 0) { red[0][wave] = re; red[1][wave] = im; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < CZ_TAB_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+    tab[2 * n + q] = float2{(float)(1.0 + 2.0 * a), (float)(2.0 * b)};
+  }
+}
+
+__device__ __forceinline__ float cz_mag(f32x2 z) { return __builtin_amdgcn_sqrtf(fmaf(z.x, z.x, z.y * z.y)); }
+__device__ __forceinline__ float cz_log(float s) { return 0.6931471805599453f * __builtin_amdgcn_logf(s); }
+
+// One circular convolution with the chirp filter: v[0..3] (natural order, slot m <-> index P m + tid; the upper half of the
+// input is zero padding) -> conj of the result in v[0..7], N times too large.  post[P m + tid] -- the table the caller multiplies the result with -- is fetched between the two
+// transforms, so its latency hides behind the second one (reads past a table's n entries stay inside tab and are unused).
+template <int R, class Between>
+__device__ __forceinline__ void czt_convolve(f32x2 (&v)[8], const typename fft::Plan<R>::Tw& tw, const f32x2* __restrict__ bh,
+                                             const f32x2* __restrict__ post, f32x2 (&pv)[4], f32x2* A, f32x2* B, int tid,
+                                             Between&& between) {
+  using PL = fft::Plan<R>;
+  f32x2 g[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) g[m] = bh[PL::P * m + tid];
+  PL::template forward<true>(v, tw, A, B, tid);              // n <= N / 2: the input fills the slots 0 .. 3 only
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = cconj(cmul(v[m], g[m]));
+#pragma unroll
+  for (int m = 0; m < 4; ++m) pv[m] = post[PL::P * m + tid];   // the result is wanted below n <= N / 2 only
+  between();                                                 // more loads of the caller's that the second transform hides
+  __syncthreads();                                           // pass 4 of the first transform still reads A
+  PL::forward(v, tw, A, B, tid);
+}
+
+template <int R>
+__global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__ xt, const float* __restrict__ xp, long ld,
+                                                    int n, int hop, int frames, int chunks,
+                                                    const float2* __restrict__ tab, float inv_wn, float eps,
+                                                    float2* __restrict__ spec_t, float2* __restrict__ spec_p,
+                                                    double* __restrict__ partial) {
+  using PL = fft::Plan<R>;
+  constexpr int N = PL::N, P = PL::P;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
+  __shared__ double red[3][R];
+  __shared__ int live[2][3];                                 // [frame parity][true, pred: a nonzero sample; the two differ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int bins = n / 2 + 1;
+  const int span = (frames + chunks - 1) / chunks;
+  const int f_lo = c * span;
+  const int f_hi = f_lo + span < frames ? f_lo + span : frames;
+  const f32x2* ch = reinterpret_cast<const f32x2*>(tab);
+  const f32x2* wc = ch + n;
+  const f32x2* bh = ch + 2 * n;
+  typename PL::Tw tw;
+  tw.init(tid);
+  const float scale = 0.5f / (float)N;                       // the inverse transform's 1/N and the 1/2 of the split
+  double d2 = 0.0, s2 = 0.0, l1 = 0.0;
+  if (tid < 6) live[tid / 3][tid % 3] = 0;
+  f32x2 wcr[4];                                              // window times chirp of this thread's four samples
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) wcr[n1] = P * n1 + tid < n ? wc[P * n1 + tid] : f32x2{0.f, 0.f};
+  float na[4], nq[4];                                        // the NEXT frame's samples: in flight during this frame's transforms
+  auto fetch = [&](int f) {
+    const float* pt = xt + (long)b * ld + (long)f * hop;
+    const float* pp = xp + (long)b * ld + (long)f * hop;
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      const int j = P * n1 + tid;
+      const int jj = j < n ? j : 0;
+      na[n1] = pt[jj];
+      nq[n1] = pp[jj];
+    }
+  };
+  if (f_lo < f_hi) fetch(f_lo);
+  __syncthreads();
+  for (int f = f_lo; f < f_hi; ++f) {
+    f32x2 v[8], co[4];
+    bool any_t = false, any_p = false, differ = false;
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      const float a = na[n1], q = nq[n1];
+      const f32x2 w = wcr[n1];                               // 0 behind the frame's end
+      v[n1] = f32x2{a * w.x - q * w.y, a * w.y + q * w.x};
+      any_t |= a * w.x != 0.f || a * w.y != 0.f;             // the WINDOWED sample: hann[0] = 0
+      any_p |= q * w.x != 0.f || q * w.y != 0.f;
+      differ |= P * n1 + tid < n && a != q;
+    }
+    if (f + 1 < f_hi) fetch(f + 1);
+    // The two signals share one transform, so each spectrum carries the other's rounding noise (1e-7 of ITS size).  A
+    // frame that is all zero behind the window -- digital silence -- must come out as exact zeros (S = eps, and a zero gradient at the origin, as
+    // the separate transforms of the reference give): such frames are flagged here and zeroed behind the split.  Likewise
+    // two EQUAL frames must give equal spectra (loss 0 for identical signals), which the two halves of the split do not.
+    if (any_t) live[f & 1][0] = 1;
+    if (any_p) live[f & 1][1] = 1;
+    if (differ) live[f & 1][2] = 1;
+    if (tid < 3) live[(f + 1) & 1][tid] = 0;                 // next frame's flags; its writers are barriers away
+    czt_convolve<R>(v, tw, bh, ch, co, ex[0], ex[1], tid, [] {});
+    const float keep_t = live[f & 1][0] ? 1.f : 0.f, keep_p = live[f & 1][1] ? 1.f : 0.f;
+    const bool same = !live[f & 1][2];
+    f32x2 z[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = P * m + tid;
+      if (k < n) {
+        const f32x2 zz = cmul(cconj(v[m]), co[m]) * scale;   // Z[k] / 2
+        ex[1][k] = zz;
+        if (m < 3) z[m] = zz;
+      }
+    }
+    __syncthreads();
+    float fd = 0.f, fs = 0.f, fl = 0.f;
+    const long row = ((long)b * frames + f) * bins;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {                            // n <= N / 2, so the bins 0 .. n/2 lie in the slots 0 .. 2
+      const int k = P * m + tid;
+      if (k < bins) {
+        const f32x2 zk = z[m], zm = ex[1][k == 0 ? 0 : n - k];
+        const f32x2 Xt = f32x2{zk.x + zm.x, zk.y - zm.y} * keep_t;      // (Z[k] + conj Z[n-k]) / 2
+        const f32x2 Xp = same ? Xt : f32x2{zk.y + zm.y, zm.x - zk.x} * keep_p;      // (Z[k] - conj Z[n-k]) / 2i
+        spec_t[row + k] = float2{Xt.x, Xt.y};
+        spec_p[row + k] = float2{Xp.x, Xp.y};
+        const float st = fmaf(cz_mag(Xt), inv_wn, eps), sp = fmaf(cz_mag(Xp), inv_wn, eps);
+        const float d = st - sp, s = st + sp;
+        fd += d * d;
+        fs += s * s;
+        fl += fabsf(cz_log(st) - cz_log(sp));
+      }
+    }
+    d2 += (double)fd; s2 += (double)fs; l1 += (double)fl;
+  }
+  d2 = wave_sum(d2); s2 = wave_sum(s2); l1 = wave_sum(l1);
+  if (lane == 0) { red[0][wave] = d2; red[1][wave] = s2; red[2][wave] = l1; }
+  __syncthreads();
+  if (tid < 3) {
+    double v = 0.0;
+    for (int w = 0; w < R; ++w) v += red[tid][w];
+    partial[((long)b * chunks + c) * 3 + tid] = v;
+  }
+}
+
+// The gradient of the loss with respect to one complex bin (k_sss_grad of loss.hip).
+template <int WRT_TRUE>
+__device__ __forceinline__ f32x2 cz_bin_grad(float2 zt, float2 zp, float k1, float k2, float kl, float go, float inv_wn,
+                                             float eps) {
+  const f32x2 a{zt.x, zt.y}, p{zp.x, zp.y};
+  const float at = cz_mag(a), ap = cz_mag(p);
+  const float st = fmaf(at, inv_wn, eps), sp = fmaf(ap, inv_wn, eps);
+  const float d = st - sp, s = st + sp;
+  const float l = cz_log(st) - cz_log(sp);
+  const float sg = l > 0.f ? 1.f : (l < 0.f ? -1.f : 0.f);
+  float g, m;
+  f32x2 z;
+  if (WRT_TRUE) { g = k1 * d - k2 * s + kl * sg / st; z = a; m = at; }
+  else          { g = -k1 * d - k2 * s - kl * sg / sp; z = p; m = ap; }
+  const float r = m > 0.f ? go * g * inv_wn / m : 0.f;
+  return z * r;
+}
+
+template <int R, int WRT_TRUE>
+__global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restrict__ spec_t, const float2* __restrict__ spec_p,
+                                                        int n, int frames, int chunks, const float2* __restrict__ tab,
+                                                        const float* __restrict__ norms, float inv_wn, float eps,
+                                                        float alpha, float inv_B, float inv_n,
+                                                        const float* __restrict__ grad_out, float* __restrict__ dx,
+                                                        long ld_dx, int T, int accumulate) {
+  using PL = fft::Plan<R>;
+  constexpr int N = PL::N, P = PL::P;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int bins = n / 2 + 1;
+  const int pairs = (frames + 1) / 2;
+  const int span = (pairs + chunks - 1) / chunks;
+  const int p_lo = c * span;
+  const int p_hi = p_lo + span < pairs ? p_lo + span : pairs;
+  const f32x2* ch = reinterpret_cast<const f32x2*>(tab);
+  const f32x2* wc = ch + n;
+  const f32x2* bh = ch + 2 * n;
+  typename PL::Tw tw;
+  tw.init(tid);
+  const float go = grad_out[0];
+  const float nd = norms[2 * b], ns = norms[2 * b + 1];
+  const float k1 = nd > 0.f ? inv_B / (nd * ns) : 0.f;
+  const float k2 = inv_B * nd / (ns * ns * ns);
+  const float kl = alpha * inv_n;
+  const float scale = 1.0f / (float)N;
+  float* o = dx + (long)b * ld_dx;
+  // One pair of frames per pass.  The NEXT pair's bins are fetched between the two transforms of this pair and turned into
+  // its input (gradient of the bins, Hermitian extension, chirp) behind them, so neither the loads' latency nor 64 registers
+  // of raw bins sit on the transforms.
+  float2 rt0[4], rp0[4], rt1[4], rp1[4];
+  auto fetch = [&](int pi) {
+    const int f0 = 2 * pi;
+    const float2* t0 = spec_t + ((long)b * frames + f0) * bins;
+    const float2* q0 = spec_p + ((long)b * frames + f0) * bins;
+    const long next = f0 + 1 < frames ? bins : 0;
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      const int k = P * n1 + tid;
+      const int kk = k >= n ? 0 : (k < bins ? k : n - k);
+      rt0[n1] = t0[kk]; rp0[n1] = q0[kk];
+      rt1[n1] = t0[next + kk]; rp1[n1] = q0[next + kk];
+    }
+  };
+  f32x2 chr[4];                                              // chirp of this thread's four bins
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) chr[n1] = P * n1 + tid < n ? ch[P * n1 + tid] : f32x2{0.f, 0.f};
+  f32x2 vn[4];
+  auto prepare = [&](int pi) {
+    const bool two = 2 * pi + 1 < frames;
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      const int k = P * n1 + tid;
+      const int kk = k >= n ? 0 : (k < bins ? k : n - k);
+      const f32x2 g0 = cz_bin_grad<WRT_TRUE>(rt0[n1], rp0[n1], k1, k2, kl, go, inv_wn, eps);
+      f32x2 g1 = cz_bin_grad<WRT_TRUE>(rt1[n1], rp1[n1], k1, k2, kl, go, inv_wn, eps);
+      if (!two) g1 = f32x2{0.f, 0.f};
+      // Hermitian extension: the real part of the one-sided sum as a full inverse transform
+      const bool edge = kk == 0 || 2 * kk == n;
+      const float hr = edge ? 1.f : 0.5f;
+      const float hi = edge ? 0.f : (k < bins ? 0.5f : -0.5f);
+      const f32x2 a0{g0.x * hr, g0.y * hi}, a1{g1.x * hr, g1.y * hi};
+      const f32x2 gc{a0.x - a1.y, a0.y + a1.x};              // frame f0 + i frame f0+1
+      vn[n1] = cmul(cconj(gc), chr[n1]);                     // chr = 0 behind the last bin
+    }
+  };
+  if (p_lo < p_hi) { fetch(p_lo); prepare(p_lo); }
+  for (int pi = p_lo; pi < p_hi; ++pi) {
+    const int f0 = 2 * pi;
+    const bool two = f0 + 1 < frames;
+    f32x2 v[8], co[4];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) v[n1] = vn[n1];
+    float old0[4], old1[4];
+    czt_convolve<R>(v, tw, bh, wc, co, ex[0], ex[1], tid, [&] {
+      if (pi + 1 < p_hi) fetch(pi + 1);
+      if (accumulate) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int j = P * m + tid;
+          const int jj = j < n ? j : 0;
+          old0[m] = o[(long)f0 * n + jj];
+          old1[m] = o[(long)(two ? f0 + 1 : f0) * n + jj];
+        }
+      }
+    });
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int j = P * m + tid;
+      if (j < n) {
+        const f32x2 dj = cmul(cconj(v[m]), co[m]) * scale;   // w[j] D[j]; the inverse transform is its conjugate
+        o[(long)f0 * n + j] = accumulate ? old0[m] + dj.x : dj.x;
+        if (two) o[(long)(f0 + 1) * n + j] = accumulate ? old1[m] - dj.y : -dj.y;
+      }
+    }
+    if (pi + 1 < p_hi) prepare(pi + 1);
+    __syncthreads();                                         // pass 4 of the last transform still reads ex[0]
+  }
+  if (c == chunks - 1 && !accumulate)                        // samples behind the last whole frame do not reach the loss
+    for (long i = (long)frames * n + tid; i < T; i += P) o[i] = 0.f;
+}
+
+int sss_wave_chunks(int B, int n, int frames, int per_item) {
+  const int R = czt_plan(n);
+  const int resident = 2 * 256 * (8 / (R ? R : 8));                  // two rounds of what the chip holds at 2 waves per SIMD
+  const int items = (frames + per_item - 1) / per_item;
+  int c = (resident + B - 1) / B;
+  if (c > items) c = items;
+  if (c < 1) c = 1;
+  return c;
+}
+
+size_t sss_wave_scratch_bytes(int B, int n, int frames) {
+  return (size_t)B * sss_wave_chunks(B, n, frames, 1) * 3 * sizeof(double);
+}
+
+int launch_czt_tables(int n, float* tab, hipStream_t st) {
+  const int R = czt_plan(n);
+  if (!R) return -1;
+  const int N = 512 * R;
+  hipLaunchKernelGGL(k_czt_tables, dim3((unsigned)(N + (n + CZ_TAB_THREADS - 1) / CZ_TAB_THREADS)), dim3(CZ_TAB_THREADS),
+                     0, st, n, N, reinterpret_cast<float2*>(tab));
+  return 0;
+}
+
+int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int hop, int frames, const float* tab,
+                    float inv_wn, float eps, float alpha, double* scratch, float* spec_t, float* spec_p, float* norms,
+                    float* loss, hipStream_t st) {
+  const int R = czt_plan(n);
+  if (!R || B < 1 || B > 65535 || frames < 1 || hop < 1) return -1;
+  const int chunks = sss_wave_chunks(B, n, frames, 1);
+  const dim3 grid((unsigned)chunks, (unsigned)B);
+  const float2* tb = reinterpret_cast<const float2*>(tab);
+  float2* s_t = reinterpret_cast<float2*>(spec_t);
+  float2* s_p = reinterpret_cast<float2*>(spec_p);
+  if (R == 2)
+    hipLaunchKernelGGL(k_sss_czt<2>, grid, dim3(128), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+                       scratch);
+  else if (R == 4)
+    hipLaunchKernelGGL(k_sss_czt<4>, grid, dim3(256), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+                       scratch);
+  else
+    hipLaunchKernelGGL(k_sss_czt<8>, grid, dim3(512), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+                       scratch);
+  const long per_utt = (long)frames * (n / 2 + 1);
+  launch_sss_final(scratch, B, chunks, per_utt, alpha, norms, loss, st);
+  return 0;
+}
+
+template <int R>
+static void launch_bwd_r(dim3 grid, hipStream_t st, int wrt_true, const float2* s_t, const float2* s_p, int n, int frames,
+                         int chunks, const float2* tb, const float* norms, float inv_wn, float eps, float alpha, float inv_B,
+                         float inv_n, const float* grad_out, float* dx, long ld_dx, int T, int accumulate) {
+  if (wrt_true)
+    hipLaunchKernelGGL((k_sss_czt_bwd<R, 1>), grid, dim3(64 * R), 0, st, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps,
+                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate);
+  else
+    hipLaunchKernelGGL((k_sss_czt_bwd<R, 0>), grid, dim3(64 * R), 0, st, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps,
+                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate);
+}
+
+int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int frames, const float* tab,
+                        const float* norms, float inv_wn, float eps, float alpha, const float* grad_out, int wrt_true,
+                        float* dx, long ld_dx, int accumulate, hipStream_t st) {
+  const int R = czt_plan(n);
+  if (!R || B < 1 || B > 65535 || frames < 1 || (long)frames * n > T) return -1;
+  const int chunks = sss_wave_chunks(B, n, frames, 2);
+  const dim3 grid((unsigned)chunks, (unsigned)B);
+  const float2* tb = reinterpret_cast<const float2*>(tab);
+  const float2* s_t = reinterpret_cast<const float2*>(spec_t);
+  const float2* s_p = reinterpret_cast<const float2*>(spec_p);
+  const float inv_B = 1.0f / (float)B;
+  const float inv_n = (float)(1.0 / ((double)B * (double)frames * (double)(n / 2 + 1)));
+  if (R == 2)
+    launch_bwd_r<2>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
+                    dx, ld_dx, T, accumulate);
+  else if (R == 4)
+    launch_bwd_r<4>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
+                    dx, ld_dx, T, accumulate);
+  else
+    launch_bwd_r<8>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
+                    dx, ld_dx, T, accumulate);
+  return 0;
+}
+
+}  // namespace ddsp

@@ -2,11 +2,14 @@
 same constructors, same ``forward`` argument order (``SSSLoss(x_true, x_pred)``, ``RSSLoss(x_pred, x_true)``), same
 random draw of the transform sizes (``torch.randint``, :47).
 
-``RSSLoss`` draws arbitrary integer transform sizes, so the STFT itself stays with ``torch.stft`` (rocFFT; plumbing).
-Everything behind it -- magnitudes, the window normalisation and eps of ``Spectrogram(power=1, normalized=True)``, the
-two Frobenius norms per utterance, the log-L1 term, and in the backward pass the whole chain down to the gradient of
-the complex spectrum -- is one pass of csrc/loss.hip over the two spectra instead of ~10 eager kernels over
-``[B, bins, frames]`` temporaries."""
+``RSSLoss`` draws arbitrary integer transform sizes, most of them with large prime factors.  With ``overlap = 0`` (the
+default, and what ``train.py`` uses) the whole loss runs in csrc/loss_czt.hip straight from the two waveforms: one
+chirp-z transform per frame carries both signals, the magnitudes and reductions follow in registers, and the backward
+pass is one more transform per two frames (``_WaveLossFunction``).  With overlapping frames the STFT stays with
+``torch.stft`` (rocFFT; plumbing) and everything behind it -- magnitudes, the window normalisation and eps of
+``Spectrogram(power=1, normalized=True)``, the two Frobenius norms per utterance, the log-L1 term, and in the backward
+pass the whole chain down to the gradient of the complex spectrum -- is one pass of csrc/loss.hip over the two spectra
+instead of ~10 eager kernels over ``[B, bins, frames]`` temporaries (``_SpectralLossFunction``)."""
 import torch
 
 from . import _ffi
@@ -70,6 +73,118 @@ class _SpectralLossFunction(torch.autograd.Function):
         return grads[0], grads[1], None, None, None
 
 
+_CZT_TABLES = {}                       # (device, stream, n_fft) -> chirps and filter spectrum of csrc/loss_czt.hip
+
+
+def _czt_tables(n_fft, like):
+    """The tables of one transform size on ``like``'s device, filled on first use (on the current stream, which is part
+    of the key: a second stream gets its own copy rather than a race with the fill).  None: size not supported."""
+    key = (str(like.device), _ffi.stream_of(like), int(n_fft))
+    t = _CZT_TABLES.get(key)
+    if t is None:
+        lib = _ffi.lib()
+        nbytes = lib.ddsp_hip_stft_loss_table_bytes(int(n_fft))
+        if nbytes == 0:
+            return None
+        t = torch.empty(nbytes // 4, dtype=torch.float32, device=like.device)
+        _ffi.check(lib.ddsp_hip_stft_loss_tables(int(n_fft), ptr(t), _ffi.stream_of(like)))
+        _CZT_TABLES[key] = t
+    return t
+
+
+class _WaveLossFunction(torch.autograd.Function):
+    """loss.py:22-31 INCLUDING the two spectrograms, for hop == n_fft (csrc/loss_czt.hip)."""
+
+    @staticmethod
+    def forward(ctx, x_true, x_pred, n_fft, inv_window_norm, eps, alpha, tables):
+        _ffi.check_device(x_true, x_pred)
+        xt, xp = x_true.detach(), x_pred.detach()
+        if xt.stride(1) != 1 or xp.stride(1) != 1 or xt.stride(0) != xp.stride(0):
+            xt, xp = xt.contiguous(), xp.contiguous()
+        B, T = xt.shape
+        lib = _ffi.lib()
+        dev = xt.device
+        frames = lib.ddsp_hip_stft_loss_frames(T, n_fft, n_fft)
+        spec = torch.empty(2, B, frames, n_fft // 2 + 1, dtype=torch.complex64, device=dev)
+        nbytes = lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n_fft, n_fft)
+        scratch = torch.empty(max(nbytes, 8) // 8, dtype=torch.float64, device=dev)
+        norms = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n_fft, n_fft, ptr(tables),
+                                          float(inv_window_norm), float(eps), float(alpha), ptr(scratch), nbytes,
+                                          ptr(spec[0]), ptr(spec[1]), ptr(norms), ptr(loss), _ffi.stream_of(xt)))
+        ctx.save_for_backward(spec, norms, tables)
+        ctx.cfg = (B, T, int(n_fft), float(inv_window_norm), float(eps), float(alpha))
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        spec, norms, tables = ctx.saved_tensors
+        B, T, n_fft, inv_wn, eps, alpha = ctx.cfg
+        go = grad_out.detach().to(torch.float32).contiguous()
+        lib = _ffi.lib()
+        grads = [None, None]
+        for which in (0, 1):                                         # 0: true, 1: pred
+            if not ctx.needs_input_grad[which]:
+                continue
+            d = torch.empty(B, T, dtype=torch.float32, device=spec.device)
+            _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tables), ptr(norms),
+                                                       inv_wn, eps, alpha, ptr(go), 1 if which == 0 else 0, ptr(d), T, 0,
+                                                       _ffi.stream_of(spec)))
+            grads[which] = d
+        return grads[0], grads[1], None, None, None, None, None
+
+
+class _RandomScaleWaveLossFunction(torch.autograd.Function):
+    """RSSLoss.forward (loss.py:46-54) for non-overlapping frames as ONE autograd node: the scales' kernels back to back,
+    their losses averaged on the device, and in the backward pass each scale's kernel adding into the one gradient
+    buffer -- instead of n_scale nodes, n_scale [B, T] temporaries and the adds between them."""
+
+    @staticmethod
+    def forward(ctx, x_true, x_pred, scales, eps, alpha, *tables):
+        _ffi.check_device(x_true, x_pred)
+        xt, xp = x_true.detach(), x_pred.detach()
+        if xt.stride(1) != 1 or xp.stride(1) != 1 or xt.stride(0) != xp.stride(0):
+            xt, xp = xt.contiguous(), xp.contiguous()
+        B, T = xt.shape
+        lib = _ffi.lib()
+        dev = xt.device
+        losses = torch.empty(len(scales), dtype=torch.float32, device=dev)
+        norms = torch.empty(len(scales), B, 2, dtype=torch.float32, device=dev)
+        nbytes = max(lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n, n) for n, _ in scales)
+        scratch = torch.empty(max(nbytes, 8) // 8, dtype=torch.float64, device=dev)   # the scales run in stream order
+        specs = []
+        for i, ((n, inv_wn), tab) in enumerate(zip(scales, tables)):
+            frames = lib.ddsp_hip_stft_loss_frames(T, n, n)
+            spec = torch.empty(2, B, frames, n // 2 + 1, dtype=torch.complex64, device=dev)
+            _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n, n, ptr(tab), inv_wn, float(eps),
+                                              float(alpha), ptr(scratch), nbytes, ptr(spec[0]), ptr(spec[1]),
+                                              ptr(norms[i]), ptr(losses[i:]), _ffi.stream_of(xt)))
+            specs.append(spec)
+        ctx.save_for_backward(norms, *specs, *tables)
+        ctx.cfg = (B, T, tuple(scales), float(eps), float(alpha))
+        return losses.sum() / len(scales)                             # loss.py:48-54: the sum over the scales / n_scale
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, T, scales, eps, alpha = ctx.cfg
+        k = len(scales)
+        norms, specs, tables = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:]
+        go = (grad_out.detach().to(torch.float32) / k).contiguous()
+        lib = _ffi.lib()
+        grads = [None, None]
+        for which in (0, 1):                                         # 0: true, 1: pred
+            if not ctx.needs_input_grad[which]:
+                continue
+            d = torch.empty(B, T, dtype=torch.float32, device=norms.device)
+            for i, ((n, inv_wn), spec, tab) in enumerate(zip(scales, specs, tables)):
+                _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n, ptr(tab), ptr(norms[i]),
+                                                           inv_wn, eps, alpha, ptr(go), 1 if which == 0 else 0, ptr(d), T,
+                                                           1 if i else 0, _ffi.stream_of(norms)))
+            grads[which] = d
+        return (grads[0], grads[1], None, None, None) + (None,) * k
+
+
 class Spectrogram(torch.nn.Module):
     """``torchaudio.transforms.Spectrogram(n_fft, hop_length=, power=None, center=False)`` as SSSLoss configures it
     (loss.py:20), returning the COMPLEX spectrum: the ``power=1`` magnitude and the ``normalized=True`` division by
@@ -79,11 +194,9 @@ class Spectrogram(torch.nn.Module):
         super().__init__()
         self.n_fft = int(n_fft)
         self.hop_length = int(hop_length)
-        self.register_buffer("window", torch.hann_window(self.n_fft))      # periodic Hann, torchaudio's default
-
-    @property
-    def inv_window_norm(self):
-        return 1.0 / float(self.window.double().pow(2).sum().sqrt())
+        window = torch.hann_window(self.n_fft)                              # periodic Hann, torchaudio's default
+        self.register_buffer("window", window)
+        self.inv_window_norm = 1.0 / float(window.double().pow(2).sum().sqrt())     # a host float: no device sync per call
 
     def forward(self, x):
         x = x.reshape(-1, x.shape[-1])
@@ -116,6 +229,12 @@ class SSSLoss(torch.nn.Module):
             raise ValueError("x_true and x_pred must have the same shape")
         x_true = x_true.reshape(-1, x_true.shape[-1]) if x_true.dim() != 2 else x_true
         x_pred = x_pred.reshape(-1, x_pred.shape[-1]) if x_pred.dim() != 2 else x_pred
+        if self.hop_length == self.n_fft and x_true.shape[-1] >= self.n_fft and x_true.shape[-1] < 2 ** 31 \
+                and not _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT"):
+            tables = _czt_tables(self.n_fft, x_pred)
+            if tables is not None:
+                return _WaveLossFunction.apply(x_true.to(torch.float32), x_pred.to(torch.float32), self.n_fft,
+                                               self.spec.inv_window_norm, self.eps, self.alpha, tables)
         return _SpectralLossFunction.apply(self.spec(x_true.to(torch.float32)), self.spec(x_pred.to(torch.float32)),
                                            self.spec.inv_window_norm, self.eps, self.alpha)
 
@@ -139,9 +258,31 @@ class RSSLoss(torch.nn.Module):
             f = self.lossdict[n_fft] = SSSLoss(n_fft, self.alpha, self.overlap, self.eps).to(device)
         return f
 
+    def _fused(self, x_pred, x_true, sizes):
+        """All scales in one autograd node when every one of them takes the in-kernel transform (overlap 0, sizes the
+        chirp-z plans cover, signals of at least one frame); None otherwise."""
+        if int(max(sizes) * (1 - self.overlap)) != max(sizes) or int(min(sizes) * (1 - self.overlap)) != min(sizes):
+            return None
+        if _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT") or x_true.shape != x_pred.shape:
+            return None
+        T = x_true.shape[-1]
+        if T < max(sizes) or T >= 2 ** 31 or len(sizes) == 0:
+            return None
+        _ffi.check_device(x_true, x_pred)
+        xt = x_true.reshape(-1, T).to(torch.float32)
+        xp = x_pred.reshape(-1, T).to(torch.float32)
+        tables = [_czt_tables(n, xp) for n in sizes]
+        if any(t is None for t in tables):
+            return None
+        scales = tuple((n, self._scale(n, xp.device).spec.inv_window_norm) for n in sizes)
+        return _RandomScaleWaveLossFunction.apply(xt, xp, scales, self.eps, self.alpha, *tables)
+
     def forward(self, x_pred, x_true):
         value = 0.
         n_ffts = torch.randint(self.fft_min, self.fft_max, (self.n_scale,))      # loss.py:47, CPU generator
+        fused = self._fused(x_pred, x_true, [int(n) for n in n_ffts])
+        if fused is not None:
+            return fused
         for n_fft in n_ffts:
             value = value + self._scale(int(n_fft), x_pred.device)(x_true, x_pred)
         return value / self.n_scale

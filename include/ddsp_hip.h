@@ -300,6 +300,30 @@ int ddsp_hip_spectral_loss_backward(const float* spec_true, const float* spec_pr
                                     const float* norms, float inv_window_norm, float eps, float alpha,
                                     const float* grad_out, int wrt_true, float* d_spec, void* stream);
 
+/* The same loss straight from the waveforms, the STFT of Spectrogram(n_fft, hop_length = hop, power = 1,
+ * normalized = True, center = False) (loss.py:20) inside the kernel: a chirp-z transform of ANY size
+ * 2 <= n_fft <= 2048 (RSSLoss draws them at random, loss.py:47; most have large prime factors), both signals in one
+ * complex transform.  tables: ddsp_hip_stft_loss_table_bytes(n_fft) bytes (0: size not supported), filled once per
+ * size and device by ddsp_hip_stft_loss_tables.  x_true / x_pred: [B, T] float32 with row stride ld; frames =
+ * ddsp_hip_stft_loss_frames(T, n_fft, hop) = 1 + (T - n_fft) / hop (0: signal shorter than one frame).  spec_true /
+ * spec_pred receive the complex spectra as [B, frames, n_fft / 2 + 1] (interleaved; the backward call reads them),
+ * norms[B][2] and loss[0] as ddsp_hip_spectral_loss.  inv_window_norm = 1 / ||hann(n_fft)||_2. */
+size_t ddsp_hip_stft_loss_table_bytes(int n_fft);
+int ddsp_hip_stft_loss_tables(int n_fft, float* tables, void* stream);
+int ddsp_hip_stft_loss_frames(int T, int n_fft, int hop);
+size_t ddsp_hip_stft_loss_scratch_bytes(int B, int T, int n_fft, int hop);
+int ddsp_hip_stft_loss(const float* x_true, const float* x_pred, int B, int T, long ld, int n_fft, int hop,
+                       const float* tables, float inv_window_norm, float eps, float alpha, void* scratch,
+                       size_t scratch_bytes, float* spec_true, float* spec_pred, float* norms, float* loss, void* stream);
+/* d loss / d x_pred (wrt_true = 0) or d x_true (1) for hop == n_fft (the frames do not overlap: overlap = 0, the
+ * configuration of RSSLoss, loss.py:40), times grad_out[0]: d_x[B, T] with row stride ld_dx, every sample written (those
+ * behind the last whole frame with 0); accumulate != 0: added to what d_x holds instead (the scales of RSSLoss summed
+ * without a temporary each). */
+int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft,
+                                const float* tables, const float* norms, float inv_window_norm, float eps, float alpha,
+                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,7 @@ static inline void sincospif(float x, float* s, float* c) { *s = (float)sin(M_PI
 static inline float sinpif(float x) { return (float)sin(M_PI * (double)x); }
 static inline float cospif(float x) { return (float)cos(M_PI * (double)x); }
 static inline double sinpi(double x) { return sin(M_PI * x); }
+static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 static inline double cospi(double x) { return cos(M_PI * x); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __float2int_rn(float x) { return (int)rintf(x); }

@@ -113,18 +113,92 @@ def test_loss_edge_cases(dev):
         f(x[:, :100], x[:, :100])
 
 
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("n_fft", [2, 97, 512, 513, 1024, 1153, 2048])
+def test_in_kernel_transform_parts(dev, n_fft):
+    """csrc/loss_czt.hip on its own, through the C ABI: the chirp-z spectra of both signals against numpy's float64 rfft
+    (every plan: 1024 / 2048 / 4096 points, at its edges), frames that are silent or equal, the backward transform against
+    the float64 adjoint of the same bin gradients, the accumulate switch and the zeroed tail."""
+    from ddsp_svc_amd import loss as L, _ffi
+    from ddsp_svc_amd._ffi import ptr
+    lib = _ffi.lib()
+    B, frames = 2, 5
+    T = frames * n_fft + min(3, n_fft - 1)
+    rng = np.random.default_rng(n_fft)
+    a = (rng.standard_normal((B, T)) * 0.1).astype(np.float32)
+    b = (a * 0.7 + rng.standard_normal((B, T)) * 0.05).astype(np.float32)
+    a[0, n_fft:2 * n_fft] = 0.0                                           # a silent frame of the truth
+    b[1, 2 * n_fft:3 * n_fft] = 0.0                                       # ... of the prediction
+    b[1, 3 * n_fft:4 * n_fft] = a[1, 3 * n_fft:4 * n_fft]                 # an equal pair of frames
+    xt, xp = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    f = L.SSSLoss(n_fft)
+    tab = L._czt_tables(n_fft, xt)
+    assert tab is not None and tab.numel() * 4 == lib.ddsp_hip_stft_loss_table_bytes(n_fft)
+    bins = n_fft // 2 + 1
+    assert lib.ddsp_hip_stft_loss_frames(T, n_fft, n_fft) == frames
+    spec = torch.empty(2, B, frames, bins, dtype=torch.complex64, device=dev)
+    nb = lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n_fft, n_fft)
+    scratch = torch.empty(max(nb, 8) // 8, dtype=torch.float64, device=dev)
+    norms, lo = torch.empty(B, 2, device=dev), torch.empty((), device=dev)
+    inv = f.spec.inv_window_norm
+    _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, T, n_fft, n_fft, ptr(tab), inv, 1e-7, 1.0, ptr(scratch), nb,
+                                      ptr(spec[0]), ptr(spec[1]), ptr(norms), ptr(lo), _ffi.stream_of(xt)))
+    w = torch.hann_window(n_fft, dtype=torch.float64).numpy()
+    X64 = lambda x: np.fft.rfft(x[:, :frames * n_fft].reshape(B, frames, n_fft).astype(np.float64) * w, axis=-1)
+    got_t, got_p = spec[0].cpu().numpy(), spec[1].cpu().numpy()
+    for got, x in ((got_t, a), (got_p, b)):
+        want = X64(x)
+        assert np.abs(got - want).max() <= 5e-7 * np.abs(want).max()
+    assert not got_t[0, 1].any() and not got_p[1, 2].any()                # silence is exact
+    assert np.array_equal(got_t[1, 3], got_p[1, 3])                       # equal frames, equal spectra
+    St, Sp = np.abs(X64(a)) * inv + 1e-7, np.abs(X64(b)) * inv + 1e-7
+    want = np.mean(np.linalg.norm((St - Sp).reshape(B, -1), axis=1) / np.linalg.norm((St + Sp).reshape(B, -1), axis=1)) \
+        + np.mean(np.abs(np.log(St) - np.log(Sp)))
+    assert abs(float(lo) - want) <= 2e-5 * want
+    go = torch.full((), 0.5, device=dev)
+    for wrt_true in (0, 1):
+        G = torch.empty_like(spec[1])
+        _ffi.check(lib.ddsp_hip_spectral_loss_backward(ptr(spec[0]), ptr(spec[1]), B, frames * bins, ptr(norms), inv, 1e-7,
+                                                       1.0, ptr(go), wrt_true, ptr(G), _ffi.stream_of(xt)))
+        xx = torch.from_numpy(a if wrt_true else b).double().requires_grad_(True)
+        Xr = torch.fft.rfft(xx[:, :frames * n_fft].reshape(B, frames, n_fft) * torch.from_numpy(w), dim=-1)
+        Xr.backward(G.cpu().to(torch.complex128))
+        d = torch.full((B, T), 7.0, device=dev)
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), wrt_true, ptr(d), T, 0, _ffi.stream_of(xt)))
+        ref = xx.grad.numpy()
+        assert _rel_rms(d.cpu().numpy(), ref) <= 1e-6
+        assert not d.cpu().numpy()[:, frames * n_fft:].any()              # the tail is written, with zeros
+        d2 = d.clone()
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), wrt_true, ptr(d2), T, 1, _ffi.stream_of(xt)))
+        assert torch.equal(d2, d + d)
+    assert lib.ddsp_hip_stft_loss_table_bytes(2049) == 0 and lib.ddsp_hip_stft_loss_table_bytes(1) == 0
+
+
 @pytest.mark.gpu
 def test_full_size_against_eager_composition():
-    """B = 32 x 10 s, the sizes RSSLoss draws from (256 .. 2047): the fused kernels against the eager float32
-    composition of loss.py:22-31 on the same device."""
-    from ddsp_svc_amd import loss as L
+    """B = 32 x 10 s, sizes RSSLoss draws from (256 .. 2047; 397, 1153 and 2047 = 23 * 89 with large prime factors): the
+    in-kernel chirp-z STFT and its loss against float64 / eager float32 compositions of loss.py:22-31 on the same device.
+
+    The loss's gradient is DISCONTINUOUS where S_true = S_pred (the sign of the log difference, times 1 / S_pred): bins
+    within float32 rounding of that flip between any two float32 transforms (rocFFT against this one, or against itself
+    on another architecture), and one flipped bin moves a whole frame's gradient.  So the gradient is checked in parts
+    that are well conditioned -- the spectra against float64, the backward transform against the float64 adjoint of the
+    SAME bin gradients -- and against the eager composition per frame: the median frame tightly, the flipped ones by
+    count."""
+    from ddsp_svc_amd import loss as L, _ffi
+    from ddsp_svc_amd._ffi import ptr
     dev = torch.device("cuda:0")
+    lib = _ffi.lib()
     g = torch.Generator(device="cpu").manual_seed(5)
-    xt = (torch.randn(32, 441344, generator=g) * 0.1).to(dev)
-    xp = (xt * 0.9 + 0.02 * torch.randn(32, 441344, generator=g).to(dev)).requires_grad_(True)
-    for n_fft in (256, 1153, 2047):
+    B, T = 32, 441344
+    xt = (torch.randn(B, T, generator=g) * 0.1).to(dev)
+    xp = (xt * 0.9 + 0.02 * torch.randn(B, T, generator=g).to(dev)).requires_grad_(True)
+    for n_fft in (256, 397, 1153, 2047):
         f = L.SSSLoss(n_fft).to(dev)
         loss = f(xt, xp)
+        assert loss.grad_fn is not None and "WaveLoss" in type(loss.grad_fn).__name__
         grad, = torch.autograd.grad(loss, xp)
         w = f.spec.window
         sp = lambda x: torch.stft(x, n_fft, hop_length=n_fft, win_length=n_fft, window=w, center=False,
@@ -134,4 +208,62 @@ def test_full_size_against_eager_composition():
             + torch.nn.functional.l1_loss(St.log(), Sp.log())
         rgrad, = torch.autograd.grad(ref, xp)
         assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * float(ref.detach())
-        assert float((grad - rgrad).pow(2).mean().sqrt() / rgrad.pow(2).mean().sqrt()) <= 1e-4
+        frames, bins = T // n_fft, n_fft // 2 + 1
+        per_frame = lambda x: x[:, :frames * n_fft].reshape(B * frames, n_fft)
+        err = (per_frame(grad) - per_frame(rgrad)).pow(2).mean(1).sqrt() / per_frame(rgrad).pow(2).mean(1).sqrt()
+        assert float(err.median()) <= 2e-5
+        assert float((err > 1e-3).float().mean()) <= 2e-3            # frames holding a flipped bin
+        assert float(grad[:, frames * n_fft:].abs().max()) == 0.0 if frames * n_fft < T else True
+        # the parts
+        tab = L._czt_tables(n_fft, xt)
+        spec = torch.empty(2, B, frames, bins, dtype=torch.complex64, device=dev)
+        nb = lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n_fft, n_fft)
+        scratch = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+        norms, lo = torch.empty(B, 2, device=dev), torch.empty((), device=dev)
+        inv = f.spec.inv_window_norm
+        _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp.detach()), B, T, T, n_fft, n_fft, ptr(tab), inv, 1e-7, 1.0,
+                                          ptr(scratch), nb, ptr(spec[0]), ptr(spec[1]), ptr(norms), ptr(lo),
+                                          _ffi.stream_of(xt)))
+        X64 = lambda x: torch.fft.rfft(x.double()[:, :frames * n_fft].reshape(B, frames, n_fft) * w.double(), dim=-1)
+        for got, x in ((spec[0], xt), (spec[1], xp.detach())):
+            want = X64(x)
+            assert float((got - want).abs().max() / want.abs().max()) <= 5e-7
+        go = torch.ones((), device=dev)
+        G = torch.empty_like(spec[1])
+        _ffi.check(lib.ddsp_hip_spectral_loss_backward(ptr(spec[0]), ptr(spec[1]), B, frames * bins, ptr(norms), inv, 1e-7,
+                                                       1.0, ptr(go), 0, ptr(G), _ffi.stream_of(xt)))
+        xx = xp.detach().double().requires_grad_(True)
+        X64(xx).backward(G.to(torch.complex128))
+        d = torch.empty(B, T, device=dev)
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), 0, ptr(d), T, 0, _ffi.stream_of(xt)))
+        assert float((d - xx.grad).pow(2).mean().sqrt() / xx.grad.pow(2).mean().sqrt()) <= 1e-6
+        d2 = d.clone()                                                  # accumulate: exactly twice
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), 0, ptr(d2), T, 1, _ffi.stream_of(xt)))
+        assert torch.equal(d2, d + d)
+
+
+@pytest.mark.gpu
+def test_random_scale_loss_is_one_node_and_matches_its_scales():
+    """RSSLoss with overlap 0: the fused node (all scales, one gradient buffer) against the scales one by one."""
+    from ddsp_svc_amd import loss as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(6)
+    xt = (torch.randn(8, 100000, generator=g) * 0.1).to(dev)
+    xp = (xt * 0.8 + 0.05 * torch.randn(8, 100000, generator=g).to(dev)).requires_grad_(True)
+    sizes = torch.tensor([1153, 397, 2011, 768])
+    rss = L.RSSLoss(256, 2048, 4, device=dev)
+    real = torch.randint
+    torch.randint = lambda *a, **k: sizes
+    try:
+        loss = rss(xp, xt)
+    finally:
+        torch.randint = real
+    assert "RandomScaleWaveLoss" in type(loss.grad_fn).__name__
+    grad, = torch.autograd.grad(loss, xp)
+    xq = xp.detach().clone().requires_grad_(True)
+    parts = sum(L.SSSLoss(int(n)).to(dev)(xt, xq) for n in sizes) / 4
+    pgrad, = torch.autograd.grad(parts, xq)
+    assert abs(float(loss.detach()) - float(parts.detach())) <= 1e-6 * float(parts.detach())
+    assert float((grad - pgrad).abs().max()) <= 1e-6 * float(pgrad.abs().max())
