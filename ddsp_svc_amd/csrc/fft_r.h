@@ -47,64 +47,90 @@ struct Plan {
   // v[n1] = z[P n1 + tid]  ->  v[m] = Z[P m + tid].  A and B hold N complex words each.
   // A must be free of readers on entry; on return A may still be read by slower waves (pass 4), B is free.
   // HI_ZERO: v[4..7] are zero on entry (an input zero-padded to twice its length) and need not be set.
-  template <bool HI_ZERO = false>
-  static __device__ __forceinline__ void forward(f32x2 (&v)[8], const Tw& tw, f32x2* A, f32x2* B, int tid) {
+  // The four passes, each between two barriers of forward():
+  template <bool HI_ZERO>
+  static __device__ __forceinline__ void pass1(f32x2 (&v)[8], const Tw& tw, f32x2* A, int tid) {
     if (HI_ZERO) dft8_lo4(v);
     else dft8(v);
     twiddle7(v, tw.w1);
     // R = 2: a row of the second pass is 16 words, so the two rows k1, k1 + 1 that a 32-lane read touches would start in
-    // the same banks; odd rows are stored with their 16-blocks swapped in pairs (R = 4: 32-word rows, nothing to do)
+    // the same banks; odd rows are stored with their 16-blocks swapped in pairs (R >= 4: rows of 32 words or more, nothing to do)
     constexpr int SW = R == 2 ? C : 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) A[k * P + (tid ^ ((k & 1) * SW))] = v[k];            // [k1][p]
-    __syncthreads();
-    {
-      const int k1 = tid / C, c = tid & (C - 1);
+  }
+  static __device__ __forceinline__ void pass2(f32x2 (&v)[8], const Tw& tw, const f32x2* A, f32x2* B, int tid) {
+    const int k1 = tid / C, c = tid & (C - 1);
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + (R == 2 ? (n2 ^ (k1 & 1)) : n2) * C + c];
-      dft8(v);
-      twiddle7(v, tw.w2);
-      const int n3 = c / R, n4 = c & (R - 1);
+    for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P + (R == 2 ? (n2 ^ (k1 & 1)) : n2) * C + c];
+    dft8(v);
+    twiddle7(v, tw.w2);
+    const int n3 = c / R, n4 = c & (R - 1);
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) B[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];   // [n3][k2][k1 ^ n3][n4]
-    }
-    __syncthreads();
-    {
+    for (int k2 = 0; k2 < 8; ++k2) B[n3 * P + ((k2 * C + k1 * R + n4) ^ (n3 * R))] = v[k2];   // [n3][k2][k1 ^ n3][n4]
+  }
+  static __device__ __forceinline__ void pass3(f32x2 (&v)[8], const Tw& tw, const f32x2* B, f32x2* A, int tid) {
 #pragma unroll
-      for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];          // tid = n4 + R k1 + 8R k2
-      dft8(v);
-      twiddle7(v, tw.w3);
+    for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];            // tid = n4 + R k1 + 8R k2
+    dft8(v);
+    twiddle7(v, tw.w3);
 #pragma unroll
-      for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + tid] = v[k3];                       // [k3][k2][k1][n4]
-    }
-    __syncthreads();
-    {
-      const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
-      const f32x2* src = A + k2 * C + k1 * R;
-      f32x2 t[8];
-      if constexpr (R == 8) {
+    for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + tid] = v[k3];                         // [k3][k2][k1][n4]
+  }
+  static __device__ __forceinline__ void pass4(f32x2 (&v)[8], const f32x2* A, int tid) {
+    const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
+    const f32x2* src = A + k2 * C + k1 * R;
+    f32x2 t[8];
+    if constexpr (R == 8) {
 #pragma unroll
-        for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + n4];
-        dft8(t);                                                                    // k4 = 0..7 -> slot m = k4
-      } else if constexpr (R == 4) {
+      for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + n4];
+      dft8(t);                                                                      // k4 = 0..7 -> slot m = k4
+    } else if constexpr (R == 4) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f32x2 a0 = src[(k3lo + 4 * s) * P + 0], a1 = src[(k3lo + 4 * s) * P + 1];
-          f32x2 a2 = src[(k3lo + 4 * s) * P + 2], a3 = src[(k3lo + 4 * s) * P + 3];
-          dft4(a0, a1, a2, a3);                                                     // k4 = 0..3 -> slot m = s + 2 k4
-          t[s] = a0; t[s + 2] = a1; t[s + 4] = a2; t[s + 6] = a3;
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const f32x2 a0 = src[(k3lo + 2 * s) * P + 0], a1 = src[(k3lo + 2 * s) * P + 1];
-          t[s] = a0 + a1;                                                           // k4 = 0, 1 -> slot m = s + 4 k4
-          t[s + 4] = a0 - a1;
-        }
+      for (int s = 0; s < 2; ++s) {
+        f32x2 a0 = src[(k3lo + 4 * s) * P + 0], a1 = src[(k3lo + 4 * s) * P + 1];
+        f32x2 a2 = src[(k3lo + 4 * s) * P + 2], a3 = src[(k3lo + 4 * s) * P + 3];
+        dft4(a0, a1, a2, a3);                                                       // k4 = 0..3 -> slot m = s + 2 k4
+        t[s] = a0; t[s + 2] = a1; t[s + 4] = a2; t[s + 6] = a3;
       }
+    } else {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = t[m];
+      for (int s = 0; s < 4; ++s) {
+        const f32x2 a0 = src[(k3lo + 2 * s) * P + 0], a1 = src[(k3lo + 2 * s) * P + 1];
+        t[s] = a0 + a1;                                                             // k4 = 0, 1 -> slot m = s + 4 k4
+        t[s + 4] = a0 - a1;
+      }
     }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = t[m];
+  }
+  template <bool HI_ZERO = false>
+  static __device__ __forceinline__ void forward(f32x2 (&v)[8], const Tw& tw, f32x2* A, f32x2* B, int tid) {
+    pass1<HI_ZERO>(v, tw, A, tid);
+    __syncthreads();
+    pass2(v, tw, A, B, tid);
+    __syncthreads();
+    pass3(v, tw, B, A, tid);
+    __syncthreads();
+    pass4(v, A, tid);
+  }
+  // Two independent transforms in lockstep (v through A, B; u through A2, B2): the same arithmetic as two forward()
+  // calls, behind shared barriers -- twice the work between two barriers, and one stream's exchange latency under the other's
+  // butterflies.
+  template <bool HI_ZERO = false>
+  static __device__ __forceinline__ void forward2(f32x2 (&v)[8], f32x2 (&u)[8], const Tw& tw, f32x2* A, f32x2* B, f32x2* A2,
+                                                  f32x2* B2, int tid) {
+    pass1<HI_ZERO>(v, tw, A, tid);
+    pass1<HI_ZERO>(u, tw, A2, tid);
+    __syncthreads();
+    pass2(v, tw, A, B, tid);
+    pass2(u, tw, A2, B2, tid);
+    __syncthreads();
+    pass3(v, tw, B, A, tid);
+    pass3(u, tw, B2, A2, tid);
+    __syncthreads();
+    pass4(v, A, tid);
+    pass4(u, A2, tid);
   }
 
   // ---- the pair without the last exchange (R = 2) -------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include "ddsp_common.h"
 #include "fft_r.h"
 #include "kernels.h"
+#include "tuning.h"
 
 namespace ddsp {
 using fft::cconj;
@@ -98,21 +99,44 @@ __device__ __forceinline__ void czt_convolve(f32x2 (&v)[8], const typename fft::
   PL::forward(v, tw, A, B, tid);
 }
 
+// The same for two inputs in lockstep (Plan::forward2): v through A, B and u through A2, B2; one copy of the tables.
+template <int R, class Between>
+__device__ __forceinline__ void czt_convolve2(f32x2 (&v)[8], f32x2 (&u)[8], const typename fft::Plan<R>::Tw& tw,
+                                              const f32x2* __restrict__ bh, const f32x2* __restrict__ post, f32x2 (&pv)[4],
+                                              f32x2* A, f32x2* B, f32x2* A2, f32x2* B2, int tid, Between&& between) {
+  using PL = fft::Plan<R>;
+  f32x2 g[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) g[m] = bh[PL::P * m + tid];
+  PL::template forward2<true>(v, u, tw, A, B, A2, B2, tid);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    v[m] = cconj(cmul(v[m], g[m]));
+    u[m] = cconj(cmul(u[m], g[m]));
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) pv[m] = post[PL::P * m + tid];
+  between();
+  __syncthreads();
+  PL::forward2(v, u, tw, A, B, A2, B2, tid);
+}
+
+// Two frames per pass, in lockstep.  A chunk with an odd number of frames runs its last one twice (the second copy is
+// neither stored nor counted).
 template <int R>
 __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__ xt, const float* __restrict__ xp, long ld,
-                                                    int n, int hop, int frames, int chunks,
-                                                    const float2* __restrict__ tab, float inv_wn, float eps,
-                                                    float2* __restrict__ spec_t, float2* __restrict__ spec_p,
-                                                    double* __restrict__ partial) {
+                                                       int n, int hop, int frames, int chunks, int span,
+                                                       const float2* __restrict__ tab, float inv_wn, float eps,
+                                                       float2* __restrict__ spec_t, float2* __restrict__ spec_p,
+                                                       double* __restrict__ partial) {
   using PL = fft::Plan<R>;
   constexpr int N = PL::N, P = PL::P;
-  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
+  __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
   __shared__ double red[3][R];
-  __shared__ int live[2][3];                                 // [frame parity][true, pred: a nonzero sample; the two differ]
+  __shared__ int live[2][2][3];                              // [pass parity][frame of the pair][true, pred: a nonzero sample; the two differ]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, b = blockIdx.y;
   const int bins = n / 2 + 1;
-  const int span = (frames + chunks - 1) / chunks;
   const int f_lo = c * span;
   const int f_hi = f_lo + span < frames ? f_lo + span : frames;
   const f32x2* ch = reinterpret_cast<const f32x2*>(tab);
@@ -122,78 +146,96 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
   tw.init(tid);
   const float scale = 0.5f / (float)N;                       // the inverse transform's 1/N and the 1/2 of the split
   double d2 = 0.0, s2 = 0.0, l1 = 0.0;
-  if (tid < 6) live[tid / 3][tid % 3] = 0;
+  if (tid < 12) (&live[0][0][0])[tid] = 0;
   f32x2 wcr[4];                                              // window times chirp of this thread's four samples
 #pragma unroll
   for (int n1 = 0; n1 < 4; ++n1) wcr[n1] = P * n1 + tid < n ? wc[P * n1 + tid] : f32x2{0.f, 0.f};
-  float na[4], nq[4];                                        // the NEXT frame's samples: in flight during this frame's transforms
+  float na[2][4], nq[2][4];                                  // the NEXT pair's samples: in flight during this pair's transforms
   auto fetch = [&](int f) {
-    const float* pt = xt + (long)b * ld + (long)f * hop;
-    const float* pp = xp + (long)b * ld + (long)f * hop;
 #pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) {
-      const int j = P * n1 + tid;
-      const int jj = j < n ? j : 0;
-      na[n1] = pt[jj];
-      nq[n1] = pp[jj];
+    for (int h = 0; h < 2; ++h) {
+      const int ff = f + h < f_hi ? f + h : f_hi - 1;
+      const float* pt = xt + (long)b * ld + (long)ff * hop;
+      const float* pp = xp + (long)b * ld + (long)ff * hop;
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) {
+        const int j = P * n1 + tid;
+        const int jj = j < n ? j : 0;
+        na[h][n1] = pt[jj];
+        nq[h][n1] = pp[jj];
+      }
     }
   };
   if (f_lo < f_hi) fetch(f_lo);
   __syncthreads();
-  for (int f = f_lo; f < f_hi; ++f) {
-    f32x2 v[8], co[4];
-    bool any_t = false, any_p = false, differ = false;
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) {
-      const float a = na[n1], q = nq[n1];
-      const f32x2 w = wcr[n1];                               // 0 behind the frame's end
-      v[n1] = f32x2{a * w.x - q * w.y, a * w.y + q * w.x};
-      any_t |= a * w.x != 0.f || a * w.y != 0.f;             // the WINDOWED sample: hann[0] = 0
-      any_p |= q * w.x != 0.f || q * w.y != 0.f;
-      differ |= P * n1 + tid < n && a != q;
-    }
-    if (f + 1 < f_hi) fetch(f + 1);
+  for (int f = f_lo, par = 0; f < f_hi; f += 2, par ^= 1) {
+    f32x2 v[2][8], co[4];
     // The two signals share one transform, so each spectrum carries the other's rounding noise (1e-7 of ITS size).  A
-    // frame that is all zero behind the window -- digital silence -- must come out as exact zeros (S = eps, and a zero gradient at the origin, as
-    // the separate transforms of the reference give): such frames are flagged here and zeroed behind the split.  Likewise
-    // two EQUAL frames must give equal spectra (loss 0 for identical signals), which the two halves of the split do not.
-    if (any_t) live[f & 1][0] = 1;
-    if (any_p) live[f & 1][1] = 1;
-    if (differ) live[f & 1][2] = 1;
-    if (tid < 3) live[(f + 1) & 1][tid] = 0;                 // next frame's flags; its writers are barriers away
-    czt_convolve<R>(v, tw, bh, ch, co, ex[0], ex[1], tid, [] {});
-    const float keep_t = live[f & 1][0] ? 1.f : 0.f, keep_p = live[f & 1][1] ? 1.f : 0.f;
-    const bool same = !live[f & 1][2];
-    f32x2 z[3];
+    // frame that is all zero behind the window -- digital silence -- must come out as exact zeros (S = eps, and a zero
+    // gradient at the origin, as the separate transforms of the reference give): such frames are flagged here and zeroed
+    // behind the split.  Likewise two EQUAL frames must give equal spectra (loss 0 for identical signals), which the two
+    // halves of the split do not.
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int k = P * m + tid;
-      if (k < n) {
-        const f32x2 zz = cmul(cconj(v[m]), co[m]) * scale;   // Z[k] / 2
-        ex[1][k] = zz;
-        if (m < 3) z[m] = zz;
+    for (int h = 0; h < 2; ++h) {
+      bool any_t = false, any_p = false, differ = false;
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) {
+        const float a = na[h][n1], q = nq[h][n1];
+        const f32x2 w = wcr[n1];                             // 0 behind the frame's end
+        v[h][n1] = f32x2{a * w.x - q * w.y, a * w.y + q * w.x};
+        any_t |= a * w.x != 0.f || a * w.y != 0.f;           // the WINDOWED sample: hann[0] = 0
+        any_p |= q * w.x != 0.f || q * w.y != 0.f;
+        differ |= P * n1 + tid < n && a != q;
+      }
+      if (any_t) live[par][h][0] = 1;
+      if (any_p) live[par][h][1] = 1;
+      if (differ) live[par][h][2] = 1;
+    }
+    if (tid < 6) (&live[par ^ 1][0][0])[tid] = 0;            // next pass's flags; its writers are barriers away
+    if (f + 2 < f_hi) fetch(f + 2);
+    czt_convolve2<R>(v[0], v[1], tw, bh, ch, co, ex[0], ex[1], ex[2], ex[3], tid, [] {});
+    f32x2 z[2][3];
+    float keep_t[2], keep_p[2];
+    bool same[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                            // read BEFORE the barrier below: the next pass resets these flags
+      keep_t[h] = live[par][h][0] ? 1.f : 0.f;
+      keep_p[h] = live[par][h][1] ? 1.f : 0.f;
+      same[h] = !live[par][h][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = P * m + tid;
+        if (k < n) {
+          const f32x2 zz = cmul(cconj(v[h][m]), co[m]) * scale;      // Z[k] / 2
+          ex[1 + 2 * h][k] = zz;
+          if (m < 3) z[h][m] = zz;
+        }
       }
     }
     __syncthreads();
-    float fd = 0.f, fs = 0.f, fl = 0.f;
-    const long row = ((long)b * frames + f) * bins;
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {                            // n <= N / 2, so the bins 0 .. n/2 lie in the slots 0 .. 2
-      const int k = P * m + tid;
-      if (k < bins) {
-        const f32x2 zk = z[m], zm = ex[1][k == 0 ? 0 : n - k];
-        const f32x2 Xt = f32x2{zk.x + zm.x, zk.y - zm.y} * keep_t;      // (Z[k] + conj Z[n-k]) / 2
-        const f32x2 Xp = same ? Xt : f32x2{zk.y + zm.y, zm.x - zk.x} * keep_p;      // (Z[k] - conj Z[n-k]) / 2i
-        spec_t[row + k] = float2{Xt.x, Xt.y};
-        spec_p[row + k] = float2{Xp.x, Xp.y};
-        const float st = fmaf(cz_mag(Xt), inv_wn, eps), sp = fmaf(cz_mag(Xp), inv_wn, eps);
-        const float d = st - sp, s = st + sp;
-        fd += d * d;
-        fs += s * s;
-        fl += fabsf(cz_log(st) - cz_log(sp));
+    for (int h = 0; h < 2; ++h) {
+      if (f + h >= f_hi) break;
+      float fd = 0.f, fs = 0.f, fl = 0.f;
+      const long row = ((long)b * frames + f + h) * bins;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {                          // n <= N / 2, so the bins 0 .. n/2 lie in the slots 0 .. 2
+        const int k = P * m + tid;
+        if (k < bins) {
+          const f32x2 zk = z[h][m], zm = ex[1 + 2 * h][k == 0 ? 0 : n - k];
+          const f32x2 Xt = f32x2{zk.x + zm.x, zk.y - zm.y} * keep_t[h];                     // (Z[k] + conj Z[n-k]) / 2
+          const f32x2 Xp = same[h] ? Xt : f32x2{zk.y + zm.y, zm.x - zk.x} * keep_p[h];      // (Z[k] - conj Z[n-k]) / 2i
+          spec_t[row + k] = float2{Xt.x, Xt.y};
+          spec_p[row + k] = float2{Xp.x, Xp.y};
+          const float st = fmaf(cz_mag(Xt), inv_wn, eps), sp = fmaf(cz_mag(Xp), inv_wn, eps);
+          const float d = st - sp, s = st + sp;
+          fd += d * d;
+          fs += s * s;
+          fl += fabsf(cz_log(st) - cz_log(sp));
+        }
       }
+      d2 += (double)fd; s2 += (double)fs; l1 += (double)fl;
     }
-    d2 += (double)fd; s2 += (double)fs; l1 += (double)fl;
   }
   d2 = wave_sum(d2); s2 = wave_sum(s2); l1 = wave_sum(l1);
   if (lane == 0) { red[0][wave] = d2; red[1][wave] = s2; red[2][wave] = l1; }
@@ -327,18 +369,49 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
     for (long i = (long)frames * n + tid; i < T; i += P) o[i] = 0.f;
 }
 
-int sss_wave_chunks(int B, int n, int frames, int per_item) {
-  const int R = czt_plan(n);
-  const int resident = 2 * 256 * (8 / (R ? R : 8));                  // two rounds of what the chip holds at 2 waves per SIMD
-  const int items = (frames + per_item - 1) / per_item;
-  int c = (resident + B - 1) / B;
-  if (c > items) c = items;
-  if (c < 1) c = 1;
-  return c;
+// Launch geometry: one round (knob CZT_ROUNDS: more) of what the chip holds (asked of the runtime once per kernel: it depends
+// on the registers the compiler used), the frames of an utterance in equal spans -- of an even number of frames, both kernels
+// take them in pairs.  Measured (profiles/r03_v25_loss_rounds.txt): a workgroup's start -- 24 sincospi for the twiddles,
+// table loads, the first fetch -- is worth about one frame, so 2 / 4 / 8 rounds cost +3 / +12 / +19 % of the step.
+struct WaveGeom { int chunks, span; };
+
+template <class K>
+static int czt_resident(K kernel, int threads, int& cache) {
+  if (cache <= 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache = cus * per_cu;
+  }
+  return cache;
+}
+
+static int czt_resident_of(int R, bool backward) {
+  static int cache[2][3];
+  int& c = cache[backward ? 1 : 0][R == 2 ? 0 : (R == 4 ? 1 : 2)];
+  if (!backward) {
+    if (R == 2) return czt_resident(k_sss_czt<2>, 128, c);
+    if (R == 4) return czt_resident(k_sss_czt<4>, 256, c);
+    return czt_resident(k_sss_czt<8>, 512, c);
+  }
+  if (R == 2) return czt_resident(k_sss_czt_bwd<2, 0>, 128, c);
+  if (R == 4) return czt_resident(k_sss_czt_bwd<4, 0>, 256, c);
+  return czt_resident(k_sss_czt_bwd<8, 0>, 512, c);
+}
+
+static WaveGeom sss_wave_geom(int B, int n, int frames, bool backward) {
+  const int pairs = (frames + 1) / 2;
+  const long rounds = knob(KNOB_CZT_ROUNDS) > 0 ? knob(KNOB_CZT_ROUNDS) : 1;
+  int want = (int)((czt_resident_of(czt_plan(n), backward) * rounds + B - 1) / B);     // chunks per utterance
+  if (want > pairs) want = pairs;
+  if (want < 1) want = 1;
+  const int span = 2 * ((pairs + want - 1) / want);
+  return WaveGeom{(frames + span - 1) / span, span};
 }
 
 size_t sss_wave_scratch_bytes(int B, int n, int frames) {
-  return (size_t)B * sss_wave_chunks(B, n, frames, 1) * 3 * sizeof(double);
+  return (size_t)B * sss_wave_geom(B, n, frames, false).chunks * 3 * sizeof(double);
 }
 
 int launch_czt_tables(int n, float* tab, hipStream_t st) {
@@ -355,19 +428,20 @@ int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int
                     float* loss, hipStream_t st) {
   const int R = czt_plan(n);
   if (!R || B < 1 || B > 65535 || frames < 1 || hop < 1) return -1;
-  const int chunks = sss_wave_chunks(B, n, frames, 1);
+  const WaveGeom geo = sss_wave_geom(B, n, frames, false);
+  const int chunks = geo.chunks, span = geo.span;
   const dim3 grid((unsigned)chunks, (unsigned)B);
   const float2* tb = reinterpret_cast<const float2*>(tab);
   float2* s_t = reinterpret_cast<float2*>(spec_t);
   float2* s_p = reinterpret_cast<float2*>(spec_p);
   if (R == 2)
-    hipLaunchKernelGGL(k_sss_czt<2>, grid, dim3(128), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+    hipLaunchKernelGGL(k_sss_czt<2>, grid, dim3(128), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
                        scratch);
   else if (R == 4)
-    hipLaunchKernelGGL(k_sss_czt<4>, grid, dim3(256), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+    hipLaunchKernelGGL(k_sss_czt<4>, grid, dim3(256), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
                        scratch);
   else
-    hipLaunchKernelGGL(k_sss_czt<8>, grid, dim3(512), 0, st, xt, xp, ld, n, hop, frames, chunks, tb, inv_wn, eps, s_t, s_p,
+    hipLaunchKernelGGL(k_sss_czt<8>, grid, dim3(512), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
                        scratch);
   const long per_utt = (long)frames * (n / 2 + 1);
   launch_sss_final(scratch, B, chunks, per_utt, alpha, norms, loss, st);
@@ -391,7 +465,8 @@ int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, 
                         float* dx, long ld_dx, int accumulate, hipStream_t st) {
   const int R = czt_plan(n);
   if (!R || B < 1 || B > 65535 || frames < 1 || (long)frames * n > T) return -1;
-  const int chunks = sss_wave_chunks(B, n, frames, 2);
+  const WaveGeom geo = sss_wave_geom(B, n, frames, true);
+  const int chunks = geo.chunks;                                       // the kernel cuts the pairs of frames into as many spans
   const dim3 grid((unsigned)chunks, (unsigned)B);
   const float2* tb = reinterpret_cast<const float2*>(tab);
   const float2* s_t = reinterpret_cast<const float2*>(spec_t);

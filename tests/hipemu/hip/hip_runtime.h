@@ -54,6 +54,10 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }   // a chip of two CUs:
+template <class K>                                                                                                 // small grids, several
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }   // chunks per row
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { static int token; *e = &token; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

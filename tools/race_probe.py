@@ -103,6 +103,23 @@ def loss_grad():
 
 
 ops["spectral loss, forward + backward (ATen stft backward: not deterministic, informational)"] = loss_grad
+rssm = hloss.RSSLoss(256, 2048, 4, device=dev)
+rss_sizes = torch.tensor([1153, 397, 2011, 768])
+
+
+def rss_grad():
+    real = torch.randint
+    torch.randint = lambda *a, **k: rss_sizes
+    try:
+        xp = x.detach().clone().requires_grad_(True)
+        l = rssm(xp, gout * 0.1)
+    finally:
+        torch.randint = real
+    l.backward()
+    return torch.cat([l.detach().reshape(-1), xp.grad.reshape(-1)])
+
+
+ops["random-scale loss from the waveforms (in-kernel chirp-z STFT, 4 sizes), forward + backward"] = rss_grad
 bad = 0
 filler = torch.empty(64 << 20, device=dev)
 for name, fn in ops.items():
