@@ -319,6 +319,31 @@ def also_lines(a, device, B, F, n, want_traffic):
         "roofline": {"kernel": "k_stft_filter<4>", "bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_per_step": 1}}
+    del step, inp, y, exc, c
+    # ---- the training loss of the reference (train.py:69): RSSLoss, 4 scales of arbitrary (here: three prime) size
+    from ddsp_svc_amd import loss as L
+    g = torch.Generator(device="cpu").manual_seed(99)
+    xt = (torch.randn(B, T, generator=g) * 0.1).to(device)
+    xp = (xt * 0.9 + 0.02 * torch.randn(B, T, generator=g).to(device)).requires_grad_(True)
+    sizes = [1153, 397, 2011, 768]
+    rss, drawn, real_randint = L.RSSLoss(256, 2048, len(sizes), device=device), torch.tensor(sizes), torch.randint
+
+    def loss_step():
+        torch.randint = lambda *a_, **k_: drawn                      # loss.py:47's draw, pinned
+        try:
+            value = rss(xp, xt)
+        finally:
+            torch.randint = real_randint
+        return torch.autograd.grad(value, xp)[0]
+    el, ev_ms, y = time_steps(loss_step, steps, warm, fence)
+    assert torch.isfinite(y).all()
+    out["rssloss"] = {
+        "metric": "audio samples/sec, RSSLoss forward+backward 44.1kHz 4 scales", "value": B * T * steps / el,
+        "unit": "samples/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3, "ms_per_step_events": ev_ms,
+        "dtype": "f32",
+        "config": {"workload": "RSSLoss(x_pred, x_true) + d/dx_pred, B=%d x %.0f s, transform sizes %s (hop = size), STFT inside "
+                               "the loss kernels (chirp-z, csrc/loss_czt.hip); `--model rssloss` gives the full line"
+                               % (B, a.seconds, sizes)}}
     return out
 
 

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """forward + backward of the DSP tails (B=32 x 10 s) for rocprofv3 --kernel-trace: which kernels a training step spends
-its time in."""
+its time in.  `train_step_probe.py <kind> [loss]`: with `loss`, the objective is the reference's RSSLoss(256, 2048, 4)
+against a target waveform (train.py:69, solver.py:93-103), its four sizes pinned to one draw (1153, 397, 2011, 768);
+without, a plain weighted sum (the synthesiser's own kernels only).  Gradients are taken with torch.autograd.grad: .backward()
+would add each step's gradient onto the leaves' .grad (one [B, F, n] add per control), which a training loop -- whose
+controls are activations of Unit2Control, not leaves -- never runs."""
 import os
 import sys
 import time
@@ -16,6 +20,7 @@ torch.autograd.set_multithreading_enabled(False)       # backward on the calling
 dev = torch.device("cuda:0")
 B, F, n = 32, 862, 256
 kind = sys.argv[1] if len(sys.argv) > 1 else "combsub"
+with_loss = len(sys.argv) > 2 and sys.argv[2] == "loss"
 if kind == "combsubsuperfast":
     f0, ctrls, noise = bench.make_inputs(kind, B, F, (1025,) * 4, dev, 1234)
     w = torch.hann_window(2048, device=dev)
@@ -23,6 +28,22 @@ else:
     f0, ctrls, noise = bench.make_inputs(kind, B, F, (n, n, n), dev, 1234)
 c = [x.clone().requires_grad_(True) for x in ctrls]
 R = torch.randn(B, F * 512, device=dev)
+if with_loss:
+    from ddsp_svc_amd import loss as hloss
+    rss = hloss.RSSLoss(256, 2048, 4, device=dev)
+    drawn = torch.tensor([1153, 397, 2011, 768])
+    target = R * 0.1
+
+
+def objective(sig):
+    if not with_loss:
+        return (sig * R).sum()
+    real = torch.randint
+    torch.randint = lambda *a, **k: drawn
+    try:
+        return rss(sig, target)
+    finally:
+        torch.randint = real
 
 
 def step():
@@ -33,14 +54,14 @@ def step():
         st = synth.phase(f0, 44100, 512)
         fn = synth.sins_synth if kind == "sins" else synth.combsub_synth
         sig = fn(f0, st, c[0], c[1], c[2], noise, 44100, 512)[0]
-    (sig * R).sum().backward()
+    return torch.autograd.grad(objective(sig), c)
 
 
 for _ in range(3):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(5):
+for _ in range(20):
     step()
 torch.cuda.synchronize()
-print(kind, "forward+backward ms/step", round((time.perf_counter() - t0) / 5 * 1e3, 3))
+print(kind, "forward+backward" + (" with RSSLoss" if with_loss else ""), "ms/step", round((time.perf_counter() - t0) / 20 * 1e3, 3))
