@@ -230,7 +230,7 @@ class SSSLoss(torch.nn.Module):
         x_true = x_true.reshape(-1, x_true.shape[-1]) if x_true.dim() != 2 else x_true
         x_pred = x_pred.reshape(-1, x_pred.shape[-1]) if x_pred.dim() != 2 else x_pred
         if self.hop_length == self.n_fft and x_true.shape[-1] >= self.n_fft and x_true.shape[-1] < 2 ** 31 \
-                and not _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT"):
+                and x_true.shape[0] <= 65535 and not _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT"):
             tables = _czt_tables(self.n_fft, x_pred)
             if tables is not None:
                 return _WaveLossFunction.apply(x_true.to(torch.float32), x_pred.to(torch.float32), self.n_fft,
@@ -266,7 +266,7 @@ class RSSLoss(torch.nn.Module):
         if _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT") or x_true.shape != x_pred.shape:
             return None
         T = x_true.shape[-1]
-        if T < max(sizes) or T >= 2 ** 31 or len(sizes) == 0:
+        if T < max(sizes) or T >= 2 ** 31 or len(sizes) == 0 or x_true.numel() // T > 65535:
             return None
         _ffi.check_device(x_true, x_pred)
         xt = x_true.reshape(-1, T).to(torch.float32)

@@ -12,6 +12,7 @@ using ddsp::fft::Plan;
 // mode 3: Plan<2>::transposed              in[k] is read into layout S, out natural = DFT of in
 // mode 4: Plan<2>::forward_s2<true>        two inputs (in, in2) -> (out, out2), both as mode 2
 // mode 5: Plan<2>::transposed_and_forward_s   in -> out as mode 3, in2 -> out2 as mode 2
+// modes 10..12 (every R): the lockstep pair forward2 (full / zero-padded inputs) and the zero-padded forward
 // modes 6..9: modes 2..5 in the sign-carrying layout S- (FLIP = true): what odd threads hold is written out negated
 //             again, so the expected values are those of modes 2..5
 template <int R>
@@ -26,6 +27,17 @@ __global__ void k_plan(int mode, const f32x2* in, const f32x2* in2, f32x2* out, 
   if (mode == 0) {
     for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
     PL::forward(v, tw, ex[0], ex[1], tid);
+    for (int m = 0; m < 8; ++m) out[P * m + tid] = v[m];
+  }
+  if (mode == 10 || mode == 11) {                            // 10: forward2, 11: forward2<true> (upper halves of the inputs zero)
+    for (int m = 0; m < 8; ++m) { v[m] = in[P * m + tid]; u[m] = in2[P * m + tid]; }
+    if (mode == 10) PL::forward2(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+    else PL::template forward2<true>(v, u, tw, ex[0], ex[1], ex[2], ex[3], tid);
+    for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m]; out2[P * m + tid] = u[m]; }
+  }
+  if (mode == 12) {                                          // forward<true>: the pruned first pass alone
+    for (int m = 0; m < 4; ++m) v[m] = in[P * m + tid];
+    PL::template forward<true>(v, tw, ex[0], ex[1], tid);
     for (int m = 0; m < 8; ++m) out[P * m + tid] = v[m];
   }
   if constexpr (R == 2) {

@@ -57,6 +57,22 @@ def test_full_transform(plans, R):
     assert _close(plans(R, 0, z)[0], np.fft.fft(z.astype(np.complex128)))
 
 
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_lockstep_pair_and_zero_padded_first_pass(plans, R):
+    """forward2 = two forward calls behind shared barriers, bit for bit; the pruned first pass (upper half of the input zero,
+    never read) against numpy and, in lockstep, against itself."""
+    n = 512 * R
+    a, b = _rand(n, 30 + R), _rand(n, 40 + R)
+    one_a, one_b = plans(R, 0, a)[0], plans(R, 0, b)[0]
+    two_a, two_b = plans(R, 10, a, b)
+    assert np.array_equal(one_a, two_a) and np.array_equal(one_b, two_b)
+    ah, bh = _rand(n, 50 + R, half=True), _rand(n, 60 + R, half=True)
+    pruned = plans(R, 12, ah)[0]
+    assert _close(pruned, np.fft.fft(ah.astype(np.complex128)))
+    pa, pb = plans(R, 11, ah, bh)
+    assert np.array_equal(pa, pruned) and np.array_equal(pb, plans(R, 12, bh)[0])
+
+
 def test_layout_s_pair(plans):
     z = _rand(1024, 10)
     zh = _rand(1024, 11, half=True)
