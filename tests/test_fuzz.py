@@ -70,3 +70,39 @@ def test_random_spectral_tails(dev, seed, knobs):
         ref = ref["signal"] if isinstance(ref, dict) else ref
         e, r = _rms(got.cpu().numpy() - ref), _rms(ref)
         assert np.isfinite(e) and e <= 2e-5 * max(r, 1e-9), (kind, B, F, run, e, r)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("seed", range(4))
+def test_random_scale_loss(dev, seed, knobs):
+    """RSSLoss as the reference draws it (loss.py:47) on random batch sizes and lengths -- exactly one frame, odd frame
+    counts, a tail shorter than a frame, strided inputs, several rounds of workgroups -- against the oracle's float64
+    loss and analytic gradient.  eps = 1e-5 keeps the comparison away from the sign flips of bins at the rounding floor
+    (tests/test_loss.py has the eps = 1e-7 cases)."""
+    from ddsp_svc_amd import loss as L
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(2):
+        B = int(rng.integers(1, 4))
+        sizes = [int(s) for s in rng.integers(2, 2048, 3)]
+        T = int(max(sizes) * rng.choice([1, 1, 2, 3]) + rng.integers(0, 40))
+        knobs("CZT_ROUNDS", int(rng.choice([0, 1, 3])))
+        a = (rng.standard_normal((B, 2 * T)) * 0.1).astype(np.float32)
+        b = (a * 0.6 + rng.standard_normal((B, 2 * T)) * 0.05).astype(np.float32)
+        strided = bool(rng.integers(0, 2))
+        xt = torch.from_numpy(a).to(dev)[:, ::2] if strided else torch.from_numpy(np.ascontiguousarray(a[:, ::2])).to(dev)
+        xp = (torch.from_numpy(b).to(dev)[:, ::2] if strided else torch.from_numpy(np.ascontiguousarray(b[:, ::2])).to(dev))
+        xp = xp.detach().requires_grad_(True)
+        rss = L.RSSLoss(2, 2048, len(sizes), eps=1e-5, device=dev)
+        real = torch.randint
+        torch.randint = lambda *args, **kw: torch.tensor(sizes)
+        try:
+            value = rss(xp, xt)
+        finally:
+            torch.randint = real
+        assert "RandomScaleWaveLoss" in type(value.grad_fn).__name__
+        grad, = torch.autograd.grad(value, xp)
+        at, bt = a[:, ::2], b[:, ::2]
+        want = np.mean([O.sss_loss(at, bt, n, 1.0, 0.0, eps=1e-5) for n in sizes])
+        gwant = np.mean([O.sss_loss_backward(at, bt, n, 1.0, 0.0, eps=1e-5) for n in sizes], axis=0)
+        assert abs(float(value.detach()) - want) <= 2e-5 * want, (B, T, sizes, strided)
+        assert _rms(grad.cpu().numpy() - gwant) <= 2e-4 * _rms(gwant), (B, T, sizes, strided)
