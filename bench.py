@@ -487,6 +487,37 @@ def cpu_baseline_aten_chain(kind, F, sizes, budget_s=14.0):
                       (batch, F, F * HOP / SR, torch.__version__, time.perf_counter() - t_start)}
 
 
+def aten_chain_on_gpu(kind, f0, ctrls, noise, ours, device, steps=5):
+    """Second half of the ``cpu_baseline_aten_chain`` leg: the SAME op chain with its tensors on the MI355X -- what a user gets
+    from running the reference's DSP tail as it is under PyTorch-ROCm (rocFFT at 2 hop + N - 1 = 1533 points, fold, ...),
+    on the full workload of the headline, beside the HIP path's step and compared with its output."""
+    from oracle import aten_chain as A
+    fn = A.sins_tail if kind == "sins" else A.combsub_tail
+    B, F = f0.shape[0], f0.shape[1]
+    f0c = f0.reshape(B, F, 1)
+
+    def step():
+        with torch.no_grad():
+            return fn(f0c, ctrls[0], ctrls[1], ctrls[2], noise, SR, HOP, True)[0]
+    t_first = time.perf_counter()
+    out = step()                                                    # rocFFT plans, allocator growth
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    err = float((out - ours).pow(2).mean().sqrt() / ours.pow(2).mean().sqrt())
+    peak = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    return {"ms_per_step": ms, "value": B * F * HOP / (ms * 1e-3), "unit": "samples/s", "steps": steps,
+            "first_call_s": t_first, "rel_rms_vs_hip_path": err, "peak_memory_gib": peak,
+            "what": "oracle/aten_chain.py (the reference's op sequence) with torch %s ROCm operators on the same GPU, same "
+                    "inputs, B=%d x %d frames" % (torch.__version__, B, F)}
+
+
 def module_mode(kind, B, F, n, device, steps, warmup):
     """Control mode (i) of SURVEY.md 8-d: the drop-in module end to end -- HOT-1, a Unit2Control producing the controls on
     the GPU, torch.rand noise, HOT-2 -- with a stand-in of the reference's Unit2Control shape (tools/standins.py: the
@@ -1224,6 +1255,13 @@ def main():
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
             res["cpu_baseline_aten_chain"] = cpu_baseline_aten_chain(a.model, F, sizes)
             res["cpu_baseline_aten_chain"]["gpu_over_cpu"] = value / res["cpu_baseline_aten_chain"]["value"]
+            if a.model in ("combsub", "sins"):
+                try:
+                    g_ = aten_chain_on_gpu(a.model, f0, ctrls, noise, out, device)
+                    g_["hip_over_eager"] = value / g_["value"]
+                except Exception as e:                                  # a baseline must not take the line down
+                    g_ = {"error": "%s: %s" % (type(e).__name__, e)}
+                res["cpu_baseline_aten_chain"]["same_chain_on_gpu"] = g_
         emit((res))
     finish_ranks()
 

@@ -6,8 +6,9 @@ This file restates the same path as the sequence of ATen kernels the reference d
 ``interpolate``, float64 ``cumsum``, ``sinc``, ``irfft`` + ``roll`` + window, zero ``pad`` + ``unfold`` + periodic
 Bartlett window, ``rfft`` / ``irfft`` at ``2 hop + N - 1`` points (1533 for the BASELINE shapes), ``fold`` overlap-add,
 crop -- so that ``bench.py`` can time "the reference's cost on this box's cores" without the reference checkout (which
-cannot travel to the GPU box).  Only ``tests/`` and ``bench.py``'s ``cpu_baseline`` leg import it; it is pinned to the
-same reference-generated fixtures as the numpy oracle (tests/test_aten_chain.py).
+cannot travel to the GPU box).  Only ``tests/`` and ``bench.py``'s ``cpu_baseline`` leg import it (which also times the
+same chain with the tensors on the GPU: what running the reference's DSP under PyTorch-ROCm costs there); it is pinned to
+the same reference-generated fixtures as the numpy oracle (tests/test_aten_chain.py).
 
 Each function names the reference lines whose op sequence it follows.
 """
@@ -43,9 +44,9 @@ def taps_from_response(resp, window=True, half_width=None):
     if not window:
         return ir.roll(n_taps // 2, -1)
     if half_width is None:                                   # periodic Hann of the full length, zero-phase then causal
-        w = torch.hann_window(n_taps, dtype=ir.dtype).roll(n_taps // 2, -1)
+        w = torch.hann_window(n_taps, dtype=ir.dtype, device=ir.device).roll(n_taps // 2, -1)
         return (ir * w).roll(n_taps // 2, -1)
-    pos = torch.arange(-(n_taps // 2), (n_taps + 1) // 2, dtype=ir.dtype) / half_width      # core.py:244
+    pos = torch.arange(-(n_taps // 2), (n_taps + 1) // 2, dtype=ir.dtype, device=ir.device) / half_width      # core.py:244
     pos[pos > 1] = 0                                                                        # core.py:245 (one-sided)
     return ir.roll(n_taps // 2, -1) * ((1 + torch.cos(math.pi * pos)) / 2)
 
@@ -56,7 +57,7 @@ def framewise_convolve(audio, taps):
     B, T = audio.shape
     Fr, n_taps = taps.shape[1], taps.shape[2]
     hop = T // Fr
-    frames = F.pad(audio, (hop, hop)).unfold(1, 2 * hop, hop) * torch.bartlett_window(2 * hop, dtype=audio.dtype)
+    frames = F.pad(audio, (hop, hop)).unfold(1, 2 * hop, hop) * torch.bartlett_window(2 * hop, dtype=audio.dtype, device=audio.device)
     size = 2 * hop + n_taps - 1
     spec = torch.fft.rfft(frames, size) * torch.fft.rfft(torch.cat([taps, taps[:, -1:]], dim=1), size)
     pieces = torch.fft.irfft(spec, size)                      # [B, F+1, size]
@@ -92,7 +93,7 @@ def sins_tail(f0_frames, c_amp, c_gd, c_noise, noise, sr=44100, hop=512, infer=T
     phase = 2 * math.pi * x
     amp = torch.exp(c_amp) / 128
     H = amp.shape[-1]
-    order = torch.arange(1, H + 1, dtype=phase.dtype)
+    order = torch.arange(1, H + 1, dtype=phase.dtype, device=phase.device)
     amp = amp * ((f0_frames * order < sr / 2).float() + 1e-7)                                      # core.py:73-77
     sinus = 0.
     for lo in range(0, H, chunk):                                                                  # :588-594
