@@ -23,7 +23,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
   cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
                          on this host's cores over a bounded sample of the same workload (N=1 only)
-  cpu_baseline_aten_chain  the reference's op chain walked with torch CPU operators (oracle/aten_chain.py), all cores
+  cpu_baseline_aten_chain  the reference's op chain walked with torch CPU operators (oracle/aten_chain.py), all cores;
+                           .same_chain_on_gpu: the same chain with its tensors on the GPU (PyTorch-ROCm), full workload
   value_module_mode      the drop-in module with a stand-in Unit2Control producing the controls on the GPU (control mode (i))
 """
 import argparse

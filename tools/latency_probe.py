@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Small-shape latency of the DSP tails (the real-time / streaming use: B = 1, a fraction of a second per call): our launches
+as they are, the same step replayed from a captured HIP graph (torch.cuda.CUDAGraph: the C ABI launches on the capturing
+stream and never allocates or synchronises, so it can be captured as is), and the reference's op chain under PyTorch-ROCm."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from ddsp_svc_amd import synth
+
+dev = torch.device("cuda:0")
+SR, HOP = 44100, 512
+
+
+def timeit(fn, reps=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+for kind in ("combsub", "sins", "combsubsuperfast"):
+    for B, seconds in ((1, 0.25), (1, 1.0), (4, 2.0)):
+        F = int(seconds * SR) // HOP + 1
+        step, inp = bench.build_step(kind, B, F, 256, dev, seed=7)
+        us = timeit(step)
+        # one synchronised call: launch-to-result latency
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        lat_us = sorted(lat)[len(lat) // 2] * 1e6
+        line = "%-17s B=%d %.2f s (F=%d): %.1f us per step back to back, %.1f us call-to-result" % (kind, B, seconds, F, us, lat_us)
+        try:
+            os.environ.setdefault("DDSP_HIP_ONE_STREAM", "1")
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph):
+                out = step()
+            ref = step()
+            graph.replay()
+            torch.cuda.synchronize()
+            same = bool(torch.equal(out, ref))
+            gus = timeit(graph.replay)
+            lat = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            line += "; graph replay %.1f us back to back, %.1f us call-to-result, same bits %s" % (gus, sorted(lat)[len(lat) // 2] * 1e6, same)
+        except Exception as e:
+            line += "; graph capture failed: %s: %s" % (type(e).__name__, str(e)[:120])
+        print(line, flush=True)
