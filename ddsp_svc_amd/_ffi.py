@@ -72,8 +72,9 @@ SIGNATURES = {
     "ddsp_hip_stft_loss_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddsp_hip_stft_loss": (c_int, [P, P, c_int, c_int, c_long, c_int, c_int, P, c_float, c_float, c_float, P, c_size_t,
                                    P, P, P, P, P]),
-    "ddsp_hip_stft_loss_backward": (c_int, [P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, P, c_int, P,
-                                            c_long, c_int, P]),
+    "ddsp_hip_stft_loss_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddsp_hip_stft_loss_backward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_float, c_float, c_float, P, c_int, P,
+                                            c_long, c_int, P, c_size_t, P]),
     "ddsp_hip_mel_frames": (c_int, [c_int, c_int, c_int]),
     "ddsp_hip_mel_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_float, P,
                                          c_long, c_long, c_long, P]),

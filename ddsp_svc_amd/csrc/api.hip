@@ -717,16 +717,25 @@ int ddsp_hip_stft_loss(const float* x_true, const float* x_pred, int B, int T, l
   return finish();
 }
 
-int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft,
+size_t ddsp_hip_stft_loss_backward_ws_bytes(int B, int T, int n_fft, int hop) {
+  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, hop);
+  if (B < 1 || frames < 1 || !czt_plan(n_fft) || hop > n_fft) return 0;
+  return sss_wave_bwd_ws_bytes(B, n_fft, hop, frames);
+}
+
+int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft, int hop,
                                 const float* tables, const float* norms, float inv_window_norm, float eps, float alpha,
-                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate,
-                                void* stream) {
+                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream) {
   if (B < 1 || T < 1 || ld_dx < T || !(inv_window_norm > 0.f)) return DDSP_HIP_EINVAL;
   if (!spec_true || !spec_pred || !tables || !norms || !grad_out || !d_x) return DDSP_HIP_EINVAL;
-  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, n_fft);
-  if (!czt_plan(n_fft) || frames < 1) return DDSP_HIP_ESHAPE;
-  if (launch_sss_wave_bwd(spec_true, spec_pred, B, T, n_fft, frames, tables, norms, inv_window_norm, eps, alpha, grad_out,
-                          wrt_true ? 1 : 0, d_x, ld_dx, accumulate ? 1 : 0, S(stream)) != 0)
+  const int frames = ddsp_hip_stft_loss_frames(T, n_fft, hop);
+  if (!czt_plan(n_fft) || frames < 1 || hop > n_fft) return DDSP_HIP_ESHAPE;
+  const size_t need = sss_wave_bwd_ws_bytes(B, n_fft, hop, frames);
+  if (need && (!ws || ws_bytes < need)) return DDSP_HIP_EWS;
+  if (need && (reinterpret_cast<uintptr_t>(ws) & 15)) return DDSP_HIP_EINVAL;
+  if (launch_sss_wave_bwd(spec_true, spec_pred, B, T, n_fft, hop, frames, tables, norms, inv_window_norm, eps, alpha, grad_out,
+                          wrt_true ? 1 : 0, d_x, ld_dx, accumulate ? 1 : 0, (float*)ws, S(stream)) != 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }

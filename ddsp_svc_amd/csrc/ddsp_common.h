@@ -176,6 +176,18 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
          (__int_as_float(__builtin_amdgcn_readlane(x, 32)) + __int_as_float(__builtin_amdgcn_readlane(x, 48)));
 }
 
+// maximum over the 64 lanes, the same way
+__device__ __forceinline__ unsigned wave_max_dpp(unsigned v) {
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+  v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+  const int x = (int)v;
+  return mx(mx((unsigned)__builtin_amdgcn_readlane(x, 0), (unsigned)__builtin_amdgcn_readlane(x, 16)),
+            mx((unsigned)__builtin_amdgcn_readlane(x, 32), (unsigned)__builtin_amdgcn_readlane(x, 48)));
+}
+
 // torch.sinc on a float32 tensor: sin(p) / p with p = fl32(pi32 * z), 1 at z == 0 (vocoder.py:839, :649).
 // |p| < 2: the Taylor series in p^2 to p^12 (truncation 1.2e-8); beyond, the hardware sine (two-constant reduction
 // of the float32 p to revolutions, v_sin_f32: abs error <= 3.9e-7) times v_rcp_f32, i.e. error <= 2e-7 / |p|.

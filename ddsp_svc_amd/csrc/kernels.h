@@ -86,7 +86,8 @@ size_t sss_wave_scratch_bytes(int B, int n, int frames);
 int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int hop, int frames, const float* tab,
                     float inv_wn, float eps, float alpha, double* scratch, float* spec_t, float* spec_p, float* norms,
                     float* loss, hipStream_t st);
-int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int frames, const float* tab,
+size_t sss_wave_bwd_ws_bytes(int B, int n, int hop, int frames);
+int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int hop, int frames, const float* tab,
                         const float* norms, float inv_wn, float eps, float alpha, const float* grad_out, int wrt_true,
-                        float* dx, long ld_dx, int accumulate, hipStream_t st);
+                        float* dx, long ld_dx, int accumulate, float* ws, hipStream_t st);
 }  // namespace ddsp

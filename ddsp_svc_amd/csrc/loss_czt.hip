@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
   __shared__ double red[3][R];
   __shared__ int live[2][2][3];                              // [pass parity][frame of the pair][true, pred: a nonzero sample; the two differ]
+  __shared__ unsigned peak[2][2][2];                         // [pass parity][frame][true, pred]: float bits of the largest windowed |sample|
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, b = blockIdx.y;
   const int bins = n / 2 + 1;
@@ -147,6 +148,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
   const float scale = 0.5f / (float)N;                       // the inverse transform's 1/N and the 1/2 of the split
   double d2 = 0.0, s2 = 0.0, l1 = 0.0;
   if (tid < 12) (&live[0][0][0])[tid] = 0;
+  if (tid < 8) (&peak[0][0][0])[tid] = 0u;
   f32x2 wcr[4];                                              // window times chirp of this thread's four samples
 #pragma unroll
   for (int n1 = 0; n1 < 4; ++n1) wcr[n1] = P * n1 + tid < n ? wc[P * n1 + tid] : f32x2{0.f, 0.f};
@@ -166,10 +168,46 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
       }
     }
   };
-  if (f_lo < f_hi) fetch(f_lo);
+  // The two signals share one transform, so each spectrum carries the other's rounding noise -- 1e-7 of the LARGER one,
+  // where separate transforms (the reference) err by 1e-7 of each signal's own size: a quiet prediction against a loud
+  // target would lose digits exactly where the loss weighs 1 / S_pred.  So the prediction enters the transform times a
+  // power of two that brings its peak to the target's (exact both ways), found per frame one pass ahead: the next pair's
+  // samples are in registers long before they are used.
+  auto note_peaks = [&](int par_next) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float mt = 0.f, mq = 0.f;
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) {                       // peaks BEHIND the window (wcr = 0 behind the frame's end)
+        const float wabs = fabsf(wcr[n1].x) + fabsf(wcr[n1].y);
+        mt = fmaxf(mt, fabsf(na[h][n1]) * wabs);
+        mq = fmaxf(mq, fabsf(nq[h][n1]) * wabs);
+      }
+      const unsigned ut = wave_max_dpp(__float_as_uint(mt)), uq = wave_max_dpp(__float_as_uint(mq));
+      if (lane == 0) {
+        atomicMax(&peak[par_next][h][0], ut);
+        atomicMax(&peak[par_next][h][1], uq);
+      }
+    }
+  };
+  __syncthreads();                                           // the zeroed flags and peaks
+  if (f_lo < f_hi) {
+    fetch(f_lo);
+    note_peaks(0);
+  }
   __syncthreads();
   for (int f = f_lo, par = 0; f < f_hi; f += 2, par ^= 1) {
     f32x2 v[2][8], co[4];
+    float up[2], down[2];                                    // 2^d and 2^-d, d = exponent of the target's peak - the prediction's
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned pt = peak[par][h][0], pq = peak[par][h][1];
+      int d = (int)((pt >> 23) & 0xff) - (int)((pq >> 23) & 0xff);
+      d = (pt == 0u || pq == 0u) ? 0 : (d > 60 ? 60 : (d < -60 ? -60 : d));
+      up[h] = __uint_as_float((unsigned)(127 + d) << 23);
+      down[h] = __uint_as_float((unsigned)(127 - d) << 23);
+    }
+    if (tid < 4) (&peak[par ^ 1][0][0])[tid] = 0u;           // the next pass's peaks; their writers are barriers away
     // The two signals share one transform, so each spectrum carries the other's rounding noise (1e-7 of ITS size).  A
     // frame that is all zero behind the window -- digital silence -- must come out as exact zeros (S = eps, and a zero
     // gradient at the origin, as the separate transforms of the reference give): such frames are flagged here and zeroed
@@ -180,9 +218,9 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
       bool any_t = false, any_p = false, differ = false;
 #pragma unroll
       for (int n1 = 0; n1 < 4; ++n1) {
-        const float a = na[h][n1], q = nq[h][n1];
+        const float a = na[h][n1], q = nq[h][n1], qs = q * up[h];
         const f32x2 w = wcr[n1];                             // 0 behind the frame's end
-        v[h][n1] = f32x2{a * w.x - q * w.y, a * w.y + q * w.x};
+        v[h][n1] = f32x2{a * w.x - qs * w.y, a * w.y + qs * w.x};
         any_t |= a * w.x != 0.f || a * w.y != 0.f;           // the WINDOWED sample: hann[0] = 0
         any_p |= q * w.x != 0.f || q * w.y != 0.f;
         differ |= P * n1 + tid < n && a != q;
@@ -194,13 +232,14 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
     if (tid < 6) (&live[par ^ 1][0][0])[tid] = 0;            // next pass's flags; its writers are barriers away
     if (f + 2 < f_hi) fetch(f + 2);
     czt_convolve2<R>(v[0], v[1], tw, bh, ch, co, ex[0], ex[1], ex[2], ex[3], tid, [] {});
+    if (f + 2 < f_hi) note_peaks(par ^ 1);                   // before the barrier below; read at the top of the next pass
     f32x2 z[2][3];
     float keep_t[2], keep_p[2];
     bool same[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                            // read BEFORE the barrier below: the next pass resets these flags
       keep_t[h] = live[par][h][0] ? 1.f : 0.f;
-      keep_p[h] = live[par][h][1] ? 1.f : 0.f;
+      keep_p[h] = live[par][h][1] ? down[h] : 0.f;               // ... and the prediction's spectrum back to its scale
       same[h] = !live[par][h][2];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -460,11 +499,43 @@ static void launch_bwd_r(dim3 grid, hipStream_t st, int wrt_true, const float2* 
                        alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate);
 }
 
-int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int frames, const float* tab,
+// Overlapping frames (hop < n): k_sss_czt_bwd leaves every frame's windowed gradient in a frame-major scratch, and each
+// sample gathers its up to ceil(n / hop) frames here -- in ascending frame order, so the sum is reproducible.
+__global__ void __launch_bounds__(256) k_frames_overlap_add(const float* __restrict__ fg, int frames, int n, int hop, int T,
+                                                            float* __restrict__ dx, long ld_dx, int accumulate) {
+  const int b = blockIdx.y;
+  const float* src = fg + (long)b * frames * n;
+  float* o = dx + (long)b * ld_dx;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+    int f_hi = t / hop;
+    if (f_hi > frames - 1) f_hi = frames - 1;
+    int f_lo = t - n + 1 <= 0 ? 0 : (t - n + hop) / hop;          // ceil((t - n + 1) / hop)
+    float acc = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) acc += src[(long)f * n + (t - f * hop)];
+    o[t] = accumulate ? o[t] + acc : acc;
+  }
+}
+
+size_t sss_wave_bwd_ws_bytes(int B, int n, int hop, int frames) {
+  return hop == n ? 0 : (size_t)B * frames * n * sizeof(float);
+}
+
+int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, int n, int hop, int frames, const float* tab,
                         const float* norms, float inv_wn, float eps, float alpha, const float* grad_out, int wrt_true,
-                        float* dx, long ld_dx, int accumulate, hipStream_t st) {
+                        float* dx, long ld_dx, int accumulate, float* ws, hipStream_t st) {
   const int R = czt_plan(n);
-  if (!R || B < 1 || B > 65535 || frames < 1 || (long)frames * n > T) return -1;
+  if (!R || B < 1 || B > 65535 || frames < 1 || hop < 1 || hop > n || (long)(frames - 1) * hop + n > T) return -1;
+  if (hop != n) {                                            // per-frame gradients into ws, then the gather
+    if (!ws || (long)frames * n >= (1L << 31)) return -1;
+    const int rc = launch_sss_wave_bwd(spec_t, spec_p, B, frames * n, n, n, frames, tab, norms, inv_wn, eps, alpha, grad_out,
+                                       wrt_true, ws, (long)frames * n, 0, nullptr, st);
+    if (rc != 0) return rc;
+    int gx = (T + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_frames_overlap_add, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, (const float*)ws, frames, n, hop,
+                       T, dx, ld_dx, accumulate);
+    return 0;
+  }
   const WaveGeom geo = sss_wave_geom(B, n, frames, true);
   const int chunks = geo.chunks;                                       // the kernel cuts the pairs of frames into as many spans
   const dim3 grid((unsigned)chunks, (unsigned)B);

@@ -2,14 +2,13 @@
 same constructors, same ``forward`` argument order (``SSSLoss(x_true, x_pred)``, ``RSSLoss(x_pred, x_true)``), same
 random draw of the transform sizes (``torch.randint``, :47).
 
-``RSSLoss`` draws arbitrary integer transform sizes, most of them with large prime factors.  With ``overlap = 0`` (the
-default, and what ``train.py`` uses) the whole loss runs in csrc/loss_czt.hip straight from the two waveforms: one
-chirp-z transform per frame carries both signals, the magnitudes and reductions follow in registers, and the backward
-pass is one more transform per two frames (``_WaveLossFunction``).  With overlapping frames the STFT stays with
-``torch.stft`` (rocFFT; plumbing) and everything behind it -- magnitudes, the window normalisation and eps of
-``Spectrogram(power=1, normalized=True)``, the two Frobenius norms per utterance, the log-L1 term, and in the backward
-pass the whole chain down to the gradient of the complex spectrum -- is one pass of csrc/loss.hip over the two spectra
-instead of ~10 eager kernels over ``[B, bins, frames]`` temporaries (``_SpectralLossFunction``)."""
+``RSSLoss`` draws arbitrary integer transform sizes, most of them with large prime factors.  The whole loss runs in
+csrc/loss_czt.hip straight from the two waveforms: one chirp-z transform per frame carries both signals, the magnitudes
+and reductions follow in registers, and the backward pass is one more transform per two frames (``_WaveLossFunction``;
+all scales of ``RSSLoss`` as one autograd node, ``_RandomScaleWaveLossFunction``).  With ``overlap = 0`` (the default,
+and what ``train.py`` uses) the frames' gradients are the signal's; with overlapping frames a second kernel gathers
+them per sample.  ``torch.stft`` + the fused reductions of csrc/loss.hip (``_SpectralLossFunction``) remain for what the
+plans do not cover -- transform sizes above 2048 -- and behind ``DDSP_HIP_LOSS_TORCH_STFT=1`` for A/B measurements."""
 import torch
 
 from . import _ffi
@@ -93,10 +92,10 @@ def _czt_tables(n_fft, like):
 
 
 class _WaveLossFunction(torch.autograd.Function):
-    """loss.py:22-31 INCLUDING the two spectrograms, for hop == n_fft (csrc/loss_czt.hip)."""
+    """loss.py:22-31 INCLUDING the two spectrograms (csrc/loss_czt.hip), any 1 <= hop <= n_fft."""
 
     @staticmethod
-    def forward(ctx, x_true, x_pred, n_fft, inv_window_norm, eps, alpha, tables):
+    def forward(ctx, x_true, x_pred, n_fft, hop, inv_window_norm, eps, alpha, tables):
         _ffi.check_device(x_true, x_pred)
         xt, xp = x_true.detach(), x_pred.detach()
         if xt.stride(1) != 1 or xp.stride(1) != 1 or xt.stride(0) != xp.stride(0):
@@ -104,39 +103,41 @@ class _WaveLossFunction(torch.autograd.Function):
         B, T = xt.shape
         lib = _ffi.lib()
         dev = xt.device
-        frames = lib.ddsp_hip_stft_loss_frames(T, n_fft, n_fft)
+        frames = lib.ddsp_hip_stft_loss_frames(T, n_fft, hop)
         spec = torch.empty(2, B, frames, n_fft // 2 + 1, dtype=torch.complex64, device=dev)
-        nbytes = lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n_fft, n_fft)
+        nbytes = lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n_fft, hop)
         scratch = torch.empty(max(nbytes, 8) // 8, dtype=torch.float64, device=dev)
         norms = torch.empty(B, 2, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n_fft, n_fft, ptr(tables),
+        _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n_fft, hop, ptr(tables),
                                           float(inv_window_norm), float(eps), float(alpha), ptr(scratch), nbytes,
                                           ptr(spec[0]), ptr(spec[1]), ptr(norms), ptr(loss), _ffi.stream_of(xt)))
         ctx.save_for_backward(spec, norms, tables)
-        ctx.cfg = (B, T, int(n_fft), float(inv_window_norm), float(eps), float(alpha))
+        ctx.cfg = (B, T, int(n_fft), int(hop), float(inv_window_norm), float(eps), float(alpha))
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         spec, norms, tables = ctx.saved_tensors
-        B, T, n_fft, inv_wn, eps, alpha = ctx.cfg
+        B, T, n_fft, hop, inv_wn, eps, alpha = ctx.cfg
         go = grad_out.detach().to(torch.float32).contiguous()
         lib = _ffi.lib()
+        ws_bytes = lib.ddsp_hip_stft_loss_backward_ws_bytes(B, T, n_fft, hop)      # overlapping frames: their gradients, then a gather
+        ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=spec.device)
         grads = [None, None]
         for which in (0, 1):                                         # 0: true, 1: pred
             if not ctx.needs_input_grad[which]:
                 continue
             d = torch.empty(B, T, dtype=torch.float32, device=spec.device)
-            _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tables), ptr(norms),
+            _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, hop, ptr(tables), ptr(norms),
                                                        inv_wn, eps, alpha, ptr(go), 1 if which == 0 else 0, ptr(d), T, 0,
-                                                       _ffi.stream_of(spec)))
+                                                       ptr(ws), ws_bytes, _ffi.stream_of(spec)))
             grads[which] = d
-        return grads[0], grads[1], None, None, None, None, None
+        return grads[0], grads[1], None, None, None, None, None, None
 
 
 class _RandomScaleWaveLossFunction(torch.autograd.Function):
-    """RSSLoss.forward (loss.py:46-54) for non-overlapping frames as ONE autograd node: the scales' kernels back to back,
+    """RSSLoss.forward (loss.py:46-54) as ONE autograd node: the scales' kernels back to back,
     their losses averaged on the device, and in the backward pass each scale's kernel adding into the one gradient
     buffer -- instead of n_scale nodes, n_scale [B, T] temporaries and the adds between them."""
 
@@ -151,13 +152,13 @@ class _RandomScaleWaveLossFunction(torch.autograd.Function):
         dev = xt.device
         losses = torch.empty(len(scales), dtype=torch.float32, device=dev)
         norms = torch.empty(len(scales), B, 2, dtype=torch.float32, device=dev)
-        nbytes = max(lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n, n) for n, _ in scales)
+        nbytes = max(lib.ddsp_hip_stft_loss_scratch_bytes(B, T, n, hop) for n, hop, _ in scales)
         scratch = torch.empty(max(nbytes, 8) // 8, dtype=torch.float64, device=dev)   # the scales run in stream order
         specs = []
-        for i, ((n, inv_wn), tab) in enumerate(zip(scales, tables)):
-            frames = lib.ddsp_hip_stft_loss_frames(T, n, n)
+        for i, ((n, hop, inv_wn), tab) in enumerate(zip(scales, tables)):
+            frames = lib.ddsp_hip_stft_loss_frames(T, n, hop)
             spec = torch.empty(2, B, frames, n // 2 + 1, dtype=torch.complex64, device=dev)
-            _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n, n, ptr(tab), inv_wn, float(eps),
+            _ffi.check(lib.ddsp_hip_stft_loss(ptr(xt), ptr(xp), B, T, xt.stride(0), n, hop, ptr(tab), inv_wn, float(eps),
                                               float(alpha), ptr(scratch), nbytes, ptr(spec[0]), ptr(spec[1]),
                                               ptr(norms[i]), ptr(losses[i:]), _ffi.stream_of(xt)))
             specs.append(spec)
@@ -172,15 +173,17 @@ class _RandomScaleWaveLossFunction(torch.autograd.Function):
         norms, specs, tables = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:]
         go = (grad_out.detach().to(torch.float32) / k).contiguous()
         lib = _ffi.lib()
+        ws_bytes = max(lib.ddsp_hip_stft_loss_backward_ws_bytes(B, T, n, hop) for n, hop, _ in scales)
+        ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=norms.device)
         grads = [None, None]
         for which in (0, 1):                                         # 0: true, 1: pred
             if not ctx.needs_input_grad[which]:
                 continue
             d = torch.empty(B, T, dtype=torch.float32, device=norms.device)
-            for i, ((n, inv_wn), spec, tab) in enumerate(zip(scales, specs, tables)):
-                _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n, ptr(tab), ptr(norms[i]),
+            for i, ((n, hop, inv_wn), spec, tab) in enumerate(zip(scales, specs, tables)):
+                _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n, hop, ptr(tab), ptr(norms[i]),
                                                            inv_wn, eps, alpha, ptr(go), 1 if which == 0 else 0, ptr(d), T,
-                                                           1 if i else 0, _ffi.stream_of(norms)))
+                                                           1 if i else 0, ptr(ws), ws_bytes, _ffi.stream_of(norms)))
             grads[which] = d
         return (grads[0], grads[1], None, None, None) + (None,) * k
 
@@ -229,12 +232,12 @@ class SSSLoss(torch.nn.Module):
             raise ValueError("x_true and x_pred must have the same shape")
         x_true = x_true.reshape(-1, x_true.shape[-1]) if x_true.dim() != 2 else x_true
         x_pred = x_pred.reshape(-1, x_pred.shape[-1]) if x_pred.dim() != 2 else x_pred
-        if self.hop_length == self.n_fft and x_true.shape[-1] >= self.n_fft and x_true.shape[-1] < 2 ** 31 \
+        if 1 <= self.hop_length <= self.n_fft and x_true.shape[-1] >= self.n_fft and x_true.shape[-1] < 2 ** 31 \
                 and x_true.shape[0] <= 65535 and not _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT"):
             tables = _czt_tables(self.n_fft, x_pred)
             if tables is not None:
                 return _WaveLossFunction.apply(x_true.to(torch.float32), x_pred.to(torch.float32), self.n_fft,
-                                               self.spec.inv_window_norm, self.eps, self.alpha, tables)
+                                               self.hop_length, self.spec.inv_window_norm, self.eps, self.alpha, tables)
         return _SpectralLossFunction.apply(self.spec(x_true.to(torch.float32)), self.spec(x_pred.to(torch.float32)),
                                            self.spec.inv_window_norm, self.eps, self.alpha)
 
@@ -259,9 +262,10 @@ class RSSLoss(torch.nn.Module):
         return f
 
     def _fused(self, x_pred, x_true, sizes):
-        """All scales in one autograd node when every one of them takes the in-kernel transform (overlap 0, sizes the
-        chirp-z plans cover, signals of at least one frame); None otherwise."""
-        if int(max(sizes) * (1 - self.overlap)) != max(sizes) or int(min(sizes) * (1 - self.overlap)) != min(sizes):
+        """All scales in one autograd node when every one of them takes the in-kernel transform (sizes the chirp-z plans
+        cover, hops of at least one sample, signals of at least one frame); None otherwise."""
+        hops = [int(n * (1 - self.overlap)) for n in sizes]                      # loss.py:19
+        if any(h < 1 or h > n for h, n in zip(hops, sizes)):
             return None
         if _ffi._env_flag("DDSP_HIP_LOSS_TORCH_STFT") or x_true.shape != x_pred.shape:
             return None
@@ -274,7 +278,7 @@ class RSSLoss(torch.nn.Module):
         tables = [_czt_tables(n, xp) for n in sizes]
         if any(t is None for t in tables):
             return None
-        scales = tuple((n, self._scale(n, xp.device).spec.inv_window_norm) for n in sizes)
+        scales = tuple((n, h, self._scale(n, xp.device).spec.inv_window_norm) for n, h in zip(sizes, hops))
         return _RandomScaleWaveLossFunction.apply(xt, xp, scales, self.eps, self.alpha, *tables)
 
     def forward(self, x_pred, x_true):

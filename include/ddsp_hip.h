@@ -315,14 +315,16 @@ size_t ddsp_hip_stft_loss_scratch_bytes(int B, int T, int n_fft, int hop);
 int ddsp_hip_stft_loss(const float* x_true, const float* x_pred, int B, int T, long ld, int n_fft, int hop,
                        const float* tables, float inv_window_norm, float eps, float alpha, void* scratch,
                        size_t scratch_bytes, float* spec_true, float* spec_pred, float* norms, float* loss, void* stream);
-/* d loss / d x_pred (wrt_true = 0) or d x_true (1) for hop == n_fft (the frames do not overlap: overlap = 0, the
- * configuration of RSSLoss, loss.py:40), times grad_out[0]: d_x[B, T] with row stride ld_dx, every sample written (those
- * behind the last whole frame with 0); accumulate != 0: added to what d_x holds instead (the scales of RSSLoss summed
- * without a temporary each). */
-int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft,
+/* d loss / d x_pred (wrt_true = 0) or d x_true (1), times grad_out[0]: d_x[B, T] with row stride ld_dx, every sample written
+ * (those no frame reaches with 0); accumulate != 0: added to what d_x holds instead (the scales of RSSLoss summed without
+ * a temporary each).  hop == n_fft (overlap = 0, the configuration of RSSLoss, loss.py:40): no workspace.  hop < n_fft
+ * (overlapping frames): ws of ddsp_hip_stft_loss_backward_ws_bytes(B, T, n_fft, hop) bytes, 16-byte aligned, receives the
+ * frames' gradients, which a second kernel gathers per sample in ascending frame order (reproducible). */
+size_t ddsp_hip_stft_loss_backward_ws_bytes(int B, int T, int n_fft, int hop);
+int ddsp_hip_stft_loss_backward(const float* spec_true, const float* spec_pred, int B, int T, int n_fft, int hop,
                                 const float* tables, const float* norms, float inv_window_norm, float eps, float alpha,
-                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate,
-                                void* stream);
+                                const float* grad_out, int wrt_true, float* d_x, long ld_dx, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,8 @@ def test_random_spectral_tails(dev, seed, knobs):
 @pytest.mark.parametrize("seed", range(4))
 def test_random_scale_loss(dev, seed, knobs):
     """RSSLoss as the reference draws it (loss.py:47) on random batch sizes and lengths -- exactly one frame, odd frame
-    counts, a tail shorter than a frame, strided inputs, several rounds of workgroups -- against the oracle's float64
+    counts, a tail shorter than a frame, overlapping frames, strided inputs, several rounds of workgroups -- against the
+    oracle's float64
     loss and analytic gradient.  eps = 1e-5 keeps the comparison away from the sign flips of bins at the rounding floor
     (tests/test_loss.py has the eps = 1e-7 cases)."""
     from ddsp_svc_amd import loss as L
@@ -92,7 +93,10 @@ def test_random_scale_loss(dev, seed, knobs):
         xt = torch.from_numpy(a).to(dev)[:, ::2] if strided else torch.from_numpy(np.ascontiguousarray(a[:, ::2])).to(dev)
         xp = (torch.from_numpy(b).to(dev)[:, ::2] if strided else torch.from_numpy(np.ascontiguousarray(b[:, ::2])).to(dev))
         xp = xp.detach().requires_grad_(True)
-        rss = L.RSSLoss(2, 2048, len(sizes), eps=1e-5, device=dev)
+        overlap = float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.75]))
+        if overlap:
+            sizes = [max(s, 8) for s in sizes]
+        rss = L.RSSLoss(2, 2048, len(sizes), overlap=overlap, eps=1e-5, device=dev)
         real = torch.randint
         torch.randint = lambda *args, **kw: torch.tensor(sizes)
         try:
@@ -102,7 +106,7 @@ def test_random_scale_loss(dev, seed, knobs):
         assert "RandomScaleWaveLoss" in type(value.grad_fn).__name__
         grad, = torch.autograd.grad(value, xp)
         at, bt = a[:, ::2], b[:, ::2]
-        want = np.mean([O.sss_loss(at, bt, n, 1.0, 0.0, eps=1e-5) for n in sizes])
-        gwant = np.mean([O.sss_loss_backward(at, bt, n, 1.0, 0.0, eps=1e-5) for n in sizes], axis=0)
-        assert abs(float(value.detach()) - want) <= 2e-5 * want, (B, T, sizes, strided)
-        assert _rms(grad.cpu().numpy() - gwant) <= 2e-4 * _rms(gwant), (B, T, sizes, strided)
+        want = np.mean([O.sss_loss(at, bt, n, 1.0, overlap, eps=1e-5) for n in sizes])
+        gwant = np.mean([O.sss_loss_backward(at, bt, n, 1.0, overlap, eps=1e-5) for n in sizes], axis=0)
+        assert abs(float(value.detach()) - want) <= 2e-5 * want, (B, T, sizes, strided, overlap)
+        assert _rms(grad.cpu().numpy() - gwant) <= 2e-4 * _rms(gwant), (B, T, sizes, strided, overlap)

@@ -130,6 +130,7 @@ def test_in_kernel_transform_parts(dev, n_fft):
     a[0, n_fft:2 * n_fft] = 0.0                                           # a silent frame of the truth
     b[1, 2 * n_fft:3 * n_fft] = 0.0                                       # ... of the prediction
     b[1, 3 * n_fft:4 * n_fft] = a[1, 3 * n_fft:4 * n_fft]                 # an equal pair of frames
+    b[0, 4 * n_fft:5 * n_fft] *= 1e-4                                     # a prediction 80 dB below its target
     xt, xp = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     f = L.SSSLoss(n_fft)
     tab = L._czt_tables(n_fft, xt)
@@ -149,6 +150,8 @@ def test_in_kernel_transform_parts(dev, n_fft):
     for got, x in ((got_t, a), (got_p, b)):
         want = X64(x)
         assert np.abs(got - want).max() <= 5e-7 * np.abs(want).max()
+    quiet = X64(b)[0, 4]                                                  # ... is accurate to ITS size, as a transform of its own
+    assert np.abs(got_p[0, 4] - quiet).max() <= 2e-6 * np.abs(quiet).max()
     assert not got_t[0, 1].any() and not got_p[1, 2].any()                # silence is exact
     assert np.array_equal(got_t[1, 3], got_p[1, 3])                       # equal frames, equal spectra
     St, Sp = np.abs(X64(a)) * inv + 1e-7, np.abs(X64(b)) * inv + 1e-7
@@ -164,14 +167,14 @@ def test_in_kernel_transform_parts(dev, n_fft):
         Xr = torch.fft.rfft(xx[:, :frames * n_fft].reshape(B, frames, n_fft) * torch.from_numpy(w), dim=-1)
         Xr.backward(G.cpu().to(torch.complex128))
         d = torch.full((B, T), 7.0, device=dev)
-        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
-                                                   1.0, ptr(go), wrt_true, ptr(d), T, 0, _ffi.stream_of(xt)))
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), wrt_true, ptr(d), T, 0, None, 0, _ffi.stream_of(xt)))
         ref = xx.grad.numpy()
         assert _rel_rms(d.cpu().numpy(), ref) <= 1e-6
         assert not d.cpu().numpy()[:, frames * n_fft:].any()              # the tail is written, with zeros
         d2 = d.clone()
-        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
-                                                   1.0, ptr(go), wrt_true, ptr(d2), T, 1, _ffi.stream_of(xt)))
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), wrt_true, ptr(d2), T, 1, None, 0, _ffi.stream_of(xt)))
         assert torch.equal(d2, d + d)
     assert lib.ddsp_hip_stft_loss_table_bytes(2049) == 0 and lib.ddsp_hip_stft_loss_table_bytes(1) == 0
 
@@ -235,12 +238,12 @@ def test_full_size_against_eager_composition():
         xx = xp.detach().double().requires_grad_(True)
         X64(xx).backward(G.to(torch.complex128))
         d = torch.empty(B, T, device=dev)
-        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
-                                                   1.0, ptr(go), 0, ptr(d), T, 0, _ffi.stream_of(xt)))
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), 0, ptr(d), T, 0, None, 0, _ffi.stream_of(xt)))
         assert float((d - xx.grad).pow(2).mean().sqrt() / xx.grad.pow(2).mean().sqrt()) <= 1e-6
         d2 = d.clone()                                                  # accumulate: exactly twice
-        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
-                                                   1.0, ptr(go), 0, ptr(d2), T, 1, _ffi.stream_of(xt)))
+        _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
+                                                   1.0, ptr(go), 0, ptr(d2), T, 1, None, 0, _ffi.stream_of(xt)))
         assert torch.equal(d2, d + d)
 
 

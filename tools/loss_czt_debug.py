@@ -49,8 +49,8 @@ for n in (256, 397, 768, 1153, 2047):
     xx = xp.detach().double().requires_grad_(True)
     X64(xx).backward(G.to(torch.complex128))
     d = torch.empty(B, T, device=dev)
-    _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n, ptr(tab), ptr(norms), inv, 1e-7, 1.0,
-                                               ptr(go), 0, ptr(d), T, 0, _ffi.stream_of(xt)))
+    _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n, n, ptr(tab), ptr(norms), inv, 1e-7, 1.0,
+                                               ptr(go), 0, ptr(d), T, 0, None, 0, _ffi.stream_of(xt)))
     e = (d - xx.grad).pow(2).mean().sqrt() / xx.grad.pow(2).mean().sqrt()
     print(n, "backward transform alone: relrms %.2e, worst utterance %.2e" % (
         float(e), float(((d - xx.grad).pow(2).mean(1).sqrt() / xx.grad.pow(2).mean(1).sqrt()).max())), flush=True)
