@@ -262,6 +262,34 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   constexpr int STEP = ST_HOP / P;                             // slots between the two frames of a pair
   // the waves that share a SIMD (of different workgroups) take turns at its arbiter's priority, pair by pair (fir_blk.hip)
   const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
+  // raw samples of the NEXT frame (exciter, noise): fetched while the current frame is transformed -- consumed where they
+  // were issued, their latency sat on every frame with only the SIMD's other wave to hide it
+  float ne[S], nu[S];
+  auto fetch_frame = [&](int j) {
+    const int s0 = j * ST_HOP - PAD;
+    if (s0 >= 0 && s0 + N <= g.T) {                              // interior frame (wave-uniform)
+      const float* ef = eb + s0 + tid;
+      const float* nf = nb + s0 + tid;
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        ne[m] = ef[P * m];
+        nu[m] = nf[P * m];
+      }
+    } else {                                                     // clamped (and reflected) addresses; masked where they are used
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        int i = s0 + P * m + tid;
+        if (g.reflect) {
+          if (i < 0) i = -i;
+          if (i >= g.T) i = 2 * (g.T - 1) - i;
+        }
+        i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
+        ne[m] = eb[i];
+        nu[m] = nb[i];
+      }
+    }
+  };
+  fetch_frame(2 * pr0);
   for (int pr = pr0; pr < p_last; ++pr) {
     if ((pr + turn) & 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
@@ -295,41 +323,27 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
           np_[m] = c_nphase[rb * g.ld_np + k];
         }
       }
-      // windowed input frame: exciter in the real, noise in the imaginary part
+      // windowed input frame: exciter in the real, noise in the imaginary part -- from the samples fetched one frame ago
       f32x2 z[S];
       const int s0 = j * ST_HOP - PAD;
       if (s0 >= 0 && s0 + N <= g.T) {                            // interior frame (wave-uniform): no edge handling
-        const float* ef = eb + s0 + tid;
-        const float* nf = nb + s0 + tid;
 #pragma unroll
         for (int m = 0; m < S; ++m) {
-          const float e = ef[P * m];
-          float u = nf[P * m];
+          float u = nu[m];
           if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
-          z[m] = f32x2{w[m] * e, w[m] * u};
+          z[m] = f32x2{w[m] * ne[m], w[m] * u};
         }
       } else {
-        float ev[S], uv[S];
-#pragma unroll
-        for (int m = 0; m < S; ++m) {
-          int i = s0 + P * m + tid;
-          if (g.reflect) {
-            if (i < 0) i = -i;
-            if (i >= g.T) i = 2 * (g.T - 1) - i;
-          }
-          i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
-          ev[m] = eb[i];
-          uv[m] = nb[i];
-        }
 #pragma unroll
         for (int m = 0; m < S; ++m) {
           const int i = s0 + P * m + tid;
           const bool ok = live && (g.reflect || (i >= 0 && i < g.T));
-          float u = uv[m];
+          float u = nu[m];
           if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
-          z[m] = f32x2{ok ? w[m] * ev[m] : 0.f, ok ? w[m] * u : 0.f};
+          z[m] = f32x2{ok ? w[m] * ne[m] : 0.f, ok ? w[m] * u : 0.f};
         }
       }
+      fetch_frame(j + 1);                                        // in flight during this frame's transform
       f32x2* A = ex[cur];
       f32x2* Bx = ex[cur ^ 1];
       cur ^= 1;
@@ -519,11 +533,36 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
     for (int m = 0; m < S; ++m) Bx[P * m + tid] = z[m];
     __syncthreads();
   };
-  // windowed cotangent of frame jj at slot m: w * grad / env, zero outside the cropped range
-  auto gamma = [&](int jj, int m) -> float {
+  // Raw inputs of the NEXT stage -- the two cotangent frames of a pair, or a frame's exciter and noise samples -- fetched
+  // while the current stage's transform runs (consumed where they were issued, their latency sat on each of the three
+  // stages of a pair).  Clamped (and reflected) addresses; masked where they are used.
+  float pf0[S], pf1[S];
+  auto fetch_cotangent = [&](int ja) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const int t = ja * ST_HOP - PAD + P * m + tid, t1 = t + ST_HOP;
+      pf0[m] = gb[t < 0 ? 0 : (t >= g.T ? g.T - 1 : t)];
+      pf1[m] = gb[t1 < 0 ? 0 : (t1 >= g.T ? g.T - 1 : t1)];
+    }
+  };
+  auto fetch_frame = [&](int jj) {
+    const int s0 = jj * ST_HOP - PAD;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      int i = s0 + P * m + tid;
+      if (g.reflect) {
+        if (i < 0) i = -i;
+        if (i >= g.T) i = 2 * (g.T - 1) - i;
+      }
+      i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
+      pf0[m] = eb[i];
+      pf1[m] = nb[i];
+    }
+  };
+  // windowed cotangent of frame jj at slot m from its raw value: w * grad / env, zero outside the cropped range
+  auto gamma = [&](int jj, int m, float v) -> float {
     const int t = jj * ST_HOP - PAD + P * m + tid;
     const bool ok = jj <= g.F && t >= 0 && t < g.T;
-    float v = gb[t < 0 ? 0 : (t >= g.T ? g.T - 1 : t)];
     if (g.normalize) {
       float env = 0.f;
 #pragma unroll
@@ -536,11 +575,13 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
     }
     return ok ? w[m] * v : 0.f;
   };
-  // Gs = c_k / (4 N) * 2 Gamma for the thread's bins of frames ja (real part of the packed transform) and ja + 1
-  auto cotangent_pair = [&](int ja, f32x2 (&G0)[NB], f32x2 (&G1)[NB]) {
+  // Gs = c_k / (4 N) * 2 Gamma for the thread's bins of frames ja (real part of the packed transform) and ja + 1; the
+  // raw cotangent is in pf0 / pf1, and next() issues the following stage's fetch
+  auto cotangent_pair = [&](int ja, f32x2 (&G0)[NB], f32x2 (&G1)[NB], auto&& next) {
     f32x2 z[S];
 #pragma unroll
-    for (int m = 0; m < S; ++m) z[m] = f32x2{gamma(ja, m), gamma(ja + 1, m)};
+    for (int m = 0; m < S; ++m) z[m] = f32x2{gamma(ja, m, pf0[m]), gamma(ja + 1, m, pf1[m])};
+    next();
     transform(z);
 #pragma unroll
     for (int m = 0; m < NB; ++m) {
@@ -554,8 +595,9 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
       G1[m] = f32x2{d.y * c, edge ? 0.f : -d.x * c};            // d / i
     }
   };
-  // one frame: spectra of exciter and noise, filters, products, store (accumulate: add onto what this thread wrote)
-  auto frame = [&](int jj, const f32x2 (&Gs)[NB], bool accumulate) {
+  // one frame: spectra of exciter and noise (raw samples in pf0 / pf1), filters, products, store (accumulate: add onto what
+  // this thread wrote)
+  auto frame = [&](int jj, const f32x2 (&Gs)[NB], bool accumulate, auto&& next) {
     const int row = jj < g.F ? jj : g.F - 1;
     const long rb = (long)b * g.F + row;
     float hm[NB], hp[NB], nm[NB], np_[NB];
@@ -578,28 +620,15 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
     }
     f32x2 z[S];
     const int s0 = jj * ST_HOP - PAD;
-    {
-      float ev[S], uv[S];
 #pragma unroll
-      for (int m = 0; m < S; ++m) {
-        int i = s0 + P * m + tid;
-        if (g.reflect) {
-          if (i < 0) i = -i;
-          if (i >= g.T) i = 2 * (g.T - 1) - i;
-        }
-        i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
-        ev[m] = eb[i];
-        uv[m] = nb[i];
-      }
-#pragma unroll
-      for (int m = 0; m < S; ++m) {
-        const int i = s0 + P * m + tid;
-        const bool ok = g.reflect || (i >= 0 && i < g.T);
-        float u = uv[m];
-        if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
-        z[m] = f32x2{ok ? w[m] * ev[m] : 0.f, ok ? w[m] * u : 0.f};
-      }
+    for (int m = 0; m < S; ++m) {
+      const int i = s0 + P * m + tid;
+      const bool ok = g.reflect || (i >= 0 && i < g.T);
+      float u = pf1[m];
+      if (g.noise_u01) u = fmaf(2.0f, u, -1.0f);
+      z[m] = f32x2{ok ? w[m] * pf0[m] : 0.f, ok ? w[m] * u : 0.f};
     }
+    next();
     transform(z);
 #pragma unroll
     for (int m = 0; m < NB; ++m) {
@@ -634,20 +663,30 @@ k_stft_filter_bwd(const float* __restrict__ exc, const float* __restrict__ noise
     }
   };
 
+  if (p_first < p_last) fetch_cotangent(2 * p_first);
   for (int pr = p_first; pr < p_last; ++pr) {
     const int j0 = 2 * pr;
+    const bool last = pr == g.pairs - 1;                         // the utterance's last pair: frame F follows (see the head comment)
+    const bool more = pr + 1 < p_last;
     f32x2 G0[NB], G1[NB];
-    cotangent_pair(j0, G0, G1);
-    frame(j0, G0, false);
-    if (j0 + 1 < g.F) frame(j0 + 1, G1, false);
-    if (pr == g.pairs - 1) {
+    cotangent_pair(j0, G0, G1, [&] { fetch_frame(j0); });
+    if (j0 + 1 < g.F) {
+      frame(j0, G0, false, [&] { fetch_frame(j0 + 1); });
+      frame(j0 + 1, G1, false, [&] {
+        if (last) fetch_cotangent(g.F);
+        else if (more) fetch_cotangent(j0 + 2);
+      });
+    } else {                                                     // F odd: j0 = F - 1 is the last frame of its own
+      frame(j0, G0, false, [&] { fetch_frame(g.F); });
+    }
+    if (last) {
       // the repeated last frame F: its cotangent is G1 when F is odd (frame F = j0 + 1), else a transform of its own
       if (j0 + 1 == g.F) {
-        frame(g.F, G1, true);
+        frame(g.F, G1, true, [] {});
       } else {
         f32x2 GF[NB], Gdrop[NB];
-        cotangent_pair(g.F, GF, Gdrop);
-        frame(g.F, GF, true);
+        cotangent_pair(g.F, GF, Gdrop, [&] { fetch_frame(g.F); });
+        frame(g.F, GF, true, [] {});
       }
     }
   }
@@ -743,7 +782,12 @@ int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u0
   g.pairs = (F + 1) / 2;                                       // frames 0..F-1; frame F rides with the last pair
   g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
   g.ld_hm = ld_hm; g.ld_hp = ld_hp; g.ld_nm = ld_nm; g.ld_np = ld_np;
-  const int wg_per_cu = win == 2048 ? 3 : 4;                   // win 2048: 3 waves per SIMD measured faster (0.39 ms) than 2 (0.45 ms)
+  // waves per SIMD of the variant launched (knob STFT_WPS: 2 or 3 at win 2048).  With the next stage's inputs prefetched the
+  // register file is the limit: 2 waves per SIMD (25 spilled dwords) 0.745 ms per CombSubSuperFast training step, 3 waves
+  // (107 spilled) 0.93; before the prefetch 3 waves (54 spilled) were the faster ones, 0.778
+  int wps = 2;
+  if (win == 2048) { if (const long v = knob(KNOB_STFT_WPS)) { if (v == 2 || v == 3) wps = (int)v; } }
+  const int wg_per_cu = win == 2048 ? wps : 4;
   const long slots = (long)wg_per_cu * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
@@ -755,8 +799,11 @@ int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u0
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
-  if (win == 2048)
+  if (win == 2048 && wps == 3)
     hipLaunchKernelGGL((k_stft_filter_bwd<4, 3>), dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase,
+                       c_nmag, c_nphase, window, grad_out, d_hmag, d_hphase, d_nmag, d_nphase, g);
+  else if (win == 2048)
+    hipLaunchKernelGGL((k_stft_filter_bwd<4, 2>), dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase,
                        c_nmag, c_nphase, window, grad_out, d_hmag, d_hphase, d_nmag, d_nphase, g);
   else
     hipLaunchKernelGGL((k_stft_filter_bwd<2, 2>), dim3((unsigned)wgs), dim3(128), 0, st, exc, noise, c_hmag, c_hphase,

@@ -24,6 +24,9 @@ with_loss = len(sys.argv) > 2 and sys.argv[2] == "loss"
 if kind == "combsubsuperfast":
     f0, ctrls, noise = bench.make_inputs(kind, B, F, (1025,) * 4, dev, 1234)
     w = torch.hann_window(2048, device=dev)
+elif kind == "combsubfast":
+    f0, ctrls, noise = bench.make_inputs(kind, B, F, bench.model_sizes(kind, n), dev, 1234)
+    w = torch.sqrt(torch.hann_window(1024, device=dev))
 else:
     f0, ctrls, noise = bench.make_inputs(kind, B, F, (n, n, n), dev, 1234)
 c = [x.clone().requires_grad_(True) for x in ctrls]
@@ -50,6 +53,9 @@ def step():
     if kind == "combsubsuperfast":
         st = synth.fast_source(f0, 44100, 512)
         sig = synth.combsubsuperfast_synth(f0, st, c[0], c[1], c[2], c[3], noise, w, 44100, 512)
+    elif kind == "combsubfast":
+        st = synth.phase(f0, 44100, 512)
+        sig = synth.combsubfast_synth(f0, st, c[0], c[1], c[2], noise, w, 44100, 512)
     else:
         st = synth.phase(f0, 44100, 512)
         fn = synth.sins_synth if kind == "sins" else synth.combsub_synth
