@@ -270,3 +270,35 @@ def test_random_scale_loss_is_one_node_and_matches_its_scales():
     pgrad, = torch.autograd.grad(parts, xq)
     assert abs(float(loss.detach()) - float(parts.detach())) <= 1e-6 * float(parts.detach())
     assert float((grad - pgrad).abs().max()) <= 1e-6 * float(pgrad.abs().max())
+
+
+@pytest.mark.gpu
+def test_full_size_properties():
+    """B = 32 x 10 s, one size per transform plan (1024 / 2048 / 4096 points): what holds at any size without a second
+    implementation -- identical signals give exactly 0 (equal frames, equal spectra) and a zero gradient; negating both
+    signals changes neither the loss nor, up to its sign, any bit of the gradient (negation commutes with every rounding
+    of the transform); the gradient behind the last whole frame is zero; two evaluations agree bit for bit."""
+    from ddsp_svc_amd import loss as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xt = (torch.randn(32, 441344, generator=g) * 0.1).to(dev)
+    xp = (xt * 0.7 + 0.03 * torch.randn(32, 441344, generator=g).to(dev))
+    for n_fft, overlap in ((509, 0.0), (1021, 0.0), (2039, 0.0), (1021, 0.5)):
+        f = L.SSSLoss(n_fft, 1.0, overlap).to(dev)
+        a = xp.clone().requires_grad_(True)
+        same = f(a, a.detach())
+        assert float(same.detach()) == 0.0
+        la = f(xt, a)
+        ga, = torch.autograd.grad(la, a)
+        b = (-xp).requires_grad_(True)
+        lb = f(-xt, b)
+        gb, = torch.autograd.grad(lb, b)
+        assert torch.equal(la.detach(), lb.detach()) and torch.equal(ga, -gb)
+        c = xp.clone().requires_grad_(True)
+        lc = f(xt, c)
+        gc, = torch.autograd.grad(lc, c)
+        assert torch.equal(la.detach(), lc.detach()) and torch.equal(ga, gc)
+        hop = int(n_fft * (1 - overlap))
+        covered = (1 + (441344 - n_fft) // hop - 1) * hop + n_fft
+        assert torch.isfinite(ga).all() and float(ga[:, covered:].abs().max()) == 0.0
+        assert float(ga[:, :covered].abs().max()) > 0.0

@@ -4,7 +4,7 @@
 # per-kernel traces in one-stream order, SQ counters of the steps, training-step traces.  Every profiler run is bounded.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
-V=${V:-r03_v20}
+V=${V:-r03_v31}
 echo "== host =="; nproc; lscpu | grep -m1 "Model name"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee "$O/${V}_pytest_gpu.log"
@@ -30,12 +30,16 @@ done
 cd "$R"
 MODELS="combsub sins" bash tools/gpu_step_pmc.sh > /dev/null 2>&1
 cp "$O/step_pmc_combsub.txt" "$O/${V}_step_pmc_combsub.txt"; cp "$O/step_pmc_sins.txt" "$O/${V}_step_pmc_sins.txt"
-MODELS="combsub sins combsubsuperfast" PROF_TIMEOUT=90 V=$V bash tools/gpu_train_prof.sh > "$O/${V}_train.log" 2>&1
-grep "forward+backward" "$O"/tp_*.log | tee "$O/${V}_train_ms.txt"
+MODELS="combsub sins combsubsuperfast" PROF_TIMEOUT=90 PROBE_ARGS=loss V=$V bash tools/gpu_train_prof.sh > "$O/${V}_train.log" 2>&1
+grep -h "forward+backward" "$O"/tp_*.log | tee "$O/${V}_train_ms.txt"
+for k in combsub sins combsubsuperfast combsubfast; do timeout 120 python tools/train_step_probe.py $k 2>&1 | tail -1; done | tee -a "$O/${V}_train_ms.txt"
+cd /tmp; rm -rf "$O/kp"; timeout 200 rocprofv3 --kernel-trace -d "$O/kp" -o k -- python "$R/bench.py" --model rssloss --steps 20 --warmup 3 > "$O/kp.log" 2>&1
+python "$R/tools/rocpd_stats.py" $(find "$O/kp" -name "*.db" | head -1) 2>&1 | head -24 > "$O/${V}_rssloss_kernel_stats.csv"; rm -rf "$O/kp"; cd "$R"
+timeout 300 python tools/race_probe.py 10 2>&1 | tail -40 > "$O/${V}_race_probe.txt"; echo "race probe: $(grep -c '0 mismatches' "$O/${V}_race_probe.txt") operations clean"; grep -v "0 mismatches" "$O/${V}_race_probe.txt" | grep -v informational | tail -3
 bash tools/gpu_if_slow.sh
 python - <<'PY'
 import json, glob, os
-V = os.environ.get("V", "r03_v20")
+V = os.environ.get("V", "r03_v31")
 for f in sorted(glob.glob("gpurun_out/%s_bench_*.json" % V)):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1]); print(os.path.basename(f), round(d["ms_per_step"], 4), d.get("ms_per_step_events"), "%.3e" % d["value"], d["unit"])
