@@ -136,15 +136,31 @@ struct Branch {
 // the knob meanwhile (a disagreement would let the fallback stage the all-pass response in a buffer the layout has
 // already given to the exciter).
 thread_local bool t_taps_gemm = false;
+thread_local int t_czt_from = 112;          // chirp-z form from this bin count on (below it the dense contraction is the faster one:
+                                            // its cost falls with n^2, the 512-point plan's does not; equal at ~120 bins, measured)
 struct TapsFormScope {
-  TapsFormScope() { t_taps_gemm = knob(KNOB_TAPS_GEMM) != 0; }
+  TapsFormScope() {
+    const long v = knob(KNOB_TAPS_GEMM);     // 0: by shape; 1: the dense contraction everywhere; 2: chirp-z wherever its plans reach
+    t_taps_gemm = v == 1;
+    t_czt_from = v == 2 ? 2 : 112;
+  }
 };
 
-// tap synthesis of one filter: the prime-factor form when the shape is its (n_mag = 256), else the dense contraction
+// the periodic Hann behind the two basis planes of the table (k_ir_table, ir.hip)
+const float* table_hann(const float* table, int n) {
+  const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
+  return table + 2 * KP * NP;
+}
+
+// tap synthesis of one filter: the prime-factor form when the shape is its (n_mag = 256), the chirp-z form for the other bin
+// counts from 112 to 1025, else (or under knob TAPS_GEMM = 1) the dense contraction
 void synth_taps(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale, const float* table,
                 int mode, const float* half_width, long rows, int n, float* taps, hipStream_t st, float hw_sr = 0.f) {
   if (!t_taps_gemm &&
       launch_taps_pfa510(a_re, ld_re, a_im, ld_im, 0, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr) == 0)
+    return;
+  if (!t_taps_gemm && n != 256 && n >= t_czt_from &&
+      launch_taps_czt(a_re, ld_re, a_im, ld_im, act, scale, table_hann(table, n), mode, half_width, rows, n, taps, st, hw_sr) == 0)
     return;
   launch_ir_gemm(a_re, ld_re, a_im, ld_im, act, scale, table, mode, half_width, rows, n, taps, st, hw_sr);
 }
@@ -157,6 +173,9 @@ void synth_allpass_taps(const float* c_gd, long ld_gd, const float* table, long 
                                          rows, n, taps, st) == 0)
     return;
   launch_allpass_response(c_gd, ld_gd, rows, n, re, im, st);
+  if (!t_taps_gemm && n != 256 && n >= t_czt_from &&
+      launch_taps_czt(re, n, im, n, DDSP_HIP_ACT_NONE, 1.0f, table_hann(table, n), DDSP_HIP_MODE_ROLL, nullptr, rows, n, taps, st, 0.f) == 0)
+    return;
   launch_ir_gemm(re, n, im, n, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n, taps, st);
 }
 
@@ -287,8 +306,13 @@ int ddsp_hip_impulse_response_backward(const float* d_taps, const float* ctrl, l
   if (mode == DDSP_HIP_MODE_DYNAMIC && !half_width) return DDSP_HIP_EINVAL;
   if (d_im && act != DDSP_HIP_ACT_NONE) return DDSP_HIP_ESHAPE;
   const TapsFormScope form;
-  if (t_taps_gemm || launch_taps_pfa510_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag,
-                                            d_im != nullptr, d_re, d_im, S(stream)) != 0)
+  // the prime-factor form at 256 bins, the chirp-z form at the other bin counts up to 1025, else the dense contraction
+  const bool fast = !t_taps_gemm &&
+      (launch_taps_pfa510_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
+                              S(stream)) == 0 ||
+       (n_mag != 256 && n_mag >= t_czt_from && launch_taps_czt_bwd(d_taps, ctrl, ld_ctrl, act, scale, table_hann(table, n_mag), mode, half_width, rows,
+                                            n_mag, d_re, d_im, S(stream)) == 0));
+  if (!fast)
     launch_ir_gemm_bwd(d_taps, ctrl, ld_ctrl, act, scale, table, mode, half_width, rows, n_mag, d_im != nullptr, d_re, d_im,
                        S(stream));
   return finish();

@@ -1,4 +1,4 @@
-// Complex FFT of N = 512 R points (R = 2: 1024, R = 4: 2048, R = 8: 4096) for one workgroup of P = 64 R threads, 8 points per
+// Complex FFT of N = 512 R points (R = 1: 512, R = 2: 1024, R = 4: 2048, R = 8: 4096) for one workgroup of P = 64 R threads, 8 points per
 // thread in registers, three LDS exchanges through two ping-pong buffers -- the generalisation of fft2048.h
 // (whose complex helpers and radix-4/8 butterflies it re-uses) that the short-time spectral filters of
 // CombSubFast (window 1024) and CombSubSuperFast (window 2048) are built on.
@@ -19,7 +19,7 @@ namespace fft {
 
 template <int R>
 struct Plan {
-  static_assert(R == 2 || R == 4 || R == 8, "N = 1024, 2048 or 4096");
+  static_assert(R == 1 || R == 2 || R == 4 || R == 8, "N = 512, 1024, 2048 or 4096");
   static constexpr int N = 512 * R;
   static constexpr int P = 64 * R;          // threads
   static constexpr int SLOTS = 8;           // complex points per thread: k = P m + tid
@@ -85,6 +85,9 @@ struct Plan {
 #pragma unroll
       for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + n4];
       dft8(t);                                                                      // k4 = 0..7 -> slot m = k4
+    } else if constexpr (R == 1) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t[s] = src[s * P];                                // nothing left to transform: slot m = k3
     } else if constexpr (R == 4) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {

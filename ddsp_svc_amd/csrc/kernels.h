@@ -28,6 +28,12 @@ void launch_ir_gemm(const float* a_re, long ld_re, const float* a_im, long ld_im
 void launch_ir_gemm_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                         int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                         hipStream_t st);
+// chirp-z form of the tap synthesis for the other bin counts up to 1025 (ir_czt.hip); 0 = taken, -1 = not its shape.
+// hann: the periodic Hann of the basis table (k_ir_table), 2 (n - 1) values
+int launch_taps_czt(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale, const float* hann,
+                    int mode, const float* half_width, long rows, int n, float* taps, hipStream_t st, float hw_from_f0_sr);
+int launch_taps_czt_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* hann, int mode,
+                        const float* half_width, long rows, int n, float* d_re, float* d_im, hipStream_t st);
 // prime-factor form of the tap synthesis for n_mag = 256 (ir_pfa.hip); 0 = taken, -1 = not its shape (use launch_ir_gemm).
 // allpass_from_control: a_re is the raw group-delay control (pi*tanh -> cumsum -> cos/sin done in the kernel).
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,

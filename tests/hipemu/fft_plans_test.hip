@@ -87,7 +87,8 @@ extern "C" int emu_fft_plan(int R, int mode, const float* in, const float* in2, 
   const f32x2* b = reinterpret_cast<const f32x2*>(in2);
   f32x2* c = reinterpret_cast<f32x2*>(out);
   f32x2* d = reinterpret_cast<f32x2*>(out2);
-  if (R == 2) hipLaunchKernelGGL(k_plan<2>, dim3(1), dim3(128), 0, nullptr, mode, a, b, c, d);
+  if (R == 1) hipLaunchKernelGGL(k_plan<1>, dim3(1), dim3(64), 0, nullptr, mode, a, b, c, d);
+  else if (R == 2) hipLaunchKernelGGL(k_plan<2>, dim3(1), dim3(128), 0, nullptr, mode, a, b, c, d);
   else if (R == 4) hipLaunchKernelGGL(k_plan<4>, dim3(1), dim3(256), 0, nullptr, mode, a, b, c, d);
   else if (R == 8) hipLaunchKernelGGL(k_plan<8>, dim3(1), dim3(512), 0, nullptr, mode, a, b, c, d);
   else return -1;

@@ -1,5 +1,5 @@
 """The in-register / LDS FFT plans of ddsp_svc_amd/csrc/fft_r.h (the building blocks of k_fir_blk, k_stft_filter, k_mel) on
-their own, under the CPU emulator, against numpy.fft: the full three-exchange transform at 1024, 2048 and 4096 points, the
+their own, under the CPU emulator, against numpy.fft: the full three-exchange transform at 512, 1024, 2048 and 4096 points, the
 two-exchange pair that stays in the scrambled layout S (forward_s with and without the pruned first pass, transposed), and
 the two lockstep forms, which must equal their separate transforms bit for bit (same arithmetic, shared barriers)."""
 import ctypes
@@ -51,13 +51,13 @@ def _close(got, ref):
     return np.sqrt(np.mean(np.abs(got - ref) ** 2)) <= 3e-7 * np.sqrt(np.mean(np.abs(ref) ** 2))
 
 
-@pytest.mark.parametrize("R", [2, 4, 8])
+@pytest.mark.parametrize("R", [1, 2, 4, 8])
 def test_full_transform(plans, R):
     z = _rand(512 * R, R)
     assert _close(plans(R, 0, z)[0], np.fft.fft(z.astype(np.complex128)))
 
 
-@pytest.mark.parametrize("R", [2, 4, 8])
+@pytest.mark.parametrize("R", [1, 2, 4, 8])
 def test_lockstep_pair_and_zero_padded_first_pass(plans, R):
     """forward2 = two forward calls behind shared barriers, bit for bit; the pruned first pass (upper half of the input zero,
     never read) against numpy and, in lockstep, against itself."""

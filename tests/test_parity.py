@@ -560,3 +560,52 @@ def test_taps_prime_factor_form(dev, rows, knobs):
     for key in [k for k in got if k[0] == "pfa"]:
         other = got[("gemm",) + key[1:]]
         assert rms(got[key] - other) <= 1e-6 * rms(other), key
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("n", [2, 3, 33, 65, 128, 129, 257, 512, 1025])
+def test_taps_chirp_z_form(dev, n, knobs):
+    """Tap synthesis and its adjoint at bin counts other than 256 (core.py:254-270 + the window helpers): the chirp-z kernels
+    (csrc/ir_czt.hip; knob TAPS_GEMM = 2 sends every size their plans reach to them) and the dense contraction (= 1), each
+    against the float64 composition and its autograd, for the three window modes, real and complex responses.  4e-6 of the
+    largest value; the dynamic window with its narrow width here (11.7 taps) evaluates cos(pi (j - N/2) / width) at
+    arguments up to N / 7 radians, whose float32 spacing (the reference's too) is the error: times N / 512 there."""
+    from ddsp_svc_amd import core
+    rng = np.random.default_rng(n)
+    B, F, N = 2, 5, 2 * (n - 1)
+    re = torch.from_numpy(rng.standard_normal((B, F, n)).astype(np.float32))
+    im = torch.from_numpy(rng.standard_normal((B, F, n)).astype(np.float32))
+    hw = torch.full((B, F, 1), 11.7)
+    go = torch.from_numpy(rng.standard_normal((B, F, N)).astype(np.float32))
+
+    def ref_taps(resp, hann, width):
+        ir = torch.fft.irfft(resp)
+        if not hann:
+            return ir.roll(N // 2, -1)
+        if width is None:
+            w = torch.hann_window(N, dtype=ir.dtype).roll(N // 2, -1)
+            return (ir * w).roll(N // 2, -1)
+        pos = torch.arange(-(N // 2), (N + 1) // 2, dtype=ir.dtype) / width
+        pos = torch.where(pos > 1, torch.zeros_like(pos), pos)
+        return ir.roll(N // 2, -1) * ((1 + torch.cos(np.pi * pos)) / 2)
+
+    worst = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    for hann, width, cplx in ((False, None, True), (True, None, False), (True, hw, False), (True, None, True)):
+        a64, b64 = re.double().requires_grad_(True), im.double().requires_grad_(True)
+        r64 = torch.complex(a64, b64 if cplx else torch.zeros_like(a64))
+        want = ref_taps(r64, hann, width.double() if width is not None else None)
+        want.backward(go.double())
+        tol = 4e-6 * (max(1.0, N / 512.0) if width is not None else 1.0)
+        for form in (2, 1):
+            knobs("TAPS_GEMM", form)
+            core._TABLES.clear()
+            a = re.clone().to(dev).requires_grad_(True)
+            b = im.clone().to(dev).requires_grad_(True)
+            resp = torch.complex(a, b if cplx else torch.zeros_like(a))
+            got = core.frequency_impulse_response(resp, hann_window=hann,
+                                                  half_width_frames=width.to(dev) if width is not None else None)
+            got.backward(go.to(dev))
+            assert worst(got.detach().cpu().numpy(), want.detach().numpy()) <= tol, (n, hann, cplx, form)
+            assert worst(a.grad.cpu().numpy(), a64.grad.numpy()) <= tol, (n, hann, cplx, form)
+            if cplx and n > 2:
+                assert worst(b.grad.cpu().numpy(), b64.grad.numpy()) <= tol, (n, hann, cplx, form)
