@@ -52,7 +52,11 @@ const char* ddsp_hip_error_string(int code);
 /* Tuning / test knobs of the launchers (workgroup run lengths, which occupancy build of a kernel is launched, ...):
  * names as in DESIGN.md section 7 without the DDSP_HIP_ prefix ("BLK_RUN", "STFT_WPS", ...).  Each knob takes its
  * initial value from the environment variable DDSP_HIP_<NAME> ONCE, at first use; after that only set_tuning changes
- * it (0 = built-in default).  No reference counterpart: measurement tools and the run-split tests use them. */
+ * it (0 = built-in default).  No reference counterpart: measurement tools and the run-split tests use them.
+ * Knobs that choose between forms of one operation: TAPS_GEMM (tap synthesis and its adjoint: 0 = by bin count -- prime
+ * factors at 256, chirp-z from 112 to 1025, the dense contraction elsewhere; 1 = the dense contraction everywhere;
+ * 2 = chirp-z wherever its plans reach), SINS_V1 (sinusoid bank generations), STFT_WPS (waves per SIMD of the short-time
+ * spectral filter's variants), CZT_ROUNDS (rounds of resident workgroups of the loss kernels); the rest are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 
