@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
   using PL = fft::Plan<2>;
   constexpr int NF = PL::N, P = PL::P, S = 8;
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][NF];
+  // the carried tap spectrum c H_j+1 of split_taps (input gradient only): a thread's own eight values, parked here between
+  // the one read and the one write a pass makes -- sixteen registers the first stage does not have to spare
+  __shared__ __attribute__((aligned(16))) f32x2 hc_park[WITH_DX ? S * 128 : 1];
   f32x2* const bA = ex[0];
   f32x2* const bB = ex[1];
   f32x2* const bC = ex[2];
@@ -154,7 +157,10 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
   const float ct = 2.0f;
   const f32x2 kG1 = {-ct, ct};
   const f32x2 kTi = {0.5f * ct, -0.5f * ct};
-  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&Hc)[S], f32x2 (&G0)[S], f32x2 (&G1)[S]) {
+  auto split_taps = [&](const f32x2 (&z)[S], const f32x2* Zp, f32x2 (&G0)[S], f32x2 (&G1)[S]) {
+    f32x2 Hc[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) Hc[m] = hc_park[128 * m + tid];
 #pragma unroll
     for (int m = 0; m < S; m += 2) {
       const f32x2 n0 = mirrored(Zp, m), n1 = mirrored(Zp, m + 1);
@@ -164,8 +170,8 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
       G1[m + 1] = n1 * kG1;
       G0[m] = fft::swap_scale_add(p0, kTi, Hc[m]);
       G0[m + 1] = fft::swap_scale_add(p1, kTi, Hc[m + 1]);
-      Hc[m] = fft::swap_scale(d0, kTi);
-      Hc[m + 1] = fft::swap_scale(d1, kTi);
+      hc_park[128 * m + tid] = fft::swap_scale(d0, kTi);
+      hc_park[128 * (m + 1) + tid] = fft::swap_scale(d1, kTi);
     }
   };
 
@@ -177,11 +183,11 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
   Four t1 = load_taps(2 * q_first - 3), t2 = load_taps(2 * q_first - 2);
   Four x0 = load_blk(2 * q_first - 2), x1 = load_blk(2 * q_first - 1);
   tw.init(tid);
-  f32x2 S0[S], S1[S], Uc[S], Hc[S], G0[S], G1[S];
+  f32x2 S0[S], S1[S], Uc[S], G0[S], G1[S];
 #pragma unroll
   for (int m = 0; m < S; ++m) {
     Uc[m] = f32x2{0.f, 0.f};
-    Hc[m] = f32x2{0.f, 0.f};
+    if (WITH_DX) hc_park[128 * m + tid] = f32x2{0.f, 0.f};
     G0[m] = f32x2{0.f, 0.f};
     G1[m] = f32x2{0.f, 0.f};
   }
@@ -195,7 +201,7 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
       park_pair(zc, bA);
       park_pair(zt, bB);
       __syncthreads();
-      split_taps(zt, bB, Hc, G0, G1);
+      split_taps(zt, bB, G0, G1);
     } else {
       PL::template forward_s<false, true>(zc, tw, bA, bC, tid);
       park_pair(zc, bA);
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
     PL::template forward_s<true, true>(zt, tw, bB, bD, tid);
     park_pair(zt, bB);
     __syncthreads();
-    split_taps(zt, bB, Hc, G0, G1);
+    split_taps(zt, bB, G0, G1);
     __syncthreads();
   }
 
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
       PL::template transposed_and_forward_s<true, true>(S0, zt, tw, bC, bA, bD, bB, tid);
       park_pair(zt, bC);
       __syncthreads();
-      split_taps(zt, bC, Hc, G0, G1);
+      split_taps(zt, bC, G0, G1);
       x0 = load_blk(b0 + 2);
       x1 = load_blk(b0 + 3);
       auto store_dx = [&](const f32x2 (&W)[S], int bi) {
