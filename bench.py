@@ -304,6 +304,7 @@ def also_lines(a, device, B, F, n, want_traffic):
     del step, inp, y
     # ---- the as-shipped configs/combsub.yaml model
     step, inp = build_step("combsubsuperfast", B, F, n, device, seed=4322)
+    prewarm(step, min(a.prewarm_seconds, 0.2))
     el, ev_ms, y = time_steps(step, steps, warm, fence)
     assert torch.isfinite(y).all()
     exc = torch.randn(B, T, device=device)
@@ -336,6 +337,7 @@ def also_lines(a, device, B, F, n, want_traffic):
         finally:
             torch.randint = real_randint
         return torch.autograd.grad(value, xp)[0]
+    prewarm(loss_step, min(a.prewarm_seconds, 0.2))
     el, ev_ms, y = time_steps(loss_step, steps, warm, fence)
     assert torch.isfinite(y).all()
     out["rssloss"] = {

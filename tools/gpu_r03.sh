@@ -36,7 +36,6 @@ for k in combsub sins combsubsuperfast combsubfast; do timeout 120 python tools/
 cd /tmp; rm -rf "$O/kp"; timeout 200 rocprofv3 --kernel-trace -d "$O/kp" -o k -- python "$R/bench.py" --model rssloss --steps 20 --warmup 3 > "$O/kp.log" 2>&1
 python "$R/tools/rocpd_stats.py" $(find "$O/kp" -name "*.db" | head -1) 2>&1 | head -24 > "$O/${V}_rssloss_kernel_stats.csv"; rm -rf "$O/kp"; cd "$R"
 timeout 300 python tools/race_probe.py 10 2>&1 | tail -40 > "$O/${V}_race_probe.txt"; echo "race probe: $(grep -c '0 mismatches' "$O/${V}_race_probe.txt") operations clean"; grep -v "0 mismatches" "$O/${V}_race_probe.txt" | grep -v informational | tail -3
-bash tools/gpu_if_slow.sh
 python - <<'PY'
 import json, glob, os
 V = os.environ.get("V", "r03_v31")
