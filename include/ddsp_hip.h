@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 141          /* 0.1.4.1: + tuning knobs, window_impulse_response, windowed complex adjoint, in-kernel noise draw */
+#define DDSP_HIP_VERSION 150          /* 0.1.5.0: + the spectral loss from the waveforms (ddsp_hip_stft_loss*), chirp-z tap synthesis */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ddsp_hip_version() == 141
+    assert lib.ddsp_hip_version() == 150
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -36,6 +36,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ddsp_hip_fast_source(None, 1, 0, 512, 44100.0, None, None, None, None) == -1   # F <= 0
     assert lib.ddsp_hip_stft_filter(None, None, 0, None, 1025, None, 1025, None, 1024, None, 0, 1.0, None, 2048,
                                     1, 1, 1, 4, 512, None, None) == -1                      # row stride < n bins
+    # the loss from the waveforms: sizes, frame counts and workspaces without a launch
+    assert lib.ddsp_hip_stft_loss_table_bytes(1153) == (2 * 1153 + 4096) * 8 and lib.ddsp_hip_stft_loss_table_bytes(512) == (1024 + 1024) * 8
+    assert lib.ddsp_hip_stft_loss_table_bytes(2049) == 0 and lib.ddsp_hip_stft_loss_table_bytes(1) == 0
+    assert lib.ddsp_hip_stft_loss_frames(1000, 100, 100) == 10 and lib.ddsp_hip_stft_loss_frames(1000, 100, 25) == 37
+    assert lib.ddsp_hip_stft_loss_frames(99, 100, 100) == 0
+    assert lib.ddsp_hip_stft_loss_backward_ws_bytes(2, 1000, 100, 100) == 0
+    assert lib.ddsp_hip_stft_loss_backward_ws_bytes(2, 1000, 100, 25) == 2 * 37 * 100 * 4
+    assert lib.ddsp_hip_stft_loss(None, None, 1, 1000, 1000, 100, 100, None, 1.0, 1e-7, 1.0, None, 0, None, None, None, None,
+                                  None) == -1                                                 # null pointers
+    assert lib.ddsp_hip_stft_loss_tables(4096, None, None) == -3                              # size the plans do not reach
 
 
 def test_host_tensors_are_rejected():
