@@ -324,3 +324,51 @@ def test_patch_reference_reaches_the_cascades(dev):
         for m, names in saved.items():
             for n, c in names.items():
                 setattr(m, n, c)
+
+
+class _SpectrogramStandIn(torch.nn.Module):
+    """torchaudio.transforms.Spectrogram as ddsp/loss.py:20 configures it (torchaudio is not installed here; the same
+    stand-in as tests/golden/make_golden.py): periodic Hann, center=False, power=1, normalized by the window's L2 norm."""
+
+    def __init__(self, n_fft, win_length=None, hop_length=None, power=1, normalized=True, center=False, **kw):
+        super().__init__()
+        self.n_fft, self.hop = n_fft, hop_length
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, x):
+        z = torch.stft(x, self.n_fft, hop_length=self.hop, win_length=self.n_fft, window=self.window, center=False,
+                       normalized=False, onesided=True, return_complex=True)
+        return z.abs() / self.window.pow(2).sum().sqrt()
+
+
+@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+def test_patch_reference_loss(dev, monkeypatch):
+    """patch_reference_loss(): ``ddsp.loss.SSSLoss`` / ``RSSLoss`` (and the name train.py imported) become the drop-ins;
+    the reference's own classes, run as they are over a stand-in for torchaudio's Spectrogram, give the same value and the
+    same gradient for the same draw of transform sizes (loss.py:47)."""
+    _import_reference()
+    sys.modules["torchaudio"].transforms.Spectrogram = _SpectrogramStandIn
+    sys.modules.pop("ddsp.loss", None)
+    from ddsp_svc_amd import loss as L
+    dl = L.patch_reference_loss()
+    try:
+        assert dl.SSSLoss is L.SSSLoss and dl.RSSLoss is L.RSSLoss
+        ref_cls = dl._reference_RSSLoss
+        g = torch.Generator().manual_seed(4)
+        xt = torch.randn(2, 9000, generator=g) * 0.1
+        xp = (xt * 0.8 + 0.05 * torch.randn(2, 9000, generator=g))
+        sizes = torch.tensor([397, 1024, 263])
+        monkeypatch.setattr(torch, "randint", lambda *a, **k: sizes)
+        ref = ref_cls(256, 1100, 3, eps=1e-5, device="cpu")
+        a = xp.clone().requires_grad_(True)
+        want = ref(a, xt)
+        want.backward()
+        ours = dl.RSSLoss(256, 1100, 3, eps=1e-5, device="cpu")
+        b = xp.clone().requires_grad_(True)
+        got = ours(b, xt)
+        got.backward()
+        assert "RandomScaleWaveLoss" in type(got.grad_fn).__name__
+        assert abs(float(got.detach()) - float(want.detach())) <= 2e-5 * float(want.detach())
+        assert rms(b.grad.numpy() - a.grad.numpy()) <= 2e-4 * rms(a.grad.numpy())
+    finally:
+        dl.SSSLoss, dl.RSSLoss = dl._reference_SSSLoss, dl._reference_RSSLoss
