@@ -74,16 +74,20 @@ struct Plan {
     for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];            // tid = n4 + R k1 + 8R k2
     dft8(v);
     twiddle7(v, tw.w3);
+    // R = 8: the last pass reads eight consecutive words per thread, 16 bytes at a time, and the threads k1, k1 + 4 of a group
+    // sit 256 bytes -- one turn of the banks -- apart: the upper four k1 keep their 16-byte pairs swapped ([n4 ^ 2])
+    const int at = R == 8 ? tid ^ (((tid >> 5) & 1) << 1) : tid;
 #pragma unroll
-    for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + tid] = v[k3];                         // [k3][k2][k1][n4]
+    for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + at] = v[k3];                          // [k3][k2][k1][n4]
   }
   static __device__ __forceinline__ void pass4(f32x2 (&v)[8], const f32x2* A, int tid) {
     const int k1 = tid & 7, k2 = (tid >> 3) & 7, k3lo = tid >> 6;
     const f32x2* src = A + k2 * C + k1 * R;
     f32x2 t[8];
     if constexpr (R == 8) {
+      const int sw = ((k1 >> 2) & 1) << 1;                                          // see pass3
 #pragma unroll
-      for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + n4];
+      for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + (n4 ^ sw)];
       dft8(t);                                                                      // k4 = 0..7 -> slot m = k4
     } else if constexpr (R == 1) {
 #pragma unroll
