@@ -74,9 +74,13 @@ struct Plan {
     for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];            // tid = n4 + R k1 + 8R k2
     dft8(v);
     twiddle7(v, tw.w3);
-    // R = 8: the last pass reads eight consecutive words per thread, 16 bytes at a time, and the threads k1, k1 + 4 of a group
-    // sit 256 bytes -- one turn of the banks -- apart: the upper four k1 keep their 16-byte pairs swapped ([n4 ^ 2])
-    const int at = R == 8 ? tid ^ (((tid >> 5) & 1) << 1) : tid;
+    // R = 8: the last pass reads eight consecutive words per thread.  LDS reads are served in groups of lanes -- for 16-byte
+    // reads {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks of 4 bytes, and with thread (k1, k2)
+    // at k2 * 512 + k1 * 64 bytes the lanes k1 | k1 + 4 and k2 = 0 | 3, 1 | 2 of a group meet in the same banks.  So the
+    // 16-byte pairs of a thread's run are stored permuted, [n4 ^ 2 (k1 bit 2) ^ 4 (k2 bit 1)], and pass4 reads them back the
+    // same way: SQ_LDS_BANK_CONFLICT 8 % of the LDS cycles -> 0 (profiles/r03_v34_loss_pmc.txt).  The same idea at R = 4
+    // ([n4 ^ 2 (k2 bit 1)]) made the compiler split the reads and tripled the conflicts there: not kept.
+    const int at = R == 8 ? tid ^ (((tid >> 5) & 1) << 1) ^ (((tid >> 7) & 1) << 2) : tid;
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + at] = v[k3];                          // [k3][k2][k1][n4]
   }
@@ -85,7 +89,7 @@ struct Plan {
     const f32x2* src = A + k2 * C + k1 * R;
     f32x2 t[8];
     if constexpr (R == 8) {
-      const int sw = ((k1 >> 2) & 1) << 1;                                          // see pass3
+      const int sw = (((k1 >> 2) & 1) << 1) ^ (((k2 >> 1) & 1) << 2);               // see pass3
 #pragma unroll
       for (int n4 = 0; n4 < 8; ++n4) t[n4] = src[k3lo * P + (n4 ^ sw)];
       dft8(t);                                                                      // k4 = 0..7 -> slot m = k4
