@@ -74,13 +74,15 @@ struct Plan {
     for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P + (tid ^ (n3 * R))];            // tid = n4 + R k1 + 8R k2
     dft8(v);
     twiddle7(v, tw.w3);
-    // R = 8: the last pass reads eight consecutive words per thread.  LDS reads are served in groups of lanes -- for 16-byte
-    // reads {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks of 4 bytes, and with thread (k1, k2)
-    // at k2 * 512 + k1 * 64 bytes the lanes k1 | k1 + 4 and k2 = 0 | 3, 1 | 2 of a group meet in the same banks.  So the
-    // 16-byte pairs of a thread's run are stored permuted, [n4 ^ 2 (k1 bit 2) ^ 4 (k2 bit 1)], and pass4 reads them back the
-    // same way: SQ_LDS_BANK_CONFLICT 8 % of the LDS cycles -> 0 (profiles/r03_v34_loss_pmc.txt).  The same idea at R = 4
-    // ([n4 ^ 2 (k2 bit 1)]) made the compiler split the reads and tripled the conflicts there: not kept.
-    const int at = R == 8 ? tid ^ (((tid >> 5) & 1) << 1) ^ (((tid >> 7) & 1) << 2) : tid;
+    // R >= 4: the last pass reads R consecutive words per thread, 16 bytes at a time.  Such reads are served in groups of
+    // 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks of 4 bytes, and with thread
+    // (k1, k2) at k2 * 64 R + k1 * 8 R bytes the lanes of a group meet in the same banks (R = 4: k2 = 0 | 3 and 1 | 2, two-way;
+    // R = 8: also k1 | k1 + 4, four-way).  So the 16-byte pairs of a thread's run are stored permuted -- [n4 ^ 2 (k2 bit 1)]
+    // for R = 4, [n4 ^ 2 (k1 bit 2) ^ 4 (k2 bit 1)] for R = 8 -- and pass4 reads them back the same way (R = 4: as explicit
+    // 16-byte loads; written as four 8-byte elements the compiler split them and the conflicts tripled):
+    // SQ_LDS_BANK_CONFLICT 8 % of the LDS cycles -> 0 on both plans (profiles/r03_v34_loss_pmc.txt).
+    const int at = R == 8 ? tid ^ (((tid >> 5) & 1) << 1) ^ (((tid >> 7) & 1) << 2)
+                          : (R == 4 ? tid ^ (((tid >> 6) & 1) << 1) : tid);
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) A[k3 * P + at] = v[k3];                          // [k3][k2][k1][n4]
   }
@@ -97,10 +99,13 @@ struct Plan {
 #pragma unroll
       for (int s = 0; s < 8; ++s) t[s] = src[s * P];                                // nothing left to transform: slot m = k3
     } else if constexpr (R == 4) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const int sw = ((k2 >> 1) & 1) << 1;                                          // see pass3: the run's 16-byte pairs swapped
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        f32x2 a0 = src[(k3lo + 4 * s) * P + 0], a1 = src[(k3lo + 4 * s) * P + 1];
-        f32x2 a2 = src[(k3lo + 4 * s) * P + 2], a3 = src[(k3lo + 4 * s) * P + 3];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src + (k3lo + 4 * s) * P + sw);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + (k3lo + 4 * s) * P + (2 ^ sw));
+        f32x2 a0{lo.x, lo.y}, a1{lo.z, lo.w}, a2{hi.x, hi.y}, a3{hi.z, hi.w};
         dft4(a0, a1, a2, a3);                                                       // k4 = 0..3 -> slot m = s + 2 k4
         t[s] = a0; t[s + 2] = a1; t[s + 4] = a2; t[s + 6] = a3;
       }
