@@ -72,7 +72,10 @@ class _SpectralLossFunction(torch.autograd.Function):
         return grads[0], grads[1], None, None, None
 
 
-_CZT_TABLES = {}                       # (device, stream, n_fft) -> chirps and filter spectrum of csrc/loss_czt.hip
+import collections
+
+_CZT_TABLES = collections.OrderedDict()    # (device, stream, n_fft) -> chirps and filter spectrum of csrc/loss_czt.hip, LRU
+_CZT_TABLES_MAX = 4096                     # <= 64 KB each: every size RSSLoss can draw on two streams stays resident
 
 
 def _czt_tables(n_fft, like):
@@ -88,6 +91,10 @@ def _czt_tables(n_fft, like):
         t = torch.empty(nbytes // 4, dtype=torch.float32, device=like.device)
         _ffi.check(lib.ddsp_hip_stft_loss_tables(int(n_fft), ptr(t), _ffi.stream_of(like)))
         _CZT_TABLES[key] = t
+        while len(_CZT_TABLES) > _CZT_TABLES_MAX:              # (a dropped table is freed once the work enqueued on it is done)
+            _CZT_TABLES.popitem(last=False)
+    else:
+        _CZT_TABLES.move_to_end(key)
     return t
 
 
