@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
                                                        int n, int hop, int frames, int chunks, int span,
                                                        const float2* __restrict__ tab, float inv_wn, float eps,
                                                        float2* __restrict__ spec_t, float2* __restrict__ spec_p,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial, int knob_turns) {
   using PL = fft::Plan<R>;
   constexpr int N = PL::N, P = PL::P;
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
@@ -196,7 +196,11 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
     note_peaks(0);
   }
   __syncthreads();
+  // the waves that share a SIMD take turns at its arbiter's priority, pass by pass (fir_blk.hip)
+  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
   for (int f = f_lo, par = 0; f < f_hi; f += 2, par ^= 1) {
+    if (knob_turns && ((par + turn) & 1)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     f32x2 v[2][8], co[4];
     float up[2], down[2];                                    // 2^d and 2^-d, d = exponent of the target's peak - the prediction's
 #pragma unroll
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
                                                         const float* __restrict__ norms, float inv_wn, float eps,
                                                         float alpha, float inv_B, float inv_n,
                                                         const float* __restrict__ grad_out, float* __restrict__ dx,
-                                                        long ld_dx, int T, int accumulate) {
+                                                        long ld_dx, int T, int accumulate, int knob_turns) {
   using PL = fft::Plan<R>;
   constexpr int N = PL::N, P = PL::P;
   __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
@@ -373,7 +377,10 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
     }
   };
   if (p_lo < p_hi) { fetch(p_lo); prepare(p_lo); }
+  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // as the forward kernel
   for (int pi = p_lo; pi < p_hi; ++pi) {
+    if (knob_turns && ((pi + turn) & 1)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     const int f0 = 2 * pi;
     const bool two = f0 + 1 < frames;
     f32x2 v[8], co[4];
@@ -469,19 +476,20 @@ int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int
   if (!R || B < 1 || B > 65535 || frames < 1 || hop < 1) return -1;
   const WaveGeom geo = sss_wave_geom(B, n, frames, false);
   const int chunks = geo.chunks, span = geo.span;
+  const int turns = knob(KNOB_CZT_TURNS) == 1 ? 1 : 0;           // priority turns of a SIMD's waves: off here (knob 1: on)
   const dim3 grid((unsigned)chunks, (unsigned)B);
   const float2* tb = reinterpret_cast<const float2*>(tab);
   float2* s_t = reinterpret_cast<float2*>(spec_t);
   float2* s_p = reinterpret_cast<float2*>(spec_p);
   if (R == 2)
     hipLaunchKernelGGL(k_sss_czt<2>, grid, dim3(128), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch);
+                       scratch, turns);
   else if (R == 4)
     hipLaunchKernelGGL(k_sss_czt<4>, grid, dim3(256), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch);
+                       scratch, turns);
   else
     hipLaunchKernelGGL(k_sss_czt<8>, grid, dim3(512), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch);
+                       scratch, turns);
   const long per_utt = (long)frames * (n / 2 + 1);
   launch_sss_final(scratch, B, chunks, per_utt, alpha, norms, loss, st);
   return 0;
@@ -490,13 +498,13 @@ int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int
 template <int R>
 static void launch_bwd_r(dim3 grid, hipStream_t st, int wrt_true, const float2* s_t, const float2* s_p, int n, int frames,
                          int chunks, const float2* tb, const float* norms, float inv_wn, float eps, float alpha, float inv_B,
-                         float inv_n, const float* grad_out, float* dx, long ld_dx, int T, int accumulate) {
+                         float inv_n, const float* grad_out, float* dx, long ld_dx, int T, int accumulate, int turns) {
   if (wrt_true)
     hipLaunchKernelGGL((k_sss_czt_bwd<R, 1>), grid, dim3(64 * R), 0, st, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps,
-                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate);
+                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate, turns);
   else
     hipLaunchKernelGGL((k_sss_czt_bwd<R, 0>), grid, dim3(64 * R), 0, st, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps,
-                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate);
+                       alpha, inv_B, inv_n, grad_out, dx, ld_dx, T, accumulate, turns);
 }
 
 // Overlapping frames (hop < n): k_sss_czt_bwd leaves every frame's windowed gradient in a frame-major scratch, and each
@@ -537,6 +545,9 @@ int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, 
     return 0;
   }
   const WaveGeom geo = sss_wave_geom(B, n, frames, true);
+  // priority turns of the waves that share a SIMD (fir_blk.hip): on in this kernel, off in the forward one -- measured, same
+  // box: both off 1.058 ms per four-scale step, both on 1.046 with the forward kernels alone 1 % slower (knob 2: off here too)
+  const int turns = knob(KNOB_CZT_TURNS) == 2 ? 0 : 1;
   const int chunks = geo.chunks;                                       // the kernel cuts the pairs of frames into as many spans
   const dim3 grid((unsigned)chunks, (unsigned)B);
   const float2* tb = reinterpret_cast<const float2*>(tab);
@@ -546,13 +557,13 @@ int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, 
   const float inv_n = (float)(1.0 / ((double)B * (double)frames * (double)(n / 2 + 1)));
   if (R == 2)
     launch_bwd_r<2>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
-                    dx, ld_dx, T, accumulate);
+                    dx, ld_dx, T, accumulate, turns);
   else if (R == 4)
     launch_bwd_r<4>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
-                    dx, ld_dx, T, accumulate);
+                    dx, ld_dx, T, accumulate, turns);
   else
     launch_bwd_r<8>(grid, st, wrt_true, s_t, s_p, n, frames, chunks, tb, norms, inv_wn, eps, alpha, inv_B, inv_n, grad_out,
-                    dx, ld_dx, T, accumulate);
+                    dx, ld_dx, T, accumulate, turns);
   return 0;
 }
 
