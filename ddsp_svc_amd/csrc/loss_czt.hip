@@ -39,7 +39,8 @@ size_t czt_table_bytes(int n) {
 }
 
 // tab: c[n] | w c[n] | bhat[N].  Blocks [0, N): one filter-spectrum bin each,
-//     bhat[q] = sum_{|m| < n} exp(+i pi m^2 / n) exp(-2 pi i q m / N) = 1 + 2 sum_{m = 1}^{n - 1} exp(i pi m^2 / n) cos(2 pi q m / N);
+//     bhat[q] = sum_{|m| < n} exp(+i pi m^2 / n) exp(-2 pi i q m / N)
+//             = 1 + 2 sum_{m = 1}^{n - 1} exp(i pi m^2 / n) cos(2 pi q m / N);
 // the blocks behind them fill the chirps.  Phases are reduced in integers, so the float64 arguments are exact.
 __global__ void __launch_bounds__(CZ_TAB_THREADS) k_czt_tables(int n, int N, float2* __restrict__ tab) {
   __shared__ double red[2][CZ_TAB_THREADS / 64];
@@ -79,8 +80,9 @@ __device__ __forceinline__ float cz_mag(f32x2 z) { return __builtin_amdgcn_sqrtf
 __device__ __forceinline__ float cz_log(float s) { return 0.6931471805599453f * __builtin_amdgcn_logf(s); }
 
 // One circular convolution with the chirp filter: v[0..3] (natural order, slot m <-> index P m + tid; the upper half of the
-// input is zero padding) -> conj of the result in v[0..7], N times too large.  post[P m + tid] -- the table the caller multiplies the result with -- is fetched between the two
-// transforms, so its latency hides behind the second one (reads past a table's n entries stay inside tab and are unused).
+// input is zero padding) -> conj of the result in v[0..7], N times too large.  post[P m + tid] -- the table the caller
+// multiplies the result with -- is fetched between the two transforms, so its latency hides behind the second one (reads
+// past a table's n entries stay inside tab and are unused).
 template <int R, class Between>
 __device__ __forceinline__ void czt_convolve(f32x2 (&v)[8], const typename fft::Plan<R>::Tw& tw, const f32x2* __restrict__ bh,
                                              const f32x2* __restrict__ post, f32x2 (&pv)[4], f32x2* A, f32x2* B, int tid,
@@ -133,8 +135,10 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
   constexpr int N = PL::N, P = PL::P;
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
   __shared__ double red[3][R];
-  __shared__ int live[2][2][3];                              // [pass parity][frame of the pair][true, pred: a nonzero sample; the two differ]
-  __shared__ unsigned peak[2][2][2];                         // [pass parity][frame][true, pred]: float bits of the largest windowed |sample|
+  // per [pass parity][frame of the pair]: flags {true, pred: a nonzero sample behind the window; the two frames differ} and
+  // the float bits of the largest windowed |sample| of {true, pred}
+  __shared__ int live[2][2][3];
+  __shared__ unsigned peak[2][2][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, b = blockIdx.y;
   const int bins = n / 2 + 1;
