@@ -10,10 +10,14 @@
 // and come apart through Z[k] and conj Z[n - k]; magnitudes, the three reductions of loss.hip and the stores of the two
 // spectra (the backward pass reads them) follow in registers.
 //   k_czt_tables  : c, w c and the filter spectrum for one n (float64 sums, once per size and device)
-//   k_sss_czt     : frames -> spectra + per (utterance, chunk) float64 partial sums; k_sss_final of loss.hip finishes
-//   k_sss_czt_bwd : d loss / d x for hop == n: the gradient of the spectrum (k_sss_grad's formula) of TWO frames,
-//                   Hermitian-extended, as one inverse chirp-z transform, times the window
+//   k_sss_czt     : frames (any hop) -> spectra + per (utterance, chunk) float64 partial sums, two frames per pass in
+//                   lockstep; k_sss_final of loss.hip finishes
+//   k_sss_czt_bwd : the gradient of the spectrum (k_sss_grad's formula) of TWO frames, Hermitian-extended, as one inverse
+//                   chirp-z transform, times the window: d loss / d x when hop == n, else the frames' gradients in a
+//                   workspace, which
+//   k_frames_overlap_add gathers per sample in ascending frame order
 // Bound: arithmetic (per frame pair 2 transforms of N points); HBM sees 8 B per sample pair in and 16 B per bin pair out.
+// Measured and what was tried: DESIGN.md 7.1, EXPERIMENTS.md 3.7.
 #include "ddsp_common.h"
 #include "fft_r.h"
 #include "kernels.h"
