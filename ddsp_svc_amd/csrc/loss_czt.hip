@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
                                                        int n, int hop, int frames, int chunks, int span,
                                                        const float2* __restrict__ tab, float inv_wn, float eps,
                                                        float2* __restrict__ spec_t, float2* __restrict__ spec_p,
-                                                       double* __restrict__ partial, int knob_turns) {
+                                                       double* __restrict__ partial) {
   using PL = fft::Plan<R>;
   constexpr int N = PL::N, P = PL::P;
   __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
@@ -204,20 +204,15 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
     note_peaks(0);
   }
   __syncthreads();
-  // the waves that share a SIMD take turns at its arbiter's priority, pass by pass (fir_blk.hip)
-  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // HW_ID[3:0]: wave slot within the SIMD
   for (int f = f_lo, par = 0; f < f_hi; f += 2, par ^= 1) {
-    if (knob_turns && ((par + turn) & 1)) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
     f32x2 v[2][8], co[4];
-    float up[2], down[2];                                    // 2^d and 2^-d, d = exponent of the target's peak - the prediction's
+    float up[2];                                             // 2^d, d = exponent of the target's peak - the prediction's
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const unsigned pt = peak[par][h][0], pq = peak[par][h][1];
       int d = (int)((pt >> 23) & 0xff) - (int)((pq >> 23) & 0xff);
       d = (pt == 0u || pq == 0u) ? 0 : (d > 60 ? 60 : (d < -60 ? -60 : d));
       up[h] = __uint_as_float((unsigned)(127 + d) << 23);
-      down[h] = __uint_as_float((unsigned)(127 - d) << 23);
     }
     if (tid < 4) (&peak[par ^ 1][0][0])[tid] = 0u;           // the next pass's peaks; their writers are barriers away
     // The two signals share one transform, so each spectrum carries the other's rounding noise (1e-7 of ITS size).  A
@@ -251,7 +246,8 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt(const float* __restrict__
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                            // read BEFORE the barrier below: the next pass resets these flags
       keep_t[h] = live[par][h][0] ? 1.f : 0.f;
-      keep_p[h] = live[par][h][1] ? down[h] : 0.f;               // ... and the prediction's spectrum back to its scale
+      // ... and the prediction's spectrum back to its scale: 2^-d from 2^d's bits (one register less across the transforms)
+      keep_p[h] = live[par][h][1] ? __uint_as_float(0x7f000000u - __float_as_uint(up[h])) : 0.f;
       same[h] = !live[par][h][2];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -484,20 +480,19 @@ int launch_sss_wave(const float* xt, const float* xp, int B, long ld, int n, int
   if (!R || B < 1 || B > 65535 || frames < 1 || hop < 1) return -1;
   const WaveGeom geo = sss_wave_geom(B, n, frames, false);
   const int chunks = geo.chunks, span = geo.span;
-  const int turns = knob(KNOB_CZT_TURNS) == 1 ? 1 : 0;           // priority turns of a SIMD's waves: off here (knob 1: on)
   const dim3 grid((unsigned)chunks, (unsigned)B);
   const float2* tb = reinterpret_cast<const float2*>(tab);
   float2* s_t = reinterpret_cast<float2*>(spec_t);
   float2* s_p = reinterpret_cast<float2*>(spec_p);
   if (R == 2)
     hipLaunchKernelGGL(k_sss_czt<2>, grid, dim3(128), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch, turns);
+                       scratch);
   else if (R == 4)
     hipLaunchKernelGGL(k_sss_czt<4>, grid, dim3(256), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch, turns);
+                       scratch);
   else
     hipLaunchKernelGGL(k_sss_czt<8>, grid, dim3(512), 0, st, xt, xp, ld, n, hop, frames, chunks, span, tb, inv_wn, eps, s_t, s_p,
-                       scratch, turns);
+                       scratch);
   const long per_utt = (long)frames * (n / 2 + 1);
   launch_sss_final(scratch, B, chunks, per_utt, alpha, norms, loss, st);
   return 0;
@@ -553,8 +548,9 @@ int launch_sss_wave_bwd(const float* spec_t, const float* spec_p, int B, int T, 
     return 0;
   }
   const WaveGeom geo = sss_wave_geom(B, n, frames, true);
-  // priority turns of the waves that share a SIMD (fir_blk.hip): on in this kernel, off in the forward one -- measured, same
-  // box: both off 1.058 ms per four-scale step, both on 1.046 with the forward kernels alone 1 % slower (knob 2: off here too)
+  // priority turns of the waves that share a SIMD (fir_blk.hip): in this kernel only -- measured, same box: off 1.058 ms per
+  // four-scale step, on in both kernels 1.046 with the forward kernels alone 1 % slower (and, at 4096 points, one register
+  // past their file), so the forward kernel does without (knob CZT_TURNS = 2: off here too)
   const int turns = knob(KNOB_CZT_TURNS) == 2 ? 0 : 1;
   const int chunks = geo.chunks;                                       // the kernel cuts the pairs of frames into as many spans
   const dim3 grid((unsigned)chunks, (unsigned)B);

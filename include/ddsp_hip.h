@@ -56,8 +56,8 @@ const char* ddsp_hip_error_string(int code);
  * Knobs that choose between forms of one operation: TAPS_GEMM (tap synthesis and its adjoint: 0 = by bin count -- prime
  * factors at 256, chirp-z from 112 to 1025, the dense contraction elsewhere; 1 = the dense contraction everywhere;
  * 2 = chirp-z wherever its plans reach), SINS_V1 (sinusoid bank generations), STFT_WPS (waves per SIMD of the short-time
- * spectral filter's variants), CZT_ROUNDS (rounds of resident workgroups of the loss kernels), CZT_TURNS (priority turns of a SIMD's waves in the loss
- * kernels: 0 = backward only, 1 = both, 2 = neither); the rest are run lengths. */
+ * spectral filter's variants), CZT_ROUNDS (rounds of resident workgroups of the loss kernels), CZT_TURNS (priority turns of a SIMD's waves in the loss's
+ * backward kernel: 0 = on, 2 = off); the rest are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 
