@@ -22,7 +22,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   cfg4                   (N = 8, or --cfg4) BASELINE cfg 4: 64 utterances per GPU, samples/s without and with the RCCL gather
   ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
   cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
-                         on this host's cores over a bounded sample of the same workload (N=1 only)
+                         on this host's cores over a bounded sample of the same workload (N=1 only); kind "reference" -- the
+                         UNMODIFIED reference module itself, with the 1e-4 parity gate -- when a reference checkout
+                         travelled with the run (DDSP_REFERENCE_PATH, tools/with_reference.sh; the port then moves to
+                         cpu_baseline_port)
   cpu_baseline_aten_chain  the reference's op chain walked with torch CPU operators (oracle/aten_chain.py), all cores;
                            .same_chain_on_gpu: the same chain with its tensors on the GPU (PyTorch-ROCm), full workload
   value_module_mode      the drop-in module with a stand-in Unit2Control producing the controls on the GPU (control mode (i))
@@ -46,6 +49,37 @@ SR, HOP = 44100, 512
 FAST_MODELS = ("combsubfast", "combsubsuperfast")
 
 
+class _HipRuntime:
+    """The device layer the rank logic below talks to: PyTorch-ROCm's HIP runtime and RCCL (``nccl``).  bench.py itself has
+    no other: without an MI355X it refuses to run.  tests/test_bench_ranks.py swaps in an emulator-backed object (CPU
+    tensors, ``gloo``) to drive the SAME setup_ranks / fence / reduce-max / rank-0-emit code under two ranks on a host
+    without GPUs, so that the first real ``--gpus 8`` run does not die in a branch that never executed."""
+    backend = "nccl"
+
+    def available(self):
+        return torch.cuda.is_available()
+
+    def device_count(self):
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+    def device(self, local_rank):
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def init_process_group(self, rank, world, device):
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+
+RT = _HipRuntime()
+
+
 def prewarm(step, seconds):
     """Bring the GPU to its sustained clocks before anything is timed: after idling the first ~50-100 ms of work run
     7-8 % slower (measured: the same fused step takes 0.64 ms in the first 20 ms of a process and 0.596 ms later).
@@ -57,7 +91,7 @@ def prewarm(step, seconds):
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
             step()
-        torch.cuda.synchronize()
+        RT.synchronize()
         n += 20
     return n
 
@@ -241,7 +275,7 @@ def time_steps(step, steps, warmup, fence):
     for _ in range(warmup):
         out = step()
     fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = RT.event(), RT.event()
     t0 = time.perf_counter()
     e0.record()
     for _ in range(steps):
@@ -355,7 +389,7 @@ def cfg4_line(a, rank, world, device, F, n, comm):
     sharded synthesis alone and with the gather of every step's waveforms to rank 0, max over ranks."""
     import torch.distributed as dist
     from ddsp_svc_amd import sharding
-    B4 = 64
+    B4 = a.cfg4_batch
     T = F * HOP
     step, _ = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
     steps, warm = max(5, min(a.steps, 20)), 3
@@ -363,7 +397,7 @@ def cfg4_line(a, rank, world, device, F, n, comm):
     def fence():
         if dist.is_initialized() and world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        RT.synchronize()
 
     def reduce_max(*vals):
         if not (dist.is_initialized() and world > 1):
@@ -389,10 +423,11 @@ def cfg4_line(a, rank, world, device, F, n, comm):
         elg, g_ms = reduce_max(elg, g_ms)
         if rank == 0:
             assert full.shape == (B4 * world, T) and torch.isfinite(full[::8, ::4096]).all()
+            res["gather_checked_rows"] = int(full.shape[0])
         res.update({"ms_per_step_with_gather": elg / steps * 1e3, "value_with_gather": B4 * world * T * steps / elg,
                     "gather_ms": g_ms, "gather_bytes_per_rank": 4.0 * B4 * T,
-                    "gather": "torch.distributed.gather (nccl = RCCL) of every step's [64, T] waveforms into slices of the "
-                              "result on rank 0"})
+                    "gather": "torch.distributed.gather (%s) of every step's [%d, T] waveforms into slices of the "
+                              "result on rank 0" % ("nccl = RCCL" if RT.backend == "nccl" else RT.backend, B4)})
     else:
         res["gather"] = "not timed: no process group (run with --gather or N > 1)"
     return res
@@ -419,6 +454,103 @@ def cpu_baseline(kind, F, sizes, budget_s=12.0):
     return {"value": done * F * HOP / wall, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%d utterances of %d frames (%.1f s audio each), numpy oracle, %d worker processes, %.1f s wall"
                       % (done, F, F * HOP / SR, cores, wall)}
+
+
+def _reference_root():
+    """a reference checkout that travelled with this run (tools/with_reference.sh sets DDSP_REFERENCE_PATH), or None.
+    /root/reference itself is never read here: it does not exist on the GPU box."""
+    r = os.environ.get("DDSP_REFERENCE_PATH")
+    return r if r and os.path.isdir(os.path.join(r, "ddsp")) else None
+
+
+def _import_reference_vocoder(root):
+    from unittest.mock import MagicMock
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    for name in ["transformers", "pyworld", "parselmouth", "torchcrepe", "resampy", "fairseq", "torchaudio", "torchaudio.transforms",
+                 "gin", "local_attention", "librosa", "librosa.sequence", "librosa.util", "librosa.filters", "librosa.core",
+                 "soundfile"]:
+        sys.modules.setdefault(name, MagicMock())      # third-party imports of the reference that this image lacks (SURVEY 8-c)
+    import ddsp.vocoder as rvoc
+    return rvoc
+
+
+def cpu_baseline_reference(kind, F, n, device, budget_s=25.0):
+    """the UNMODIFIED reference module (ddsp/vocoder.py Sins / CombSub, random-init Unit2Control, eval,
+    no_grad, float32, infer=True) on this host's cores, same process and run as the GPU number -- full forward and DSP only
+    (forward minus the separately timed unit2ctrl) -- and the parity gate of 3.7 on the same inputs: the HIP path on the
+    controls the reference's own Unit2Control produced, against the reference's waveform (must be <= 1e-4 RMS)."""
+    from unittest import mock
+    root = _reference_root()
+    rvoc = _import_reference_vocoder(root)
+    from ddsp_svc_amd import synth
+    name = "CombSub" if kind == "combsub" else "Sins"
+    cls = getattr(rvoc, "_reference_" + name, getattr(rvoc, name))
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):         # the reference announces its models on stdout; the JSON line owns that
+        ref = cls(SR, HOP, n, n, n, n_unit=768, n_spk=1).eval()
+    T = F * HOP
+    g = torch.Generator().manual_seed(1234)
+    t_u2c = [0.0]
+    captured = {}
+
+    def pre(mod, args):
+        t_u2c.append(time.perf_counter())
+
+    def post(mod, args, out):
+        t_u2c[0] += time.perf_counter() - t_u2c.pop()
+        captured["ctrls"] = out[0]
+    ref.unit2ctrl.register_forward_pre_hook(pre)
+    ref.unit2ctrl.register_forward_hook(post)
+
+    def run(B):
+        units = torch.randn(B, F, 768, generator=g)
+        vol = torch.rand(B, F, 1, generator=g) * 0.1
+        f0 = torch.from_numpy(synthetic_f0(B, F, 1234))
+        u = torch.rand(B, T, generator=g)
+        t_u2c[0] = 0.0
+        t0 = time.perf_counter()
+        with torch.no_grad(), mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)):
+            sig, _, _ = ref(units, f0, vol, infer=True)
+        return time.perf_counter() - t0, t_u2c[0], sig, f0, u
+    B = 2
+    wall, u2c, sig, f0, u = run(B)                      # warm-up, and the parity gate's inputs
+    c = [v.to(device) for v in captured["ctrls"].values()]
+    st = synth.phase(f0.to(device), SR, HOP)
+    tail = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+    ours = tail(f0.to(device), st, c[0], c[1], c[2], u.to(device), SR, HOP, noise_is_u01=True, want_components=False)[0].cpu()
+    d = (ours - sig).double()
+    parity = {"rms_error": float(d.pow(2).mean().sqrt()), "max_abs_error": float(d.abs().max()),
+              "rms_reference": float(sig.double().pow(2).mean().sqrt()), "utterances": B, "bar": 1e-4}
+    parity["relative_rms"] = parity["rms_error"] / max(parity["rms_reference"], 1e-30)
+    if not parity["rms_error"] <= 1e-4:
+        raise SystemExit("parity gate failed against the reference module: %r" % parity)
+    # size the timed batch so that three runs fit the budget
+    B = max(1, min(32, int(B * (budget_s / 4.0) / max(wall, 1e-3))))
+    walls, dsps = [], []
+    for _ in range(3):
+        w, c_, _, _, _ = run(B)
+        walls.append(w)
+        dsps.append(w - c_)
+    w_med, d_med = sorted(walls)[1], sorted(dsps)[1]
+    cpu = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": B * T / d_med, "unit": "samples/s", "cores": threads, "kind": "reference",
+            "value_full_forward": B * T / w_med,
+            "sample": "the unmodified reference %s(44100, 512, %d, %d, %d, n_unit 768) on CPU tensors, %d utterances of %.1f s "
+                      "per run, 1 warm-up + 3 runs, median: full forward %.2f s, unit2ctrl %.2f s, DSP only %.2f s; value = DSP only"
+                      % (name, n, n, n, B, T / SR, w_med, w_med - d_med, d_med),
+            "torch_threads": torch.get_num_threads(), "host_cpu": cpu, "torch": torch.__version__,
+            "parity_vs_reference": parity}
 
 
 def _cpu_mel_worker(args):
@@ -577,7 +709,7 @@ def module_mode(kind, B, F, n, device, steps, warmup):
 def launch_ranks(n):
     """``--gpus N`` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    have = RT.device_count()
     if have < n:
         raise SystemExit("bench.py --gpus %d needs %d devices, this host shows %d" % (n, n, have))
     with socket.socket() as sk:
@@ -602,22 +734,21 @@ def setup_ranks(a):
     if world != a.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: refusing to report a different GPU count"
                          % (a.gpus, world))
-    if not torch.cuda.is_available():
+    if not RT.available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("bench.py --gpus %d needs %d devices, this host shows %d" % (a.gpus, a.gpus, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if RT.device_count() <= local_rank:
+        raise SystemExit("bench.py --gpus %d needs %d devices, this host shows %d" % (a.gpus, a.gpus, RT.device_count()))
+    device = RT.device(local_rank)
     info = {}
     if world > 1 or a.gather or a.cfg4:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        RT.init_process_group(rank, world, device)
         probe = torch.ones(1, device=device)
         dist.all_reduce(probe)
         info["rccl_ranks"] = int(probe.item())
         if info["rccl_ranks"] != world:
-            raise SystemExit("RCCL all-reduce saw %d ranks, expected %d" % (info["rccl_ranks"], world))
+            raise SystemExit("%s all-reduce saw %d ranks, expected %d" % (RT.backend, info["rccl_ranks"], world))
     return rank, world, device, info
 
 
@@ -1030,7 +1161,7 @@ def bench_cascade_seam(a, rank, world, device):
                 "dsp_kernels_ms is the product's part -- fast_source + stft filter + log-mel + NSF source"}))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -1054,7 +1185,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the Sins (cfg 3) / CombSubSuperFast lines of the N = 1 run")
     ap.add_argument("--cfg4", action="store_true",
                     help="also run BASELINE cfg 4's per-GPU shape (64 utterances per GPU) -- default at --gpus 8")
-    a = ap.parse_args()
+    ap.add_argument("--cfg4-batch", type=int, default=64, help="utterances per GPU of the cfg-4 line (BASELINE: 64)")
+    a = ap.parse_args(argv)
     if a.only_steps:
         a.prewarm_seconds = 0.0
 
@@ -1083,13 +1215,13 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        RT.synchronize()
 
     prewarm(step, a.prewarm_seconds)
     for _ in range(a.warmup):
         out = step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = RT.event(), RT.event()
     t0 = time.perf_counter()
     ev0.record()                                     # the same K steps on the device clock (launch stream)
     for _ in range(a.steps):
@@ -1256,6 +1388,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, F, sizes)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            if _reference_root():                        # a reference checkout travelled with this run: it IS the baseline
+                res["cpu_baseline_port"] = res["cpu_baseline"]
+                res["cpu_baseline"] = cpu_baseline_reference(a.model, F, n, device)
+                res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
             res["cpu_baseline_aten_chain"] = cpu_baseline_aten_chain(a.model, F, sizes)
             res["cpu_baseline_aten_chain"]["gpu_over_cpu"] = value / res["cpu_baseline_aten_chain"]["value"]
             if a.model in ("combsub", "sins"):

@@ -15,7 +15,7 @@ namespace ddsp {
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {

@@ -318,8 +318,8 @@ constexpr int SB3_LD = 4 + 4 * SB3_J;                 // floats per block in LDS
 
 __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0_frames,
                                                     const float* __restrict__ initial_phase,
-                                                    const float* __restrict__ c_amp, long ld_amp, int F, int H, int nblk,
-                                                    int nsingle, Upsampler up, PhaseCfg cfg,
+                                                    const float* __restrict__ c_amp, long ld_amp, int F, int H, int nblk_all,
+                                                    int nsingle_all, int skip_masked, Upsampler up, PhaseCfg cfg,
                                                     const double* __restrict__ phase0, float* __restrict__ out) {
   constexpr int HOP = 512;
   HIP_DYNAMIC_SHARED(float, amp)                    // [nblk][SB3_LD], then [nsingle][2]
@@ -334,6 +334,18 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
   const float* row0 = c_amp + (b * F + f) * ld_amp;
   const float* row1 = c_amp + (b * F + f1) * ld_amp;
   const float fa = f0_row[f], fb = f0_row[f1];
+  // Harmonics at or above Nyquist in BOTH frames of this hop keep 1e-7 of their amplitude (core.py:73-77: the mask is
+  // (f0 k < fmax) + 1e-7).  A trailing block of 17 whose LOWEST harmonic is masked in both frames is all such harmonics
+  // (f0 k grows with k), and so is every block behind it: they are left out -- at f0 = 400 Hz that is 200 of 256 harmonics.
+  // What that changes is 1e-7 of the masked harmonics' amplitudes (measured against the oracle in tests/test_parity.py
+  // test_sinusoid_bank; knob SINS_NOSKIP = 1 keeps them).  Workgroup-uniform; written so that a NaN f0 skips nothing.
+  int nblk = nblk_all, nsingle = nsingle_all;
+  if (skip_masked) {
+    auto masked = [&](int k) { const float kk = (float)k; return fa * kk >= nyq && fb * kk >= nyq; };
+    while (nblk > 0 && masked(1 + SB3_W * (nblk - 1))) --nblk;
+    if (nblk < nblk_all) nsingle = 0;
+    while (nsingle > 0 && masked(SB3_W * nblk_all + nsingle)) --nsingle;
+  }
   // activated, masked amplitude of harmonic k (1-based) in the two frames; zero outside 1..H
   auto amp2 = [&](int k, float& a0, float& a1) {
     a0 = 0.f;
@@ -364,7 +376,7 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
     } else {
       const int q = i - nblk * (SB3_J + 1);
       float p0, p1;
-      amp2(SB3_W * nblk + 1 + q, p0, p1);
+      amp2(SB3_W * nblk_all + 1 + q, p0, p1);                   // (singles survive only when no block was dropped: nblk = nblk_all)
       amp[nblk * SB3_LD + 2 * q] = p0;
       amp[nblk * SB3_LD + 2 * q + 1] = p1 - p0;
     }
@@ -435,7 +447,7 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
     S = __builtin_elementwise_fma(Cb, P, S);
   }
   for (int q = 0; q < nsingle; ++q) {               // one or two harmonics beyond the last whole block
-    const float k = (float)(SB3_W * nblk + 1 + q);
+    const float k = (float)(SB3_W * nblk_all + 1 + q);
     float c0, s0, c1, s1;
     cis_product(k, theta.x, c0, s0);
     cis_product(k, theta.y, c1, s1);
@@ -710,7 +722,7 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
     const int nblk = H / SB3_W + (rem > 2 ? 1 : 0), nsingle = rem > 2 ? 0 : rem;
     const size_t sh3 = ((size_t)nblk * SB3_LD + 2 * (size_t)nsingle + 4) * sizeof(float);
     hipLaunchKernelGGL(k_sins_bank3, dim3((unsigned)((long)B * F)), dim3(256), sh3, st, f0_frames, initial_phase, c_amp,
-                       ld_amp, F, H, nblk, nsingle, up, cfg, phase0, out);
+                       ld_amp, F, H, nblk, nsingle, knob(KNOB_SINS_NOSKIP) == 1 ? 0 : 1, up, cfg, phase0, out);
     return 0;
   }
   const int groups = (F + 3) / 4;

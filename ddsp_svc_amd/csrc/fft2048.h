@@ -206,6 +206,15 @@ __device__ __forceinline__ void dft8_lo4(f32x2* v) {
   v[1] = o0; v[3] = o1; v[5] = o2; v[7] = o3;
 }
 
+// exp(-i pi x): the twiddles' one call site of sincospif -- NOT inlined, so that a kernel's 24 twiddles cost one copy of its
+// ~40 instructions instead of 24 (a third of the code of the short-time kernels; code that is not there is not fetched,
+// DESIGN.md "instruction cache")
+__device__ __attribute__((noinline)) inline f32x2 cis_mpi(float x) {
+  float s, c;
+  sincospif(-x, &s, &c);
+  return f32x2{c, s};
+}
+
 // per-thread twiddles, computed once per workgroup lifetime (exact arguments: multiples of 2^-10)
 struct Twiddles {
   f32x2 w1[8];       // W_2048^(p k),   p = tid
@@ -215,13 +224,9 @@ struct Twiddles {
     const int c = tid & 31, n4 = tid & 3;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float s, co;
-      sincospif(-(float)((tid * k) & 2047) / 1024.0f, &s, &co);
-      w1[k] = f32x2{co, s};
-      sincospif(-(float)((c * k) & 255) / 128.0f, &s, &co);
-      w2[k] = f32x2{co, s};
-      sincospif(-(float)((n4 * k) & 31) / 16.0f, &s, &co);
-      w3[k] = f32x2{co, s};
+      w1[k] = cis_mpi((float)((tid * k) & 2047) / 1024.0f);
+      w2[k] = cis_mpi((float)((c * k) & 255) / 128.0f);
+      w3[k] = cis_mpi((float)((n4 * k) & 31) / 16.0f);
     }
   }
 };

@@ -33,16 +33,61 @@ struct Plan {
       const int c = tid & (C - 1), n4 = tid & (R - 1);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float s, co;
-        sincospif(-(float)((tid * k) & (N - 1)) / (float)(N / 2), &s, &co);
-        w1[k] = f32x2{co, s};
-        sincospif(-(float)((c * k) & (P - 1)) / (float)(P / 2), &s, &co);
-        w2[k] = f32x2{co, s};
-        sincospif(-(float)((n4 * k) & (C - 1)) / (float)(C / 2), &s, &co);
-        w3[k] = f32x2{co, s};
+        w1[k] = cis_mpi((float)((tid * k) & (N - 1)) / (float)(N / 2));
+        w2[k] = cis_mpi((float)((c * k) & (P - 1)) / (float)(P / 2));
+        w3[k] = cis_mpi((float)((n4 * k) & (C - 1)) / (float)(C / 2));
       }
     }
   };
+
+  // R = 2: the third set W_16^(n4 k) depends on the lane parity only -- 1 on even lanes, a constant on odd ones -- so it needs
+  // no registers: apply_w3 multiplies the odd lanes (exec mask) by constants held in scalar registers.  14 VGPRs less for a
+  // kernel that counts them (k_fir_blk6); the same 14 packed instructions.
+  struct TwLite {
+    f32x2 w1[8];       // W_N^(tid k)
+    f32x2 w2[8];       // W_P^(c k),   c = tid % 8R
+    __device__ __forceinline__ void init(int tid) {
+      static_assert(R == 2, "the scalar third set is implemented for the 1024-point plan");
+      const int c = tid & (C - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        w1[k] = cis_mpi((float)((tid * k) & (N - 1)) / (float)(N / 2));
+        w2[k] = cis_mpi((float)((c * k) & (P - 1)) / (float)(P / 2));
+      }
+    }
+  };
+  static __device__ __forceinline__ void apply_w3(f32x2 (&v)[8], const Tw& tw, int) { twiddle7(v, tw.w3); }
+  static __device__ __forceinline__ void apply_w3(f32x2 (&v)[8], const TwLite&, int tid) {
+    // W_16^k = cos(pi k / 8) - i sin(pi k / 8), k = 1..7, correctly rounded
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    const f32x2 c1 = {C1, -S1}, c2 = {H, -H}, c3 = {S1, -C1}, c4 = {0.f, -1.f}, c5 = {-S1, -C1}, c6 = {-H, -H}, c7 = {-C1, -S1};
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one block: exec narrowed to the odd lanes, seven products (v_pk_mul + v_pk_fma each, in place, four in flight), exec
+    // restored.  The factors are SGPR pairs; the even lanes' values are not touched.
+    f32x2 t0, t1, t2, t3;
+    unsigned long long saved;
+#define DDSP_W3M(t, a, w) "v_pk_mul_f32 %[" #t "], %[" #a "], %[" #w "] op_sel_hi:[0,1]\n"
+#define DDSP_W3F(t, a, w) "v_pk_fma_f32 %[" #a "], %[" #a "], %[" #w "], %[" #t "] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n"
+    asm("s_mov_b64 %[sv], exec\n"
+        "s_mov_b32 exec_lo, 0xaaaaaaaa\n"
+        "s_mov_b32 exec_hi, 0xaaaaaaaa\n"
+        DDSP_W3M(t0, a1, w1) DDSP_W3M(t1, a2, w2) DDSP_W3M(t2, a3, w3) DDSP_W3M(t3, a4, w4)
+        DDSP_W3F(t0, a1, w1) DDSP_W3F(t1, a2, w2) DDSP_W3F(t2, a3, w3) DDSP_W3F(t3, a4, w4)
+        DDSP_W3M(t0, a5, w5) DDSP_W3M(t1, a6, w6) DDSP_W3M(t2, a7, w7)
+        DDSP_W3F(t0, a5, w5) DDSP_W3F(t1, a6, w6) DDSP_W3F(t2, a7, w7)
+        "s_mov_b64 exec, %[sv]\n"
+        : [a1] "+v"(v[1]), [a2] "+v"(v[2]), [a3] "+v"(v[3]), [a4] "+v"(v[4]), [a5] "+v"(v[5]), [a6] "+v"(v[6]), [a7] "+v"(v[7]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(saved)
+        : [w1] "s"(c1), [w2] "s"(c2), [w3] "s"(c3), [w4] "s"(c4), [w5] "s"(c5), [w6] "s"(c6), [w7] "s"(c7));
+#undef DDSP_W3M
+#undef DDSP_W3F
+#else
+    if (tid & 1) {
+      v[1] = cmul(v[1], c1); v[2] = cmul(v[2], c2); v[3] = cmul(v[3], c3); v[4] = cmul(v[4], c4);
+      v[5] = cmul(v[5], c5); v[6] = cmul(v[6], c6); v[7] = cmul(v[7], c7);
+    }
+#endif
+  }
 
   // v[n1] = z[P n1 + tid]  ->  v[m] = Z[P m + tid].  A and B hold N complex words each.
   // A must be free of readers on entry; on return A may still be read by slower waves (pass 4), B is free.
@@ -207,8 +252,8 @@ struct Plan {
   // and Y may still be read by slower waves.
   // HI_ZERO: v[4..7] are zero on entry (input zero-padded from 512 to 1024 points)
   // FLIP: layout S- (lane_pair_dft2 above)
-  template <bool HI_ZERO = false, bool FLIP = false>
-  static __device__ __forceinline__ void forward_s(f32x2 (&v)[8], const Tw& tw, f32x2* X, f32x2* Y, int tid) {
+  template <bool HI_ZERO = false, bool FLIP = false, class TW = Tw>
+  static __device__ __forceinline__ void forward_s(f32x2 (&v)[8], const TW& tw, f32x2* X, f32x2* Y, int tid) {
     static_assert(R == 2, "layout S is implemented for the 1024-point plan");
     if (HI_ZERO) dft8_lo4(v);
     else dft8(v);
@@ -230,7 +275,7 @@ struct Plan {
 #pragma unroll
     for (int n3 = 0; n3 < 8; ++n3) v[n3] = Y[n3 * P + (tid ^ (n3 * R))];
     dft8(v);
-    twiddle7(v, tw.w3);
+    apply_w3(v, tw, tid);
     lane_pair_dft2<FLIP>(v, tid);
   }
   // Two independent transforms in lockstep (u through X0 / Y0, v through X1 / Y1): the same passes as forward_s, but
@@ -347,6 +392,54 @@ struct Plan {
     dft8(u);
     twiddle7x2(v, tw.w1, u, tw.w3);
     dft8(v);
+    lane_pair_dft2<FLIP>(u, tid);
+  }
+  // The same two transforms on THREE buffers: u runs one exchange behind v, so that v's first buffer is free again when u
+  // needs its second one.  Three barriers instead of the lockstep form's two, but 24 KB of exchange space instead of 32 --
+  // what a kernel that wants six 128-thread workgroups per CU (three waves per SIMD) can afford.
+  //     interval 0   v: first column -> Y
+  //     interval 1   v: Y -> middle column -> X          u: first column -> Q
+  //     interval 2   v: X -> last column (done)          u: Q -> middle column -> Y
+  //     interval 3                                       u: Y -> last column, lane-pair step (done)
+  // Y and Q must be free of readers on entry (Q: by the first barrier), X becomes free at the first barrier; on return X and
+  // Q are free and Y may still be read by slower waves.
+  template <bool FLIP = false, bool U_PRUNED = true, class TW = Tw>
+  static __device__ __forceinline__ void transposed_then_forward_s(f32x2 (&v)[8], f32x2 (&u)[8], const TW& tw, f32x2* Y,
+                                                                   f32x2* X, f32x2* Q, int tid) {
+    static_assert(R == 2, "layout S is implemented for the 1024-point plan");
+    const int k1 = tid / C, c = tid & (C - 1);
+    const int n3 = c / R, n4 = c & (R - 1);
+    lane_pair_dft2<FLIP>(v, tid);
+    apply_w3(v, tw, tid);
+    dft8(v);
+    const int ts = tid ^ (((tid / R) & 1) * C);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Y[k * P + (ts ^ (k * R))] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = Y[n3 * P + (((k ^ (k1 & 1)) * C + k1 * R + n4) ^ (n3 * R))];
+    if (U_PRUNED) dft8_lo4(u);
+    else dft8(u);
+    twiddle7x2(v, tw.w2, u, tw.w1);
+    dft8(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      X[k1 * P + k * C + c] = v[k];
+      Q[k * P + (tid ^ ((k & 1) * C))] = u[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = X[k * P + tid]; u[k] = Q[k1 * P + (k ^ (k1 & 1)) * C + c]; }
+    dft8(u);
+    twiddle7x2(v, tw.w1, u, tw.w2);
+    dft8(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Y[n3 * P + ((k * C + k1 * R + n4) ^ (n3 * R))] = u[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = Y[k * P + (tid ^ (k * R))];
+    dft8(u);
+    apply_w3(u, tw, tid);
     lane_pair_dft2<FLIP>(u, tid);
   }
 };

@@ -414,7 +414,12 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
   auto fits = [&](int waves) { return vec_ok && fir_mfma_lds_bytes(F, hop, N, waves) <= 64 * 1024; };
   // auto: the hop-block FFT form where it applies (hop 512, N <= 512: 0.137 ms against 0.188 ms for the per-frame
   // FFT form and 0.32 ms for the direct form at B = 32 x 10 s, N = 510), else the MFMA direct form, else the simple kernel
-  if (impl == 0 && hop == 512 && N <= 512) impl = 5;
+  if (impl == 0 && hop == 512 && N <= 512) {
+    // auto: the hop-block form unless it declines the shape (an utterance of 2^28 samples or more: its buffer descriptors
+    // span less than 2^30 bytes) -- then the direct forms below, not an error; only an explicit impl = 5 fails there
+    const int r = launch_fir_blk(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
+    if (r >= 0) return r;
+  }
   if (impl == 4) return launch_fir_fft(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
   if (impl == 5) return launch_fir_blk(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
   if (impl == 0) impl = fits(8) ? 3 : fits(4) ? 2 : 1;

@@ -28,7 +28,7 @@
 // bit-reproducible (different run splits agree to rounding: the first tap spectrum of a run comes out of a differently
 // packed transform).  A pair of blocks is two lockstep stages (fft_r.h): the two block transforms, then the pair's
 // inverse beside the transform of the next pair's tap rows.
-#include "fft_r.h"
+#include "fft_1024p.h"
 #include "kernels.h"
 #include "philox.h"
 #include <stdlib.h>
@@ -355,6 +355,280 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
   }
 }
 
+// ---- the same operator at three waves per SIMD (six workgroups per CU) ---------------------------------------------------
+// k_fir_blk above holds 226 registers and 32 KB of LDS per workgroup: four workgroups per CU, two waves per SIMD, and at two
+// waves a SIMD is bound by each wave's in-order issue.  A third wave needs <= 168 registers and <= 26.6 KB.
+// What moves, against the kernel above:
+//   * the filter spectra G0, G1 (32 registers through the whole first stage) are not kept: the tap transform T stays PARKED
+//     in its LDS buffer Cp from the end of one pass to the product of the next, and the product forms G0[m], G1[m], Hc'[m]
+//     from T[k] (its own parked value) and T[-k] (the mirrored read) bin by bin where it consumes them; only Hc is carried;
+//   * three exchange buffers instead of four (24 KB): the two block transforms run one after the other through X / Y
+//     (Cp is busy holding T), the pair's inverse and the next tap transform run staggered through Y / X / Cp
+//     (fft_r.h, transposed_then_forward_s); 8 barriers per pass instead of 6;
+//   * the loads of a pass's two blocks are issued half a pass ahead (at the top of its predecessor's second stage) instead of
+//     a whole pass: with six workgroups per CU there are other waves to cover what is left of their latency.
+// Buffer roles per pass (every wave is past the barrier that followed a buffer's last read before anyone writes it):
+//     z0: X -> Y      z1: X -> Y      product: reads Cp (T), parks B in X      barrier      mirrored read of X
+//     inverse: Y -> X beside taps: Cp -> Y      T parked in Cp (last read: the product, four barriers ago)
+// and the next pass's first write is to X, last read before the stage's third barrier.
+template <bool RNG = false>
+__global__ void __launch_bounds__(128, 3) k_fir_blk6(const float* __restrict__ x, int x_is_u01, const float* __restrict__ taps,
+                                                      const float* __restrict__ addend, float* __restrict__ out,
+                                                      float* __restrict__ out_plain, FirBlkGeom g, NoiseGen rng) {
+  using PL = fft::Plan1024P;
+  constexpr int NF = PL::N, P = PL::P, S = 8;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[3][PL::WORDS];
+  f32x2* const bX = ex[0];
+  f32x2* const bY = ex[1];
+  f32x2* const bC = ex[2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.runs_per_utt;
+  const int run_no = (int)((blockIdx.x - b * g.runs_per_utt + b + (b >> 4) + (b >> 8)) % g.runs_per_utt);
+  const int q_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);
+  const int q_last = (int)(((long)(run_no + 1) * g.pairs) / g.runs_per_utt);
+  const int SH = FB_HOP / 2 - (g.N >> 1);
+  const int bu = __builtin_amdgcn_readfirstlane(b);
+  const float* xb = x + (long)bu * g.T;
+  const float* tb = taps + (long)bu * g.F * g.N;
+  const long ob = (long)bu * g.T;
+  const BufF32 out_buf = BufF32::make(out + ob, g.T);
+  const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
+  const BufF32 add_buf = BufF32::make(addend ? addend + ob : out + ob, addend ? g.T : 0);
+  const int tid4 = 4 * tid;
+  // the Bartlett weights of this thread's four samples of a block: lambda_m = (128 m + tid) / 512 = lam0 + m / 4 and
+  // 1 - lambda_m = (1 - m / 4) - lam0, all exact.  Only lam0 is kept; the pairs are formed where they are used (one packed
+  // add each) -- as loop invariants they would hold eight registers that this kernel does not have
+  const float lam0 = (float)tid * (1.0f / (float)FB_HOP);
+  float tail[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) tail[m] = 0.f;
+  struct TapRow { float v[4]; };
+  int tap_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = P * m + tid - SH;
+    tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+  }
+  auto load_taps = [&](int j) -> TapRow {
+    TapRow r;
+    const int row = j < g.F ? j : g.F - 1;                     // core.py:167
+    const BufF32 tr = BufF32::make(tb + (long)row * g.N, g.N);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
+    return r;
+  };
+  struct Blk { float v[4]; };
+  auto load_blk = [&](int bi) -> Blk {
+    Blk r;
+    if (RNG) {
+      const Quad q = philox_uniform4(rng, (unsigned)bu, (unsigned)bi, (unsigned)tid);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) r.v[m] = bi < g.F ? q.u[m] : 0.f;
+      return r;
+    }
+    const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F ? FB_HOP : 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
+    return r;
+  };
+  auto pack_taps = [&](const TapRow& ta, const TapRow& tb2, f32x2 (&z)[S]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) z[m] = f32x2{ta.v[m], tb2.v[m]};
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
+  };
+  auto pack_blk = [&](const Blk& cx, bool live, f32x2 (&z)[S]) {
+    const bool u01 = (RNG || x_is_u01) && live;                 // noise = rand * 2 - 1 (vocoder.py:603,854)
+    const float ua = u01 ? 2.0f : 1.0f, ub = u01 ? -1.0f : 0.0f;
+    float l0 = lam0;
+    asm volatile("" : "+v"(l0));                                // not a loop invariant (see lam0)
+    const f32x2 lp = {-l0, l0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float xv = fmaf(ua, cx.v[m], ub);
+      const f32x2 w = f32x2{1.0f - 0.25f * (float)m, 0.25f * (float)m} + lp;   // (1 - lambda, lambda)
+      z[m] = w * f32x2{xv, xv};
+    }
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
+  };
+  const int kS0 = PL::s_index(tid, 0);
+  const int kP0 = PL::parked(kS0);
+  // the mirror image of slot m, parked, is at mb - 64 m (fft_1024p.h); not for slot 0 of threads 0, 1 (own_mirror)
+  const int mb = PL::mirror_base(tid);
+  auto mirrored = [&](const f32x2* X, int m) -> f32x2 { return PL::rd_parked(X + mb - 64 * m); };
+  const bool own_mirror = tid < 2;
+  const float sg = (tid & 1) ? -1.0f : 1.0f;
+  const float nsg = -sg;
+  // bins 0 and 512 (slot 0 of threads 0, 1) are their own mirror images: every other bin's mirror image lives on a thread of
+  // the other parity and comes back with the opposite sign (layout S-); for these two the thread's own value, negated, takes
+  // the place of the read, so that the split is one formula for all bins
+  auto park = [&](const f32x2 (&z)[S], f32x2* X) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) X[kP0 + 64 * m] = z[m];
+  };
+  const float ch = 0.5f / (float)NF;
+  const f32x2 kG1 = {-ch, ch};
+  const f32x2 kMi = {0.5f * ch, -0.5f * ch};
+  // the split of k_fir_blk's split_taps and its products in one sweep over the bins: from T (own value z, mirror image tn,
+  // both read from Cp) and the carried Hc:  G1 = -c conj tn,  G0 = Hc - i (c/2)(z - conj tn),  Hc' = -i (c/2)(z + conj tn);
+  // W0 = Z0 G0, W1 = Z1 G1;  A = W0 + i W1 replaces za, B = W0 - i W1 is parked for the mirrored read
+  auto split_and_products = [&](f32x2 (&za)[S], const f32x2 (&zb)[S], f32x2 (&Hc)[S], const f32x2* Tp, f32x2* Bp, f32x2& B0) {
+#pragma unroll
+    for (int m = 0; m < S; m += 2) {
+      const f32x2 o0 = PL::rd_parked(Tp + kP0 + 64 * m), o1 = PL::rd_parked(Tp + kP0 + 64 * (m + 1));
+      f32x2 tn0 = mirrored(Tp, m);
+      const f32x2 tn1 = mirrored(Tp, m + 1);
+      if (m == 0) tn0 = own_mirror ? -o0 : tn0;
+      const f32x2 p0 = fft::sub_conj(o0, tn0), p1 = fft::sub_conj(o1, tn1);
+      const f32x2 d0 = fft::add_conj(o0, tn0), d1 = fft::add_conj(o1, tn1);
+      const f32x2 g10 = tn0 * kG1, g11 = tn1 * kG1;
+      const f32x2 g00 = fft::swap_scale_add(p0, kMi, Hc[m]), g01 = fft::swap_scale_add(p1, kMi, Hc[m + 1]);
+      Hc[m] = fft::swap_scale(d0, kMi);
+      Hc[m + 1] = fft::swap_scale(d1, kMi);
+      const f32x2 t0 = fft::cmul_lo(za[m], g00), t1 = fft::cmul_lo(zb[m], g10);
+      const f32x2 t2 = fft::cmul_lo(za[m + 1], g01), t3 = fft::cmul_lo(zb[m + 1], g11);
+      const f32x2 w0 = fft::cmul_hi(za[m], g00, t0), w1 = fft::cmul_hi(zb[m], g10, t1);
+      const f32x2 w2 = fft::cmul_hi(za[m + 1], g01, t2), w3 = fft::cmul_hi(zb[m + 1], g11, t3);
+      za[m] = fft::sub_mi(w0, w1);
+      za[m + 1] = fft::sub_mi(w2, w3);
+      const f32x2 b0v = fft::add_mi(w0, w1);
+      if (m == 0) B0 = b0v;
+      Bp[kP0 + 64 * m] = b0v;
+      Bp[kP0 + 64 * (m + 1)] = fft::add_mi(w2, w3);
+    }
+  };
+  auto hermitian = [&](f32x2 (&a)[S], const f32x2* Bp, f32x2 B0) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      f32x2 bm = mirrored(Bp, m);
+      if (m == 0) bm = own_mirror ? B0 : bm;                    // B is plain layout S: the own value as it is
+      a[m] = fft::add_conj(bm, a[m]);
+    }
+  };
+
+  // the warm-up pass q_first - 1 is a pass of the same loop (see k_fir_blk): [rows b_w, b_w+1 | block b_w] where a pass of
+  // the run has its two blocks; its tap transform is parked in Cp where every other pass finds its predecessor's
+  const int bw = 2 * q_first - 1;
+  TapRow t1 = load_taps(bw > 0 ? bw : 0), t2 = load_taps(bw + 1);
+  Blk x0 = load_blk(bw >= 0 ? bw : g.F), x1 = x0;
+  typename PL::Tw tw;
+  tw.init(tid);
+  typename PL::Ix ix;
+  ix.init(tid);
+  f32x2 Hc[S];
+#pragma unroll
+  for (int m = 0; m < S; ++m) Hc[m] = f32x2{0.f, 0.f};
+  const bool has_add = addend != nullptr, has_plain = out_plain != nullptr;
+  const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;
+  const int turns_mask = g.turns ? 1 : 0;
+  float add[S];                                                 // the addend of the 1024 samples a pass emits (zeros without one)
+#pragma unroll
+  for (int i = 0; i < S; ++i) add[i] = 0.f;
+  for (int q = q_first - 1; q < q_last; ++q) {
+    const bool warm = q < q_first;                              // workgroup-uniform
+    if ((q + turn) & turns_mask) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+    const int b0 = 2 * q;
+    f32x2 z0[S], z1[S];
+#if defined(DDSP_B6_HALF_PASS_AHEAD)
+    if (warm) pack_taps(t1, t2, z0);                            // rows b_w, b_w + 1
+    else pack_blk(x0, b0 < g.F, z0);
+    // the tap rows of the next pass: their transform rides behind this pass's inverse
+    t1 = load_taps(b0 + 3);
+    t2 = load_taps(b0 + 4);
+    PL::template forward_s<true, true>(z0, tw, bX, bY, ix);
+    if (warm) pack_blk(x0, bw >= 0, z1);                        // block b_w
+    else pack_blk(x1, b0 + 1 < g.F, z1);
+    PL::template forward_s<true, true>(z1, tw, bX, bY, ix);
+#else
+    // Every global load is issued a whole pass ahead of its use, into the registers its predecessor has just left (inside
+    // a step the blocks and tap rows come from HBM, written by the kernel before: half a pass does not cover that --
+    // measured alone, on inputs that sit in the memory-side cache, 76 us; inside the step 88; profiles/r04_v5_*)
+    if (warm) {
+      pack_taps(t1, t2, z0);                                    // rows b_w, b_w + 1
+      t1 = load_taps(b0 + 3);                                   // the rows whose transform rides behind THIS pass's inverse
+      t2 = load_taps(b0 + 4);
+    } else {
+      pack_blk(x0, b0 < g.F, z0);
+      x0 = load_blk(b0 + 2);                                    // the next pass's first block
+    }
+    PL::template forward_s<true, true>(z0, tw, bX, bY, ix);
+    if (warm) {
+      pack_blk(x0, bw >= 0, z1);                                // block b_w
+      x0 = load_blk(b0 + 2);
+    } else {
+      pack_blk(x1, b0 + 1 < g.F, z1);
+    }
+    x1 = load_blk(b0 + 3);
+    PL::template forward_s<true, true>(z1, tw, bX, bY, ix);
+#endif
+    if (warm) {
+      park(z0, bC);                                             // Cp has no readers yet
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < S; ++m) z0[m] = f32x2{0.f, 0.f};     // the even block of this pass is absent
+    }
+    f32x2 B0;
+    split_and_products(z0, z1, Hc, bC, bX, B0);                 // z0 := A
+    __syncthreads();
+    hermitian(z0, bX, B0);                                          // z0 = conj(Y_b0 + i Y_b0+1)
+#if defined(DDSP_B6_HALF_PASS_AHEAD)
+    x0 = load_blk(b0 + 2);
+    x1 = load_blk(b0 + 3);
+#endif
+    // fetched now: this pass's addend
+    const int e0 = b0 * FB_HOP - 256 + tid;                     // first emitted time of this thread
+    const int off_a = b0 > 0 ? 4 * e0 : BufF32::kOutOfRange;
+    const int off_b = 4 * e0 + 8 * P;
+    auto t_off = [&](int i) -> int { return i < 2 ? off_a + 4 * P * i : off_b + 4 * P * (i - 2); };
+#if defined(DDSP_B6_HALF_PASS_AHEAD)
+    if (has_add && !warm) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));
+    }
+#endif
+    f32x2 zt[S];
+    pack_taps(t1, t2, zt);
+#if !defined(DDSP_B6_HALF_PASS_AHEAD)
+    t1 = load_taps(b0 + 5);                                     // the rows of the NEXT pass's second stage
+    t2 = load_taps(b0 + 6);
+#endif
+    PL::template transposed_then_forward_s<true>(z0, zt, tw, bY, bX, bC, ix);
+    park(zt, bC);                                               // read by the next pass's product, behind its first stage's barriers
+    if (!warm) {
+      float d[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) d[i] = i < 4 ? z0[i].x - tail[i] : z0[i].x - z0[i - 4].y;
+      if (has_plain) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) plain_buf.st(sg * d[i], t_off(i));
+      }
+#pragma unroll
+      for (int i = 0; i < S; ++i) out_buf.st(fmaf(sg, d[i], add[i]), t_off(i));
+      if (q == g.pairs - 1) {                                   // the last pair also emits the upper half of its second block
+#pragma unroll
+        for (int m = 4; m < S; ++m) {
+          const int off = t_off(4 + m);
+          const float v = nsg * z0[m].y;
+          if (has_plain) plain_buf.st(v, off);
+          out_buf.st(v + (has_add ? add_buf.ld(off) : 0.f), off);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tail[m] = z0[4 + m].y;
+#if !defined(DDSP_B6_HALF_PASS_AHEAD)
+    if (has_add) {                                              // the NEXT pass's addend (times b0 + 2 on: never negative), a pass ahead like every load
+      const int n0 = e0 + 2 * FB_HOP;                           // the next pass's first emitted time; negative only for b0 + 2 = 0
+      const int nx_a = b0 + 2 > 0 ? 4 * n0 : BufF32::kOutOfRange, nx_b = 4 * n0 + 8 * P;
+#pragma unroll
+      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(i < 2 ? nx_a + 4 * P * i : nx_b + 4 * P * (i - 2));
+    }
+#endif
+  }
+}
+
 // the same draw written out as a [B,T] tensor of u in [0,1) (tests, the oracle comparison, and callers whose noise filter
 // is not served by the in-kernel form); any T: block = t / 512, lane = t % 128, output word = (t % 512) / 128
 __global__ void __launch_bounds__(128) k_uniform_noise(NoiseGen rng, int B, long T, float* __restrict__ out) {
@@ -384,7 +658,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 1) / 2;
-  int wps = 2;
+  // three waves per SIMD (k_fir_blk6, six workgroups per CU) unless knob BLK_WPS = 2 asks for the two-wave kernel
+  // (k_fir_blk, four per CU: the round-3 form, kept for same-box A/B runs)
+  int wps = 3;
   if (const long v = knob(KNOB_BLK_WPS)) { if (v >= 1) wps = (int)v; }
   // run length: as many workgroups as the chip holds at once (2 waves each), one round, equal work; every run
   // but an utterance's first pays one warm-up block (three transforms; a pair costs four)
@@ -403,13 +679,14 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   NoiseGen rng{0ull, 0ull, 0};
   if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
     rng = *noise_gen;
-    hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+    if (wps >= 3) hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+    else hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
     return 5;
   }
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
   if (wps >= 3 && pad == 0)
-    hipLaunchKernelGGL((k_fir_blk<3, false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
+    hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   else
     hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   return 5;

@@ -11,6 +11,7 @@
 #include "ddsp_common.h"
 #include "fft_r.h"
 #include "kernels.h"
+#include "occupancy.h"
 
 namespace ddsp {
 using fft::cconj;
@@ -272,28 +273,17 @@ int taps_czt_plan(int n) {
   return 0;
 }
 
-template <class K>
-static int tc_resident(K kernel, int threads, int& cache) {
-  if (cache <= 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    cache = cus * per_cu;
-  }
-  return cache;
-}
-
 // 0 = taken, -1 = not its shape (use launch_ir_gemm)
 int launch_taps_czt(const float* a_re, long ld_re, const float* a_im, long ld_im, int act, float scale, const float* hann,
                     int mode, const float* half_width, long rows, int n, float* taps, hipStream_t st, float hw_from_f0_sr) {
   const int R = taps_czt_plan(n);
   if (!R || rows < 0 || (mode == TC_MODE_HANN && !hann) || (mode == TC_MODE_DYNAMIC && !half_width)) return -1;
+  if (act == 1 && a_im) return -1;          // exp of a complex response: only the dense form defines it (as launch_taps_pfa510 declines it)
   if (rows == 0) return 0;
-  static int cache[4];
-  const int resident = R == 1 ? tc_resident(k_taps_czt<1>, 64, cache[3])
-                     : R == 2 ? tc_resident(k_taps_czt<2>, 128, cache[0])
-                              : (R == 4 ? tc_resident(k_taps_czt<4>, 256, cache[1]) : tc_resident(k_taps_czt<8>, 512, cache[2]));
+  static ResidentCache cache[4];
+  const int resident = R == 1 ? resident_workgroups(k_taps_czt<1>, 64, cache[3])
+                     : R == 2 ? resident_workgroups(k_taps_czt<2>, 128, cache[0])
+                              : (R == 4 ? resident_workgroups(k_taps_czt<4>, 256, cache[1]) : resident_workgroups(k_taps_czt<8>, 512, cache[2]));
   const long pairs = (rows + 1) / 2;
   long per = (pairs + resident - 1) / resident;                  // one round of what the chip holds (loss_czt.hip)
   if (per < 1) per = 1;
@@ -322,10 +312,10 @@ int launch_taps_czt_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, in
   if (!R || rows < 0 || (mode == TC_MODE_HANN && !hann) || (mode == TC_MODE_DYNAMIC && !half_width)) return -1;
   if (act == 1 && (!ctrl || d_im)) return -1;
   if (rows == 0) return 0;
-  static int cache[4];
-  const int resident = R == 1 ? tc_resident(k_taps_czt_bwd<1>, 64, cache[3])
-                     : R == 2 ? tc_resident(k_taps_czt_bwd<2>, 128, cache[0])
-                              : (R == 4 ? tc_resident(k_taps_czt_bwd<4>, 256, cache[1]) : tc_resident(k_taps_czt_bwd<8>, 512, cache[2]));
+  static ResidentCache cache[4];
+  const int resident = R == 1 ? resident_workgroups(k_taps_czt_bwd<1>, 64, cache[3])
+                     : R == 2 ? resident_workgroups(k_taps_czt_bwd<2>, 128, cache[0])
+                              : (R == 4 ? resident_workgroups(k_taps_czt_bwd<4>, 256, cache[1]) : resident_workgroups(k_taps_czt_bwd<8>, 512, cache[2]));
   const long pairs = (rows + 1) / 2;
   long per = (pairs + resident - 1) / resident;
   if (per < 1) per = 1;

@@ -21,6 +21,7 @@
 #include "ddsp_common.h"
 #include "fft_r.h"
 #include "kernels.h"
+#include "occupancy.h"
 #include "tuning.h"
 
 namespace ddsp {
@@ -380,13 +381,14 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
       vn[n1] = cmul(cconj(gc), chr[n1]);                     // chr = 0 behind the last bin
     }
   };
-  if (p_lo < p_hi) { fetch(p_lo); prepare(p_lo); }
+  if (p_lo < p_hi) fetch(p_lo);
   const int turn = __builtin_amdgcn_s_getreg(0x1804) & 1;      // as the forward kernel
   for (int pi = p_lo; pi < p_hi; ++pi) {
     if (knob_turns && ((pi + turn) & 1)) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     const int f0 = 2 * pi;
     const bool two = f0 + 1 < frames;
+    prepare(pi);                                             // ONE call site (the bins were fetched between the previous pair's transforms): code that exists once is fetched once
     f32x2 v[8], co[4];
 #pragma unroll
     for (int n1 = 0; n1 < 4; ++n1) v[n1] = vn[n1];
@@ -412,7 +414,6 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
         if (two) o[(long)(f0 + 1) * n + j] = accumulate ? old1[m] - dj.y : -dj.y;
       }
     }
-    if (pi + 1 < p_hi) prepare(pi + 1);
     __syncthreads();                                         // pass 4 of the last transform still reads ex[0]
   }
   if (c == chunks - 1 && !accumulate)                        // samples behind the last whole frame do not reach the loss
@@ -425,29 +426,17 @@ __global__ void __launch_bounds__(64 * R, 2) k_sss_czt_bwd(const float2* __restr
 // table loads, the first fetch -- is worth about one frame, so 2 / 4 / 8 rounds cost +3 / +12 / +19 % of the step.
 struct WaveGeom { int chunks, span; };
 
-template <class K>
-static int czt_resident(K kernel, int threads, int& cache) {
-  if (cache <= 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    cache = cus * per_cu;
-  }
-  return cache;
-}
-
 static int czt_resident_of(int R, bool backward) {
-  static int cache[2][3];
-  int& c = cache[backward ? 1 : 0][R == 2 ? 0 : (R == 4 ? 1 : 2)];
+  static ResidentCache cache[2][3];
+  ResidentCache& c = cache[backward ? 1 : 0][R == 2 ? 0 : (R == 4 ? 1 : 2)];
   if (!backward) {
-    if (R == 2) return czt_resident(k_sss_czt<2>, 128, c);
-    if (R == 4) return czt_resident(k_sss_czt<4>, 256, c);
-    return czt_resident(k_sss_czt<8>, 512, c);
+    if (R == 2) return resident_workgroups(k_sss_czt<2>, 128, c);
+    if (R == 4) return resident_workgroups(k_sss_czt<4>, 256, c);
+    return resident_workgroups(k_sss_czt<8>, 512, c);
   }
-  if (R == 2) return czt_resident(k_sss_czt_bwd<2, 0>, 128, c);
-  if (R == 4) return czt_resident(k_sss_czt_bwd<4, 0>, 256, c);
-  return czt_resident(k_sss_czt_bwd<8, 0>, 512, c);
+  if (R == 2) return resident_workgroups(k_sss_czt_bwd<2, 0>, 128, c);
+  if (R == 4) return resident_workgroups(k_sss_czt_bwd<4, 0>, 256, c);
+  return resident_workgroups(k_sss_czt_bwd<8, 0>, 512, c);
 }
 
 static WaveGeom sss_wave_geom(int B, int n, int frames, bool backward) {

@@ -73,28 +73,42 @@ class _SpectralLossFunction(torch.autograd.Function):
 
 
 import collections
+import threading
 
 _CZT_TABLES = collections.OrderedDict()    # (device, stream, n_fft) -> chirps and filter spectrum of csrc/loss_czt.hip, LRU
-_CZT_TABLES_MAX = 4096                     # <= 64 KB each: every size RSSLoss can draw on two streams stays resident
+_CZT_TABLES_LOCK = threading.Lock()        # host threads of one process share the cache (get / insert / evict are not atomic)
+_CZT_TABLES_BYTES = 64 << 20               # byte budget of the cache: every size RSSLoss draws from [256, 2048) is ~47 MB per stream
+_czt_tables_held = 0
 
 
 def _czt_tables(n_fft, like):
     """The tables of one transform size on ``like``'s device, filled on first use (on the current stream, which is part
-    of the key: a second stream gets its own copy rather than a race with the fill).  None: size not supported."""
+    of the key: a second stream gets its own copy rather than a race with the fill).  None: size not supported.
+    A table first needed while a HIP graph is being captured is not cached: its contents exist only after a replay."""
+    global _czt_tables_held
     key = (str(like.device), _ffi.stream_of(like), int(n_fft))
-    t = _CZT_TABLES.get(key)
-    if t is None:
-        lib = _ffi.lib()
-        nbytes = lib.ddsp_hip_stft_loss_table_bytes(int(n_fft))
-        if nbytes == 0:
-            return None
-        t = torch.empty(nbytes // 4, dtype=torch.float32, device=like.device)
-        _ffi.check(lib.ddsp_hip_stft_loss_tables(int(n_fft), ptr(t), _ffi.stream_of(like)))
+    with _CZT_TABLES_LOCK:
+        t = _CZT_TABLES.get(key)
+        if t is not None:
+            _CZT_TABLES.move_to_end(key)
+            return t
+    lib = _ffi.lib()
+    nbytes = lib.ddsp_hip_stft_loss_table_bytes(int(n_fft))
+    if nbytes == 0:
+        return None
+    t = torch.empty(nbytes // 4, dtype=torch.float32, device=like.device)
+    _ffi.check(lib.ddsp_hip_stft_loss_tables(int(n_fft), ptr(t), _ffi.stream_of(like)))
+    if like.is_cuda and torch.cuda.is_current_stream_capturing():
+        return t
+    with _CZT_TABLES_LOCK:
+        other = _CZT_TABLES.get(key)
+        if other is not None:                                  # another thread filled the same key meanwhile: one copy is kept
+            return other
         _CZT_TABLES[key] = t
-        while len(_CZT_TABLES) > _CZT_TABLES_MAX:              # (a dropped table is freed once the work enqueued on it is done)
-            _CZT_TABLES.popitem(last=False)
-    else:
-        _CZT_TABLES.move_to_end(key)
+        _czt_tables_held += nbytes
+        while _czt_tables_held > _CZT_TABLES_BYTES and len(_CZT_TABLES) > 1:
+            _, dropped = _CZT_TABLES.popitem(last=False)       # (freed once the work already enqueued on it is done)
+            _czt_tables_held -= dropped.numel() * 4
     return t
 
 
@@ -271,6 +285,9 @@ class RSSLoss(torch.nn.Module):
     def _fused(self, x_pred, x_true, sizes):
         """All scales in one autograd node when every one of them takes the in-kernel transform (sizes the chirp-z plans
         cover, hops of at least one sample, signals of at least one frame); None otherwise."""
+        # ascending sizes: scales that share a transform plan (1024 / 2048 / 4096 points) then launch back to back, and the
+        # second launch finds the kernel's code in the instruction cache (the sum over the scales does not care about order)
+        sizes = sorted(sizes)
         hops = [int(n * (1 - self.overlap)) for n in sizes]                      # loss.py:19
         if any(h < 1 or h > n for h, n in zip(hops, sizes)):
             return None

@@ -1,6 +1,6 @@
 // Unit-test kernels for the in-register / LDS FFT plans of ddsp_svc_amd/csrc/fft_r.h, run under the CPU emulator
 // (tests/test_fft_plans.py compares them with numpy.fft).  TEST INFRASTRUCTURE ONLY.
-#include "fft_r.h"
+#include "fft_1024p.h"
 
 namespace {
 using ddsp::f32x2;
@@ -13,6 +13,9 @@ using ddsp::fft::Plan;
 // mode 4: Plan<2>::forward_s2<true>        two inputs (in, in2) -> (out, out2), both as mode 2
 // mode 5: Plan<2>::transposed_and_forward_s   in -> out as mode 3, in2 -> out2 as mode 2
 // modes 10..12 (every R): the lockstep pair forward2 (full / zero-padded inputs) and the zero-padded forward
+// modes 13, 14: Plan<2>::transposed_then_forward_s (the three-buffer, staggered form of mode 5), plain and in layout S-
+// modes 15, 16: the padded-row plan of fft_1024p.h (k_fir_blk6): forward_s<true, true> as mode 6, transposed_then_forward_s<true> as
+//                mode 14; mode 17: its mirror_base against parked(-k) for every slot but the two self-mirrored ones (out = count of mismatches)
 // modes 6..9: modes 2..5 in the sign-carrying layout S- (FLIP = true): what odd threads hold is written out negated
 //             again, so the expected values are those of modes 2..5
 template <int R>
@@ -60,6 +63,40 @@ __global__ void k_plan(int mode, const f32x2* in, const f32x2* in2, f32x2* out, 
       for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m]; out2[PL::s_index(tid, m)] = u[m]; }
     }
     const float sg = (tid & 1) ? -1.0f : 1.0f;
+    if (mode == 13 || mode == 14) {
+      for (int m = 0; m < 8; ++m) { v[m] = in[PL::s_index(tid, m)]; u[m] = in2[P * m + tid]; }
+      if (mode == 13) PL::transposed_then_forward_s(v, u, tw, ex[0], ex[1], ex[2], tid);
+      else PL::template transposed_then_forward_s<true>(v, u, tw, ex[0], ex[1], ex[2], tid);
+      const float s2 = mode == 14 ? sg : 1.0f;
+      for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m] * s2; out2[PL::s_index(tid, m)] = u[m] * s2; }
+    }
+    if (mode >= 15 && mode <= 17) {
+      using PP = ddsp::fft::Plan1024P;
+      __shared__ __attribute__((aligned(16))) f32x2 exp_[3][PP::WORDS];
+      typename PP::Tw twl;
+      twl.init(tid);
+      typename PP::Ix ix;
+      ix.init(tid);
+      if (mode == 15) {
+        for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
+        PP::template forward_s<true, true>(v, twl, exp_[0], exp_[1], ix);
+        for (int m = 0; m < 8; ++m) out[PL::s_index(tid, m)] = v[m] * sg;
+      } else if (mode == 16) {
+        for (int m = 0; m < 8; ++m) { v[m] = in[PL::s_index(tid, m)]; u[m] = in2[P * m + tid]; }
+        PP::template transposed_then_forward_s<true>(v, u, twl, exp_[0], exp_[1], exp_[2], ix);
+        for (int m = 0; m < 8; ++m) { out[P * m + tid] = v[m] * sg; out2[PL::s_index(tid, m)] = u[m] * sg; }
+      } else {
+        int bad = 0;
+        const int mb = PP::mirror_base(tid);
+        for (int m = 0; m < 8; ++m) {
+          const int want = PP::parked((1024 - PL::s_index(tid, m)) & 1023);
+          const bool self = tid < 2 && m == 0;
+          if (!self && mb - 64 * m != want) ++bad;
+          if (mb - 64 * m < 0 || mb - 64 * m >= PP::WORDS) ++bad;
+        }
+        out[tid] = f32x2{(float)bad, 0.f};
+      }
+    }
     if (mode == 6) {
       for (int m = 0; m < 8; ++m) v[m] = in[P * m + tid];
       PL::template forward_s<true, true>(v, tw, ex[0], ex[1], tid);

@@ -106,7 +106,7 @@ def test_backward_golden_and_autograd(dev, golden_dir, kind):
         assert rms(a.cpu().numpy() - ref) <= 5e-6 * rms(ref), (k, rms(a.cpu().numpy() - ref), rms(ref))
 
 
-@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("kind", ["fast", "superfast"])
 def test_module_training_step_matches_reference(dev, kind):
     """one backward pass through the drop-in module (reference Unit2Control inside): the parameter gradients equal the
@@ -130,6 +130,7 @@ def test_module_training_step_matches_reference(dev, kind):
     ref = ref_cls(*args, n_unit=n_unit, n_spk=1).train()
     ours = getattr(V, name)(*args, n_unit=n_unit, n_spk=1).train()
     ours.load_state_dict(ref.state_dict(), strict=True)
+    ours = ours.to(dev)                                         # the reference stays on its CPU path
     for m in (ref, ours):                                       # dropout off, everything else in training mode
         for sub in m.modules():
             if isinstance(sub, torch.nn.Dropout):
@@ -144,17 +145,22 @@ def test_module_training_step_matches_reference(dev, kind):
     with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)), \
             mock.patch("torch.randn_like", side_effect=lambda t: gz.reshape(t.shape)):
         r_sig, _, _ = ref(units, f0, vol, infer=True)
-    with mock.patch("torch.rand", side_effect=lambda *a, **k: u), mock.patch("torch.randn", side_effect=lambda *a, **k: gz):
-        o_sig, _, _ = ours(units, f0, vol, infer=True)
+    ud, gd = u.to(dev), gz.to(dev)
+    with mock.patch("torch.rand", side_effect=lambda *a, **k: ud), mock.patch("torch.randn", side_effect=lambda *a, **k: gd):
+        o_sig, _, _ = ours(units.to(dev), f0.to(dev), vol.to(dev), infer=True)
     (r_sig * R).sum().backward()
-    (o_sig * R).sum().backward()
-    checked = 0
+    (o_sig * R.to(dev)).sum().backward()
+    tol = 2e-5 if dev.type == "cpu" else 2e-3                   # on the MI355X Unit2Control's own GEMMs round differently from the CPU's
+    checked, worst = 0, 0.0
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), ours.named_parameters()):
         assert n1 == n2
         if p1.grad is None:
             assert p2.grad is None
             continue
         scale = max(rms(p1.grad.numpy()), 1e-12)
-        assert rms((p2.grad - p1.grad).numpy()) <= 2e-5 * scale + 1e-9, (n1, rms((p2.grad - p1.grad).numpy()), scale)
+        err = rms((p2.grad.cpu() - p1.grad).numpy())
+        worst = max(worst, err / scale)
+        assert err <= tol * scale + 1e-9, (n1, err, scale)
         checked += 1
+    print("training step %s on %s: %d parameter gradients, worst relative rms error %.2e" % (kind, dev, checked, worst))
     assert checked > 10

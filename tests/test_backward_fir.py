@@ -183,7 +183,7 @@ def test_sins_backward_golden(dev, golden_dir):
         assert rms(a.cpu().numpy() - ref) <= 3e-5 * rms(ref), (k, rms(a.cpu().numpy() - ref), rms(ref))
 
 
-@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("kind", ["combsub", "sins"])
 def test_combsub_module_training_step_matches_reference(dev, kind):
     """one backward pass through the drop-in CombSub / Sins (reference Unit2Control inside): parameter gradients equal
@@ -209,6 +209,7 @@ def test_combsub_module_training_step_matches_reference(dev, kind):
     ref = ref_cls(*args, n_unit=n_unit, n_spk=1).train()
     ours = getattr(V, name)(*args, n_unit=n_unit, n_spk=1).train()
     ours.load_state_dict(ref.state_dict(), strict=True)
+    ours = ours.to(dev)                                         # the reference stays on its CPU path
     for m in (ref, ours):
         for sub in m.modules():
             if isinstance(sub, torch.nn.Dropout):
@@ -219,19 +220,25 @@ def test_combsub_module_training_step_matches_reference(dev, kind):
     vol = torch.rand(B, F, 1, generator=g) * 0.1
     u = torch.rand(B, F * 512, generator=g)
     R = torch.randn(B, F * 512, generator=g)
+    ud = u.to(dev)
     with mock.patch("torch.rand_like", side_effect=lambda t: u.reshape(t.shape)):
         r_sig, _, _ = ref(units, f0, vol, infer=True)
-    with mock.patch("torch.rand", side_effect=lambda *a, **k: u):
-        o_sig, _, _ = ours(units, f0, vol, infer=True)
+    with mock.patch("torch.rand", side_effect=lambda *a, **k: ud):
+        o_sig, _, _ = ours(units.to(dev), f0.to(dev), vol.to(dev), infer=True)
     (r_sig * R).sum().backward()
-    (o_sig * R).sum().backward()
-    checked = 0
+    (o_sig * R.to(dev)).sum().backward()
+    # on the MI355X Unit2Control's own float32 GEMMs (forward and backward) round differently from the CPU's
+    tol = 5e-5 if dev.type == "cpu" else 2e-3
+    checked, worst = 0, 0.0
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), ours.named_parameters()):
         assert n1 == n2
         if p1.grad is None:
             assert p2.grad is None
             continue
         scale = max(rms(p1.grad.numpy()), 1e-12)
-        assert rms((p2.grad - p1.grad).numpy()) <= 5e-5 * scale + 1e-9, (n1, rms((p2.grad - p1.grad).numpy()), scale)
+        err = rms((p2.grad.cpu() - p1.grad).numpy())
+        worst = max(worst, err / scale)
+        assert err <= tol * scale + 1e-9, (n1, err, scale)
         checked += 1
+    print("training step %s on %s: %d parameter gradients, worst relative rms error %.2e" % (kind, dev, checked, worst))
     assert checked > 10

@@ -18,7 +18,7 @@ def plans():
     lib_emu = emu.build()                                   # the emulator runtime (hipemu.cpp) lives in the product's emulator build
     out = os.path.join(emu.OUT, "libfft_plans_test.so")
     src = os.path.join(HERE, "hipemu", "fft_plans_test.hip")
-    deps = [src, os.path.join(emu.CSRC, "fft_r.h"), os.path.join(emu.CSRC, "fft2048.h"), os.path.join(HERE, "hipemu", "hip", "hip_runtime.h")]
+    deps = [src, os.path.join(emu.CSRC, "fft_r.h"), os.path.join(emu.CSRC, "fft_1024p.h"), os.path.join(emu.CSRC, "fft2048.h"), os.path.join(HERE, "hipemu", "hip", "hip_runtime.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         obj = os.path.join(emu.OUT, "fft_plans_test.o")
         subprocess.run([emu._clang(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", emu.HERE, "-I", emu.CSRC,
@@ -93,6 +93,9 @@ def test_lockstep_forms_equal_their_parts(plans):
     v = _rand(1024, 22)
     inv, fwd = plans(2, 5, v, b)
     assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, one_b)
+    # the three-buffer form (the tap transform one exchange behind the inverse): the same arithmetic again
+    inv3, fwd3 = plans(2, 13, v, b)
+    assert np.array_equal(inv3, inv) and np.array_equal(fwd3, one_b)
 
 
 def test_sign_carrying_layout(plans):
@@ -106,6 +109,19 @@ def test_sign_carrying_layout(plans):
     assert np.array_equal(two_a, plans(2, 2, a)[0]) and np.array_equal(two_b, plans(2, 2, b)[0])
     inv, fwd = plans(2, 9, v, b)
     assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, plans(2, 2, b)[0])
+    inv, fwd = plans(2, 14, v, b)
+    assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, plans(2, 2, b)[0])
+
+
+def test_padded_row_plan(plans):
+    """fft_1024p.h (k_fir_blk6): the same transforms on padded exchange rows -- one base register per exchange instead of XOR
+    swizzles -- bit for bit; and its one-base form of the mirrored read against parked(-k) for every thread and slot"""
+    a, b = _rand(1024, 70, half=True), _rand(1024, 71, half=True)
+    v = _rand(1024, 72)
+    assert np.array_equal(plans(2, 15, a)[0], plans(2, 2, a)[0])
+    inv, fwd = plans(2, 16, v, b)
+    assert np.array_equal(inv, plans(2, 3, v)[0]) and np.array_equal(fwd, plans(2, 2, b)[0])
+    assert float(np.abs(plans(2, 17, a)[0][:128]).sum()) == 0.0
 
 
 def test_emulator_selftest():

@@ -123,7 +123,7 @@ def test_get_mel_contract(dev):
         M.STFT(44100, 80, 1024, 1024, 256, 40, 16000).get_mel(y)
 
 
-@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_against_reference_stft_class(dev):
     """the reference's own STFT.get_mel (librosa's filterbank replaced by the oracle's, the only missing piece in this
     image) against the drop-in on the same audio"""
@@ -142,7 +142,7 @@ def test_against_reference_stft_class(dev):
     y = torch.randn(2, 512 * 12, generator=g) * 0.2
     with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis):
         ref = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y)
-    ours = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y)
+    ours = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y.to(dev)).cpu()
     assert ours.shape == ref.shape
     _check(ours.numpy(), ref.numpy())
 
