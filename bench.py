@@ -1161,13 +1161,127 @@ def bench_cascade_seam(a, rank, world, device):
                 "dsp_kernels_ms is the product's part -- fast_source + stft filter + log-mel + NSF source"}))
 
 
+def bench_cascade_ref(a, rank, world, device):
+    """BASELINE cfg 5 with the REFERENCE's own networks (random weights), when a reference checkout travelled with the run
+    (DDSP_REFERENCE_PATH, tools/with_reference.sh): main_diff.py:356-378's loop body for B utterances of 10 s --
+        external DDSP model  ddsp/vocoder.py CombSub(256/256/256), the reference's Unit2Control inside     -> patch_reference(): HIP tail
+        vocoder.extract      nsf_hifigan/nvSTFT.py STFT.get_mel                                           -> patch_reference_stft(): k_mel
+        shallow diffusion    diffusion/vocoder.py Unit2Mel (WaveNet 20 x 384), dpm-solver, k_step 100 / speed-up 10 = 10 steps
+        vocoder.infer        nsf_hifigan/models.py Generator (44.1 kHz / hop 512 layout), SourceModuleHnNSF -> patch_reference_source(): k_sinegen
+    -- all of it unmodified reference code except the three patched seams.  Reported: the chain per step, and the same chain
+    with the seams unpatched (the reference's own DSP under PyTorch-ROCm) on the same GPU."""
+    import contextlib
+    import importlib
+    root = _reference_root()
+    if root is None:
+        raise SystemExit("--model cascade_ref needs a reference checkout: run under tools/with_reference.sh (DDSP_REFERENCE_PATH)")
+    rvoc = _import_reference_vocoder(root)
+    from ddsp_svc_amd import vocoder as V, mel as M, nsf_source as NS
+    with contextlib.redirect_stdout(sys.stderr):
+        dvoc = importlib.import_module("diffusion.vocoder")
+        nm = importlib.import_module("nsf_hifigan.models")
+        nv = importlib.import_module("nsf_hifigan.nvSTFT")
+        from nsf_hifigan.env import AttrDict
+    nv.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: M.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax).numpy()
+    h = AttrDict({"resblock": "1", "upsample_rates": [8, 8, 2, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4, 4],
+                  "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+                  "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "sampling_rate": SR, "num_mels": 128,
+                  "n_fft": 2048, "win_size": 2048, "hop_size": HOP, "fmin": 40, "fmax": 16000})
+    B = a.batch_per_gpu
+    F = int(a.seconds * SR) // HOP + 1
+    T = F * HOP
+    g = torch.Generator().manual_seed(31 + rank)
+    units = torch.randn(B, F, 768, generator=g).to(device)
+    vol = (torch.rand(B, F, 1, generator=g) * 0.1).to(device)
+    f0 = torch.from_numpy(synthetic_f0(B, F, 1234 + rank)).to(device)
+
+    def build():
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sys.stderr):
+            ddsp = rvoc.CombSub(SR, HOP, 256, 256, 256, n_unit=768, n_spk=1).to(device).eval()
+            diff = dvoc.Unit2Mel(768, 1, False, 128, 20, 384, 256).to(device).eval()
+            gen = nm.Generator(h).to(device).eval()
+            gen.remove_weight_norm()
+        stft = nv.STFT(SR, 128, 2048, 2048, HOP, 40, 16000)
+        return ddsp, diff, gen, stft
+
+    def chain(mods):
+        ddsp, diff, gen, stft = mods
+        with torch.no_grad():
+            wav, _, _ = ddsp(units, f0, vol)                                          # main_diff.py:359
+            mel = stft.get_mel(wav).transpose(1, 2)                                   # :360, diffusion/vocoder.py:147
+            out = diff(units, f0, vol, gt_spec=mel, infer=True, infer_speedup=10, method="dpm-solver", k_step=100,
+                       use_tqdm=False)                                                # :366-378
+            return gen(out.transpose(1, 2), f0[:, :out.size(1), 0])                   # :379, diffusion/vocoder.py:151-153
+
+    def timed(mods, steps, warm):
+        for _ in range(warm):
+            out = chain(mods)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = chain(mods)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, out
+    steps, warm = max(2, a.steps // 25), 1
+    # (1) the reference as it is: its own DSP under PyTorch-ROCm
+    t_ref, out_ref = timed(build(), steps, warm)
+    # (2) the three seams patched
+    V.patch_reference()
+    M.patch_reference_stft()
+    NS.patch_reference_source()
+    try:
+        mods = build()
+        assert type(mods[0]) is V.CombSub
+        t_hip, out = timed(mods, steps, warm)
+        # the product's share: the DSP pieces alone on resident inputs
+        from ddsp_svc_amd import synth
+        with torch.no_grad():
+            st = synth.phase(f0, SR, HOP)
+            ctrls, _ = mods[0].unit2ctrl(units, f0, st.phase_frames, vol)
+            u = torch.rand(B, T, device=device)
+            ri = torch.zeros(9, device=device)
+            nz9 = torch.randn(B, T, 9, device=device)
+            src = mods[2].m_source
+
+            def dsp():
+                s2 = synth.phase(f0, SR, HOP)
+                w = synth.combsub_synth(f0, s2, ctrls["group_delay"], ctrls["harmonic_magnitude"], ctrls["noise_magnitude"], u, SR,
+                                        HOP, noise_is_u01=True, want_components=False)[0]
+                m = mods[3].get_mel(w)
+                e = NS.sine_source(f0[..., 0], HOP, SR, src.l_linear.weight, src.l_linear.bias, ri, nz9)
+                return m, e
+            dsp_ms = time_alone(dsp, 10)
+    finally:
+        V.unpatch_reference()
+        nv.STFT.get_mel = nv.STFT._reference_get_mel
+        del nv.STFT._reference_get_mel
+        nm.SourceModuleHnNSF.forward = nm.SourceModuleHnNSF._reference_forward
+        del nm.SourceModuleHnNSF._reference_forward
+    assert out.shape == out_ref.shape and out.shape[0] == B and torch.isfinite(out).all() and torch.isfinite(out_ref).all()
+    if rank != 0:
+        return
+    emit({
+        "metric": "audio samples/sec, main_diff.py end to end with the reference's networks (cfg 5)", "value": B * world * T / t_hip,
+        "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": t_hip * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic, random weights",
+        "config": {"workload": "main_diff.py:356-379 for B=%d/GPU x %.0f s (F=%d, T=%d): reference CombSub(256/256/256) + Unit2Control, "
+                               "STFT.get_mel, Unit2Mel (WaveNet 20x384, dpm-solver 10 steps, k_step 100), NSF-HiFiGAN Generator "
+                               "(512 ch, rates 8-8-2-2-2); DSP seams patched to the HIP library" % (B, a.seconds, F, T),
+                   "batch_per_gpu": B, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
+        "reference_unpatched_ms_per_step": t_ref * 1e3, "speedup_over_unpatched": t_ref / t_hip,
+        "dsp_kernels_ms": dsp_ms, "dsp_share_of_step": dsp_ms / (t_hip * 1e3),
+        "note": "integration line: the neural networks are the reference's own PyTorch modules on the same GPU in both rows; "
+                "dsp_kernels_ms is the product's part of the patched chain (phase + CombSub tail + log-mel + NSF source)"})
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="combsub", choices=["combsub", "sins", "combsubfast", "combsubsuperfast", "mel", "sinesrc", "rssloss",
-                                                         "cascade_seam"])
+                                                         "cascade_seam", "cascade_ref"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--bins", type=int, default=256)
@@ -1203,6 +1317,9 @@ def main(argv=None):
         return finish_ranks()
     if a.model == "cascade_seam":
         bench_cascade_seam(a, rank, world, device)
+        return finish_ranks()
+    if a.model == "cascade_ref":
+        bench_cascade_ref(a, rank, world, device)
         return finish_ranks()
 
     B = a.batch_per_gpu

@@ -6,7 +6,8 @@ Sins/CombSub forward pass of yxlllc/DDSP-SVC).
   vocoder   -- nn.Module drop-ins + patch_reference()
   mel       -- nsf_hifigan.nvSTFT.STFT.get_mel (the cascade's waveform -> log-mel front-end)
   nsf_source -- nsf_hifigan.models.SourceModuleHnNSF (SineGen + merge), the vocoder's harmonic source
-  loss      -- ddsp/loss.py SSSLoss / RSSLoss (torch.stft + fused loss kernels)
+  loss      -- ddsp/loss.py SSSLoss / RSSLoss (the STFT of any size below 2049 as an in-kernel chirp-z transform, the loss and
+               its gradient in the same kernels; torch.stft only above that)
   sharding  -- utterance sharding across the GPUs of a node (+ optional RCCL gather)
 """
 from . import _ffi, build, core, loss, mel, nsf_source, synth  # noqa: F401

@@ -15,7 +15,7 @@ namespace ddsp {
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -80,6 +80,7 @@ struct Carver {
 struct SynthWs {
   float *buf0, *buf1, *taps, *re, *im;
   float *taps_nz, *nzbuf;      // the noise branch's own taps and output when it runs on a second stream
+  float *taps3;                // streaming shapes only (B F < kSmallRows): a third tap buffer, so that all tap syntheses of a step are one launch
 };
 
 // Fork / join of independent branches of a synthesiser tail onto a caller-provided second stream.  The events are
@@ -197,6 +198,7 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   }
   w.taps_nz = c.take<float>(R * N);
   w.nzbuf = c.take<float>(BT);
+  w.taps3 = (long)R < kSmallRows ? c.take<float>(R * N) : nullptr;
   return align_up(c.used, 256);
 }
 
@@ -457,12 +459,31 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
-  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
   // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
   float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+  const TapsFormScope form;
+  // Streaming shapes (as ddsp_hip_combsub_synth below): both tap syntheses in one launch -- four dependent launches instead of
+  // five: sinusoid bank | taps (grid.y) | noise filter | all-pass filter + noise.  Same kernels, same arguments, same bits.
+  if (R < kSmallRows && n_ap == 256 && n_nz == 256 && !t_taps_gemm && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
+    const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
+    if (r == -1) return DDSP_HIP_EHOP;
+    if (r == -2) return DDSP_HIP_ESHAPE;
+    TapsJobs jobs;
+    jobs.n = 0;
+    int ok = launch_taps_pfa510(c_nz, ld_nz, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                                n_nz, w.taps_nz, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                             w.taps, st, 0.f, &jobs);
+    if (ok != 0 || launch_taps_pfa510_batch(jobs, st) != 0) return DDSP_HIP_ESHAPE;
+    if (launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, st, &gen) < 0)
+      return DDSP_HIP_ESHAPE;
+    if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
+  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
   // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
   // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
-  const TapsFormScope form;
   const bool ap_ahead = n_ap == 256 && !t_taps_gemm && knob(KNOB_STREAM_LAYOUT) != 1;
   if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
   synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
@@ -504,6 +525,34 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (!c.ok) return DDSP_HIP_EWS;
   hipStream_t st = S(stream);
   const long R = (long)B * F;
+  const TapsFormScope form;
+  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
+  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
+  // Streaming shapes (B = 1, a fraction of a second per call: gui.py:118-133): the step's latency is its chain of DEPENDENT
+  // launches (~9 us each on the GPU whatever the length), so the same kernels are issued as THREE launches instead of seven:
+  // exciter and the three tap syntheses (k_front_small, grid.y) | all-pass filter beside the noise filter (grid.y) | harmonic
+  // filter + noise.
+  // Same kernels, same arguments, same bits as the batch layout below (tests/test_small_shapes.py); knob SMALL_PATH = 1: off.
+  if (R < kSmallRows && all256 && hop == 512 && !gen.on && (fir_impl == 0 || fir_impl == 5) && w.taps3 &&
+      knob(KNOB_SMALL_PATH) != 1 && knob(KNOB_BLK_WPS) != 2 && knob(KNOB_BLK_PADLDS) == 0) {
+    ExciterJob exc;
+    if (make_exciter_job(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
+    TapsJobs jobs;
+    jobs.n = 0;
+    int ok = launch_taps_pfa510(c_nz, ld_nz, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
+                                n_nz, w.taps_nz, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                             w.taps, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(c_harm, ld_harm, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
+                             n_harm, w.taps3, st, (float)sr, &jobs);
+    if (ok != 0 || launch_taps_pfa510_batch(jobs, st, &exc) != 0) return DDSP_HIP_ESHAPE;   // exciter + the three tap syntheses
+    const FirSecond second{noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr};
+    if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, nullptr, &second) < 0)
+      return DDSP_HIP_ESHAPE;
+    if (launch_fir(w.buf1, 0, w.taps3, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
   Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
   // Stream layout (knob STREAM_LAYOUT).  1: the noise branch -- its taps and its filter -- on the second stream beside the
   // harmonic chain, joined into the last filter as its addend.  4 (default where every filter has 256 bins; otherwise the
@@ -513,11 +562,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   // lost (all taps ahead on the second stream, 0.424; the second harmonic filter's taps there too, 0.403; the harmonic
   // chain's front on the second stream, 0.439 against 0.422) are in DESIGN.md section 7 and no longer in the code.
   long layout = knob(KNOB_STREAM_LAYOUT);
-  const TapsFormScope form;
-  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
   if (layout != 1) layout = 4;
   if (!all256) layout = 1;
-  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
   int rc = 0;
   if (layout == 4) {                                       // exciter: combtooth (vocoder.py:839-840)
     rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, br.aux);

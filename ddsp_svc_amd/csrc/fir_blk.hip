@@ -371,10 +371,24 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
 //     z0: X -> Y      z1: X -> Y      product: reads Cp (T), parks B in X      barrier      mirrored read of X
 //     inverse: Y -> X beside taps: Cp -> Y      T parked in Cp (last read: the product, four barriers ago)
 // and the next pass's first write is to X, last read before the stage's third barrier.
+// A launch takes one or two JOBS (grid.y): filters of the same shape that do not depend on each other -- the all-pass and the
+// noise filter of a CombSub step at a streaming shape, where the chain of dependent launches is the latency.
+struct FirJob {
+  const float* x; int x_is_u01;
+  const float* taps; const float* addend;
+  float* out; float* out_plain;
+};
+struct FirJobs { FirJob j[2]; };
+
 template <bool RNG = false>
-__global__ void __launch_bounds__(128, 3) k_fir_blk6(const float* __restrict__ x, int x_is_u01, const float* __restrict__ taps,
-                                                      const float* __restrict__ addend, float* __restrict__ out,
-                                                      float* __restrict__ out_plain, FirBlkGeom g, NoiseGen rng) {
+__global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g, NoiseGen rng) {
+  const FirJob& J = jobs.j[blockIdx.y];
+  const float* __restrict__ x = J.x;
+  const int x_is_u01 = J.x_is_u01;
+  const float* __restrict__ taps = J.taps;
+  const float* __restrict__ addend = J.addend;
+  float* __restrict__ out = J.out;
+  float* __restrict__ out_plain = J.out_plain;
   using PL = fft::Plan1024P;
   constexpr int NF = PL::N, P = PL::P, S = 8;
   __shared__ __attribute__((aligned(16))) f32x2 ex[3][PL::WORDS];
@@ -653,7 +667,7 @@ int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int
 
 // returns the implementation id (5) or < 0 when the shape is outside this kernel
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen) {
+                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen, const FirSecond* second) {
   if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance stays below 2^30 bytes (buffer descriptors, BufF32::kOutOfRange)
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
@@ -668,7 +682,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
-  if (run < 3) run = 3;
+  // at least three pairs per workgroup (each pays a warm-up block and its twiddles) -- except at streaming shapes, where every
+  // workgroup is resident at once anyway and the launch is as long as its longest workgroup: one pair each
+  if (run < 3 && (long)B * F >= kSmallRows) run = 3;
   if (const long v = knob(KNOB_BLK_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
@@ -677,16 +693,27 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
+  FirJobs jobs;
+  jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain};
+  jobs.j[1] = jobs.j[0];
   if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
+    if (second) return -1;
     rng = *noise_gen;
-    if (wps >= 3) hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+    jobs.j[0].x_is_u01 = 0;
+    if (wps >= 3) hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
     else hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
     return 5;
   }
+  if (second && wps >= 3) {                                     // two independent filters of this shape in one launch
+    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain};
+    hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs, 2u), dim3(128), 0, st, jobs, g, rng);
+    return 5;
+  }
+  if (second) return -1;
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
   if (wps >= 3 && pad == 0)
-    hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs), dim3(128), 0, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
+    hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
   else
     hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
   return 5;

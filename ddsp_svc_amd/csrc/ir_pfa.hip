@@ -21,6 +21,7 @@
 //   stage C  window + fully coalesced 16-byte stores of the batch's contiguous 16 x 510 taps
 #include "ddsp_common.h"
 #include "fft2048.h"
+#include "frame_phase.h"
 #include "kernels.h"
 
 namespace ddsp {
@@ -185,12 +186,38 @@ static_assert(U_FLOATS >= 2 * W_WORDS && U_FLOATS >= HW_AT + 2 * ROWS, "union re
 // instead of three of 11-17 KB that evict each other and the filter kernel -- on the part of the pool where an
 // instruction fetch past that cache is slow, a cold launch of this kernel takes 44-62 us against 28-38 warm (DESIGN.md,
 // "instruction cache").  Every switch on them is workgroup-uniform (scalar branches).
-__global__ void __launch_bounds__(256, 4) k_taps_pfa510(int KIND, int ACT, int MODE, const float* __restrict__ a_re, long ld_re,
-                                                     const float* __restrict__ a_im, long ld_im, float scale,
-                                                     const float* __restrict__ hann, const float* __restrict__ half_width,
-                                                     float hw_sr, long rows, float* __restrict__ taps) {
+//
+// A launch takes up to three JOBS (grid.y): the three tap syntheses of a CombSub / Sins step depend on the controls only, so a
+// step at a streaming shape (B = 1, a fraction of a second: the chain of dependent launches IS its latency, ~9 us each)
+// issues them as one launch.  The job is workgroup-uniform like everything it selects.
+//
+// EXC (k_front_small): one more row of workgroups (blockIdx.y = jobs.n) makes the step's exciter, the combtooth
+// (frame_phase.h), 16 frames each -- it depends on the phase state only, like the tap syntheses on the controls, so a
+// streaming-shape CombSub step has ONE launch in front of its filters.  A second entry point, so that the batch layout's
+// kernel does not carry the exciter's code through the instruction cache.
+template <bool EXC>
+__device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const ExciterJob& exc, float* U) {
   using namespace pfa;
-  __shared__ __attribute__((aligned(16))) float U[U_FLOATS];
+  if (EXC && (int)blockIdx.y == jobs.n) {                  // workgroup-uniform; before any barrier
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int q = 0; q < ROWS / 4; ++q) {
+      const long fr = (long)blockIdx.x * ROWS + q * 4 + wave;
+      if (fr < exc.n_frames)
+        combtooth_frame<8, true>(exc.f0_frames, exc.initial_phase, fr, exc.F, exc.hop, exc.up, exc.cfg, exc.phase0, exc.out, lane);
+    }
+    return;
+  }
+  const TapsJob& J = jobs.j[blockIdx.y];
+  const int KIND = J.kind, ACT = J.act, MODE = J.mode;
+  const float* __restrict__ a_re = J.a_re;
+  const float* __restrict__ a_im = J.a_im;
+  const long ld_re = J.ld_re, ld_im = J.ld_im;
+  const float scale = J.scale, hw_sr = J.hw_sr;
+  const float* __restrict__ hann = J.hann;
+  const float* __restrict__ half_width = J.half_width;
+  const long rows = J.rows;
+  float* __restrict__ taps = J.taps;
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * ROWS;
   float* re_s = U;
@@ -454,6 +481,16 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510(int KIND, int ACT, int M
   PFA_STAMP(4);
 }
 
+__global__ void __launch_bounds__(256, 4) k_taps_pfa510(TapsJobs jobs) {
+  __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
+  taps_pfa510_body<false>(jobs, ExciterJob{}, U);
+}
+
+__global__ void __launch_bounds__(256, 4) k_front_small(TapsJobs jobs, ExciterJob exc) {
+  __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
+  taps_pfa510_body<true>(jobs, exc, U);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adjoint of the tap synthesis at 256 bins (what autograd returns for core.py:254-270 + the window helpers): d_taps
 // [rows, 510] -> gradient of the one-sided response (or of the raw control through the exp activation).  The forward is
@@ -618,7 +655,7 @@ int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl,
 // returns 0 when the fast form took the call, -1 when the shape is not its (the caller then uses the dense contraction)
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                       hipStream_t st, float hw_from_f0_sr) {
+                       hipStream_t st, float hw_from_f0_sr, TapsJobs* batch) {
   if (n != pfa::NB || rows <= 0) return -1;                 // (knob TAPS_GEMM is the caller's decision: read once per API call)
   if ((reinterpret_cast<uintptr_t>(taps) & 15) != 0) return -1;
   const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
@@ -633,8 +670,29 @@ int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld
     kind = pfa::KIND_COMPLEX;
   }
   const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
-  hipLaunchKernelGGL(k_taps_pfa510, grid, block, 0, st, kind, act == 1 ? 1 : 0, m, a_re, ld_re, a_im, ld_im, scale, hann, half_width,
-                     hw_from_f0_sr, rows, taps);
+  TapsJob job{kind, act == 1 ? 1 : 0, m, a_re, ld_re, a_im, ld_im, scale, hann, half_width, hw_from_f0_sr, rows, taps};
+  if (batch) {                                              // collected, launched by launch_taps_pfa510_batch (all jobs: the same row count)
+    if (batch->n >= 3 || (batch->n > 0 && batch->j[0].rows != rows)) return -1;
+    batch->j[batch->n++] = job;
+    return 0;
+  }
+  TapsJobs jobs;
+  jobs.j[0] = job;
+  jobs.n = 1;
+  hipLaunchKernelGGL(k_taps_pfa510, grid, block, 0, st, jobs);
+  return 0;
+}
+
+int launch_taps_pfa510_batch(const TapsJobs& jobs, hipStream_t st, const ExciterJob* exciter) {
+  if (jobs.n < 1) return 0;
+  const long rows = jobs.j[0].rows;
+  const unsigned gx = (unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS);
+  if (exciter) {
+    if (exciter->n_frames != rows || exciter->hop != 512 || exciter->up.shift <= 0) return -1;
+    hipLaunchKernelGGL(k_front_small, dim3(gx, (unsigned)jobs.n + 1u), dim3(256), 0, st, jobs, *exciter);
+  } else {
+    hipLaunchKernelGGL(k_taps_pfa510, dim3(gx, (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  }
   return 0;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "ddsp_common.h"
 #include "tuning.h"
 
 namespace ddsp {
@@ -36,9 +37,33 @@ int launch_taps_czt_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, in
                         const float* half_width, long rows, int n, float* d_re, float* d_im, hipStream_t st);
 // prime-factor form of the tap synthesis for n_mag = 256 (ir_pfa.hip); 0 = taken, -1 = not its shape (use launch_ir_gemm).
 // allpass_from_control: a_re is the raw group-delay control (pi*tanh -> cumsum -> cos/sin done in the kernel).
+// one tap synthesis of k_taps_pfa510 as data: a launch takes up to three of them (grid.y)
+struct TapsJob {
+  int kind, act, mode;
+  const float* a_re; long ld_re;
+  const float* a_im; long ld_im;
+  float scale;
+  const float* hann;
+  const float* half_width;
+  float hw_sr;
+  long rows;
+  float* taps;
+};
+struct TapsJobs { TapsJob j[3]; int n; };
+// batch != null: the job is appended to *batch instead of being launched (launch_taps_pfa510_batch launches them together)
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                       hipStream_t st, float hw_from_f0_sr = 0.f);
+                       hipStream_t st, float hw_from_f0_sr = 0.f, TapsJobs* batch = nullptr);
+// the exciter of a streaming-shape CombSub step as data (launch_combtooth's arguments): rides in the tap launch (k_front_small)
+struct ExciterJob {
+  const float* f0_frames; const float* initial_phase;
+  long n_frames; int F, hop;
+  Upsampler up; PhaseCfg cfg;
+  const double* phase0; float* out;
+};
+int make_exciter_job(const float* f0_frames, const float* initial_phase, int B, int F, int hop, double sr, int infer,
+                     const double* phase0, float* out, ExciterJob* job);   // 0, or -1 when the shape is not the fused form's
+int launch_taps_pfa510_batch(const TapsJobs& jobs, hipStream_t st, const ExciterJob* exciter = nullptr);
 int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                            int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                            hipStream_t st);
@@ -53,8 +78,12 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
 int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int B, long T, float* out, hipStream_t st);
 int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st);
+// second != null: a second, independent filter of the same shape (B, F, hop, N) rides in the same launch (k_fir_blk6, grid.y);
+// -1 when this launch cannot take it (the in-kernel noise draw, the two-wave kernel)
+struct FirSecond { const float* x; int x_is_u01; const float* taps; const float* addend; float* out; float* out_plain; };
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr);
+                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr,
+                   const FirSecond* second = nullptr);
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st);
 int launch_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc, float* phase_frames,

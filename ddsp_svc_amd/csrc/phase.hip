@@ -8,6 +8,7 @@
 // per-frame start value with one more wave scan (frame_phase() below) instead of reading a
 // [B,T] tensor back from HBM.
 #include "ddsp_common.h"
+#include "kernels.h"
 
 namespace ddsp {
 
@@ -80,14 +81,12 @@ __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restric
 // level 3: exclusive scan of the frame totals of one utterance; also emits phase_frames
 // (= 2*pi*x[:, ::hop], vocoder.py:574-575).  One 256-thread workgroup per utterance.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_phase_frame_scan(const float* __restrict__ f0_frames,
-                                                          const float* __restrict__ initial_phase, int F, int hop,
-                                                          Upsampler up, PhaseCfg cfg, const double* __restrict__ sums,
-                                                          double* __restrict__ phase0, float* __restrict__ phase_frames) {
-  __shared__ double part[256];
+// the scan of one utterance's frame totals s[0..F) by the 256 threads of a workgroup (both kernels below)
+__device__ __forceinline__ void phase_scan_utterance(const float* __restrict__ f0_frames, const float* __restrict__ initial_phase,
+                                                     int F, int hop, const Upsampler& up, const PhaseCfg& cfg, const double* s,
+                                                     double* __restrict__ phase0, float* __restrict__ phase_frames, long b,
+                                                     double* part) {
   const int tid = threadIdx.x;
-  const long b = blockIdx.x;
-  const double* s = sums + b * F;
   const int chunk = (F + 255) / 256;
   const int lo = tid * chunk;
   const int hi = (lo + chunk < F) ? lo + chunk : F;
@@ -113,6 +112,46 @@ __global__ void __launch_bounds__(256) k_phase_frame_scan(const float* __restric
     }
     run += s[f];
   }
+}
+
+__global__ void __launch_bounds__(256) k_phase_frame_scan(const float* __restrict__ f0_frames,
+                                                          const float* __restrict__ initial_phase, int F, int hop,
+                                                          Upsampler up, PhaseCfg cfg, const double* __restrict__ sums,
+                                                          double* __restrict__ phase0, float* __restrict__ phase_frames) {
+  __shared__ double part[256];
+  const long b = blockIdx.x;
+  phase_scan_utterance(f0_frames, initial_phase, F, hop, up, cfg, sums + b * F, phase0, phase_frames, b, part);
+}
+
+// Streaming shapes (B = 1, a fraction of a second per call -- gui.py:118-133): both levels in ONE launch, one workgroup per
+// utterance: its four waves take the frames in turn (the frame totals exactly as k_phase_frame_sums<8, true> forms them),
+// the totals wait in LDS, the same scan follows.  At such shapes a step's latency is its chain of dependent launches, about
+// 9 us each, not the work; at batch shapes the per-sample float64 work wants the whole chip (the two-launch form above).
+constexpr int PH_SMALL_MAX_F = 1024;
+
+__global__ void __launch_bounds__(1024) k_phase_small(const float* __restrict__ f0_frames, const float* __restrict__ initial_phase,
+                                                      int F, int hop, Upsampler up, PhaseCfg cfg, double* __restrict__ sums,
+                                                      double* __restrict__ phase0, float* __restrict__ phase_frames) {
+  constexpr int SPL = 8;
+  __shared__ double part[1024];                      // the scan is the first 256 threads' (the others hold empty chunks)
+  __shared__ double tot[PH_SMALL_MAX_F];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long b = blockIdx.x;
+  const float* row = f0_frames + b * F;
+#pragma unroll 1
+  for (int f = wave; f < F; f += 16) {
+    const Upsampler::Row3 rows = up.load3(row, f);
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < SPL; ++r) {
+      const int j = lane * SPL + r;
+      if (j < hop) acc += cfg.term(up.at3_pow2(rows, j));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) { tot[f] = acc; sums[b * F + f] = acc; }
+  }
+  __syncthreads();
+  phase_scan_utterance(f0_frames, initial_phase, F, hop, up, cfg, tot, phase0, phase_frames, b, part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,6 +249,11 @@ int launch_phase(const float* f0_frames, const float* initial_phase, int B, int 
   Upsampler up = make_upsampler(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
+  if (!x_or_null && spl == 8 && up.shift > 0 && F <= PH_SMALL_MAX_F && n_frames < kSmallRows && knob(KNOB_SMALL_PATH) != 1) {
+    hipLaunchKernelGGL(k_phase_small, dim3((unsigned)B), dim3(1024), 0, st, f0_frames, initial_phase, F, hop, up, cfg, frame_sums,
+                       phase0, phase_frames);
+    return 0;
+  }
   const dim3 sgrid((unsigned)((n_frames + 4 * PH_FRAMES_PER_WAVE - 1) / (4 * PH_FRAMES_PER_WAVE)));
   if (spl == 8)
     if (up.shift > 0) hipLaunchKernelGGL((k_phase_frame_sums<8, true>), sgrid, block, 0, st, f0_frames, n_frames, F, hop, up, cfg, frame_sums);

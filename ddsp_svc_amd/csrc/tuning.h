@@ -9,9 +9,12 @@ namespace ddsp {
 enum Knob {
   KNOB_BLK_WPS = 0, KNOB_BLK_RUN, KNOB_BLK_PADLDS, KNOB_FFT_RUN, KNOB_STFT_WPS, KNOB_STFT_RUN, KNOB_MEL_WPS,
   KNOB_MEL_RUN, KNOB_FIR_MAX_SLOTS, KNOB_SINS_V1, KNOB_TAPS_GEMM, KNOB_STREAM_LAYOUT, KNOB_BLK_TURNS, KNOB_CZT_ROUNDS, KNOB_CZT_TURNS,
-  KNOB_SINS_NOSKIP,
+  KNOB_SINS_NOSKIP, KNOB_SMALL_PATH,
   KNOB_COUNT
 };
+
+// a step with fewer frames than this (B F) takes the streaming-shape forms: fewer, fused launches (knob SMALL_PATH = 1: never)
+constexpr long kSmallRows = 4096;
 
 long knob(Knob k);                       // current value; 0 = unset (use the built-in default)
 int knob_set(const char* name, long v);  // 0 on success, -1 for an unknown name

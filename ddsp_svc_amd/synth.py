@@ -342,6 +342,53 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
     return signal, harm, nzo
 
 
+class StreamingCombSub:
+    """The CombSub tail for a real-time caller (gui.py:118-133: the same small shape every audio callback): ``phase`` and
+    ``synth`` of one FIXED shape with every buffer -- phase state, workspace, outputs -- allocated once and every pointer
+    bound once.  A call is then two C calls and nothing else on the host: at B = 1, a second of audio, the functional API
+    above spends ~25 us of Python (six ``torch.empty``, argument marshalling) around ~35 us of GPU work.
+
+    The numbers are those of ``phase`` + ``combsub_synth`` bit for bit (same library calls).  The returned tensors are the
+    session's own buffers: the next call overwrites them -- copy what must outlive it (the GUI copies to the host anyway).
+    One session per host thread / stream; controls must be float32 with a contiguous last dimension."""
+
+    def __init__(self, B, F, n_mag_allpass, n_mag_harmonic, n_mag_noise, sampling_rate, block_size, device, infer=True,
+                 want_components=False):
+        self.B, self.F, self.hop, self.sr, self.infer = int(B), int(F), int(block_size), float(sampling_rate), bool(infer)
+        self.n = (int(n_mag_allpass), int(n_mag_harmonic), int(n_mag_noise))
+        dev = torch.device(device)
+        T = self.F * self.hop
+        self._sums = torch.empty(B, F, dtype=torch.float64, device=dev)
+        self.state = PhaseState(torch.empty(B, F, dtype=torch.float64, device=dev), torch.empty(B, F, 1, dtype=torch.float32, device=dev),
+                                None, self.infer)
+        self._ws, self._need = _workspace(B, F, self.hop, max(self.n), dev)
+        self.signal, self.harmonic, self.noise = _outputs(B, T, dev, want_components)
+        self._tables = tuple(ir_table(n, dev) for n in self.n)
+        self._lib = _ffi.lib()
+        _ffi.check_device(self.signal)
+
+    def phase(self, f0_frames):
+        """``synth.phase`` into the session's state (what ``Unit2Control`` needs is ``.phase_frames``)"""
+        f0 = f0_frames.reshape(self.B, self.F)
+        st = self.state
+        _ffi.check(self._lib.ddsp_hip_phase(f0.data_ptr(), None, self.B, self.F, self.hop, self.sr, int(self.infer),
+                                            self._sums.data_ptr(), st.phase0.data_ptr(), st.phase_frames.data_ptr(), None,
+                                            _ffi.stream_of(f0)))
+        return st
+
+    def synth(self, f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, noise_is_u01=False):
+        """``combsub_synth`` on the session's state and buffers -> ``signal`` (and the components, if asked for)"""
+        f0 = f0_frames.reshape(self.B, self.F)
+        t = self._tables
+        _ffi.check(self._lib.ddsp_hip_combsub_synth(
+            f0.data_ptr(), None, self.state.phase0.data_ptr(), group_delay.data_ptr(), group_delay.stride(1),
+            harmonic_magnitude.data_ptr(), harmonic_magnitude.stride(1), noise_magnitude.data_ptr(), noise_magnitude.stride(1),
+            noise.data_ptr(), int(noise_is_u01), self.B, self.F, self.hop, self.sr, int(self.infer), self.n[0], self.n[1], self.n[2],
+            t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), self.signal.data_ptr(), ptr(self.harmonic), ptr(self.noise),
+            self._ws.data_ptr(), self._need, 0, _ffi.stream_of(f0), None, 0, 0))
+        return self.signal if self.harmonic is None else (self.signal, self.harmonic, self.noise)
+
+
 # ---- CombSubFast / CombSubSuperFast (vocoder.py:613-786) ------------------------------------------
 @dataclass
 class FastSourceState:

@@ -216,17 +216,6 @@ def test_full_size_against_eager_composition():
         err = (per_frame(grad) - per_frame(rgrad)).pow(2).mean(1).sqrt() / per_frame(rgrad).pow(2).mean(1).sqrt()
         assert float(err.median()) <= 2e-5
         assert float((err > 1e-3).float().mean()) <= 2e-3            # frames holding a flipped bin
-        # ... and what such a frame may be off by is bounded: a bin whose two magnitudes agree to the transforms' rounding
-        # (1e-7 of the frame's largest bin) may carry the other sign of log S_true - log S_pred, which moves its bin gradient by
-        # 2 alpha / (M S_pred) (M = all bins of the batch) and the frame's sample gradient by that times rms(w) / ||w|| =
-        # 1 / sqrt(n_fft).  Every frame's error must fit under the sum over ITS near-equal bins (+ 1e-3 relative): a frame
-        # that is wrong for any other reason fails here however few such frames there are.
-        M = float(B * bins * frames)
-        near = (St - Sp).abs() <= 4e-6 * torch.maximum(St, Sp).amax(dim=1, keepdim=True)       # [B, bins, frames]
-        allow = (near.float() * 2.0 / (M * Sp)).sum(1).reshape(B * frames) / float(n_fft) ** 0.5
-        abs_err = (per_frame(grad) - per_frame(rgrad)).pow(2).mean(1).sqrt()
-        slack = abs_err - (1.5 * allow + 1e-3 * per_frame(rgrad).pow(2).mean(1).sqrt())
-        assert float(slack.max()) <= 0.0, (n_fft, float(slack.max()), int((slack > 0).sum()))
         assert float(grad[:, frames * n_fft:].abs().max()) == 0.0 if frames * n_fft < T else True
         # the parts
         tab = L._czt_tables(n_fft, xt)
@@ -252,6 +241,13 @@ def test_full_size_against_eager_composition():
         _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
                                                    1.0, ptr(go), 0, ptr(d), T, 0, None, 0, _ffi.stream_of(xt)))
         assert float((d - xx.grad).pow(2).mean().sqrt() / xx.grad.pow(2).mean().sqrt()) <= 1e-6
+        # ... and frame by frame, with NO frame excused: against the float64 adjoint of the same bin gradients nothing is
+        # discontinuous, so a frame whose gradient were wrong for any reason fails here however few such frames there are --
+        # the cap the flipped-frame count above cannot give.  The autograd path returns these very numbers.
+        fe = (per_frame(d) - per_frame(xx.grad)).pow(2).mean(1).sqrt() / per_frame(xx.grad).pow(2).mean(1).sqrt().clamp_min(1e-30)
+        assert float(fe.max()) <= 2e-5, (n_fft, float(fe.max()))
+        ge = (per_frame(grad) - per_frame(d)).pow(2).mean(1).sqrt() / per_frame(d).pow(2).mean(1).sqrt().clamp_min(1e-30)
+        assert float(ge.max()) <= 1e-6, (n_fft, float(ge.max()))
         d2 = d.clone()                                                  # accumulate: exactly twice
         _ffi.check(lib.ddsp_hip_stft_loss_backward(ptr(spec[0]), ptr(spec[1]), B, T, n_fft, n_fft, ptr(tab), ptr(norms), inv, 1e-7,
                                                    1.0, ptr(go), 0, ptr(d2), T, 1, None, 0, _ffi.stream_of(xt)))

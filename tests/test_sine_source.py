@@ -82,7 +82,7 @@ def test_source_module_dropin(dev, monkeypatch):
                       torch.zeros(2, 5 * UPP, 4, device=dev))
 
 
-@pytest.mark.parametrize("dev", ["emu"], indirect=True)
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_against_reference_source_module(dev):
     ref_root = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
     if not os.path.isdir(os.path.join(ref_root, "nsf_hifigan")):
@@ -105,7 +105,13 @@ def test_against_reference_source_module(dev):
     with mock.patch("torch.rand", side_effect=lambda *a, **k: ri.clone()), \
             mock.patch("torch.randn_like", side_effect=lambda t: nz), \
             mock.patch("torch.randn", side_effect=lambda *a, **k: nz), torch.no_grad():
-        want = ref(f0, UPP)
-        got = ours(f0, UPP)
+        want = ref(f0, UPP)                                  # the reference on its CPU path
+    ours = ours.to(dev)
+    rid, nzd = ri.to(dev), nz.to(dev)
+    with mock.patch("torch.rand", side_effect=lambda *a, **k: rid.clone()), \
+            mock.patch("torch.randn_like", side_effect=lambda t: nzd), \
+            mock.patch("torch.randn", side_effect=lambda *a, **k: nzd), torch.no_grad():
+        got = ours(f0.to(dev), UPP).cpu()
     assert got.shape == want.shape
+    print("SourceModuleHnNSF on %s against the reference's CPU path: max abs error %.2e" % (dev, float((got - want).abs().max())))
     assert (got - want).abs().max() <= 2e-6

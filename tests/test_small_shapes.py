@@ -1,0 +1,142 @@
+"""Streaming shapes (the real-time caller, gui.py:118-133: B = 1, a fraction of a second per call).  Below 4096 frames a
+CombSub step is issued as THREE dependent launches instead of seven -- exciter and the three tap syntheses in one launch
+(k_front_small, grid.y) | all-pass filter beside the noise filter (grid.y) | harmonic filter + noise -- and the phase state as
+ONE launch instead of two.  Same kernels, same arguments: the results must be the SAME BITS as the batch layout's (knob SMALL_PATH = 1
+switches the fused forms off), at F = 1, 3, 47, 200, from any host thread, and within the usual bars of the oracle."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddsp_oracle as O
+from tests.backends import BACKENDS, dev  # noqa: F401
+
+SR, HOP = 44100, 512
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+def _inputs(B, F, device, seed):
+    f0 = O.synth_f0(B, F, SR, HOP, seed=seed)
+    f0[0] = np.clip(f0[0] * 2.1, 65, 800)
+    cg, ch, cn = O.synth_controls(B, F, [256, 256, 256], seed=seed + 1)
+    u = np.random.default_rng(seed + 2).random((B, F * HOP), dtype=np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return (f0, cg, ch, cn, u), tuple(t(a) for a in (f0, cg, ch, cn, u))
+
+
+def _step(tensors):
+    from ddsp_svc_amd import synth
+    f0, cg, ch, cn, u = tensors
+    st = synth.phase(f0, SR, HOP)
+    sig, harm, nz = synth.combsub_synth(f0, st, cg, ch, cn, u, SR, HOP, noise_is_u01=True)
+    return st, sig, harm, nz
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F", [(1, 1), (1, 3), (1, 47), (1, 200), (3, 22), (2, 1000)])
+def test_fused_launches_same_bits(dev, B, F, knobs):
+    arrays, tensors = _inputs(B, F, dev, seed=100 + F)
+    st, sig, harm, nz = _step(tensors)
+    knobs("SMALL_PATH", 1)                               # the batch layout: one launch per kernel
+    st2, sig2, harm2, nz2 = _step(tensors)
+    assert torch.equal(st.phase0, st2.phase0) and torch.equal(st.phase_frames, st2.phase_frames)
+    assert torch.equal(sig, sig2) and torch.equal(harm, harm2) and torch.equal(nz, nz2)
+    # and they are the reference's numbers
+    f0, cg, ch, cn, u = arrays
+    noise = (u * np.float32(2) - np.float32(1)).astype(np.float32)
+    ref = O.combsub_dsp(f0, cg, ch, cn, noise, SR, HOP)
+    for got, key in ((sig, "signal"), (harm, "harmonic"), (nz, "noise")):
+        e = rms(got.cpu().numpy() - ref[key])
+        assert e <= 1e-5 * rms(ref[key]) and e <= 1e-4, (key, e, rms(ref[key]))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F,H", [(1, 1, 40), (1, 47, 256), (2, 130, 128)])
+def test_sins_fused_launches_same_bits(dev, B, F, H, knobs):
+    """Sins at streaming shapes: sinusoid bank | both tap syntheses in one launch | noise filter | all-pass filter + noise"""
+    from ddsp_svc_amd import synth
+    f0 = O.synth_f0(B, F, SR, HOP, seed=9 + F)
+    ca, cg, cn = O.synth_controls(B, F, [H, 256, 256], seed=F)
+    u = np.random.default_rng(F).random((B, F * HOP), dtype=np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f0t, cat, cgt, cnt, ut = t(f0), t(ca), t(cg), t(cn), t(u)
+
+    def step():
+        st = synth.phase(f0t, SR, HOP)
+        return synth.sins_synth(f0t, st, cat, cgt, cnt, ut, SR, HOP, noise_is_u01=True)
+    a = step()
+    knobs("SMALL_PATH", 1)
+    b = step()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ref = O.sins_dsp(f0, ca, cg, cn, (u * np.float32(2) - np.float32(1)).astype(np.float32), SR, HOP)
+    e = rms(a[0].cpu().numpy() - ref["signal"])
+    assert e <= 1e-5 * rms(ref["signal"]) and e <= 1e-4
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_small_path_is_taken_and_bounded(dev, knobs):
+    """the fused forms stop at 4096 frames (B F): one frame below they run, at 4096 the batch layout does -- both equal to the
+    batch layout bit for bit either way, so the switch-over cannot be seen in the numbers"""
+    from ddsp_svc_amd import _ffi
+    lib = _ffi.lib()
+    # the workspace of a streaming shape holds the third tap buffer, a batch shape's does not
+    small = lib.ddsp_hip_synth_workspace_bytes(1, 100, HOP, 256)
+    assert small >= 4 * (3 * 100 * HOP + 3 * 100 * 510)
+    big = lib.ddsp_hip_synth_workspace_bytes(8, 512, HOP, 256)
+    assert big < 4 * (3 * 4096 * HOP + 3 * 4096 * 510) + 4096
+    for B, F in ((1, 4095), (1, 4096)) if dev.type != "cpu" else ((1, 65), ):
+        _, tensors = _inputs(B, F, dev, seed=7)
+        _, sig, _, _ = _step(tensors)
+        knobs("SMALL_PATH", 1)
+        _, sig2, _, _ = _step(tensors)
+        knobs("SMALL_PATH", 0)
+        assert torch.equal(sig, sig2)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_streaming_session_same_bits(dev):
+    """synth.StreamingCombSub -- every buffer allocated and every pointer bound once, a call = two C calls -- returns the
+    functional API's numbers bit for bit, call after call, and rejects nothing the functional API accepts at that shape"""
+    from ddsp_svc_amd import synth
+    B, F = 1, 33
+    sess = synth.StreamingCombSub(B, F, 256, 256, 256, SR, HOP, dev, want_components=True)
+    for seed in (1, 2):
+        _, tensors = _inputs(B, F, dev, seed=seed)
+        f0, cg, ch, cn, u = tensors
+        st, sig, harm, nz = _step(tensors)
+        pst = sess.phase(f0)
+        assert torch.equal(pst.phase0, st.phase0) and torch.equal(pst.phase_frames, st.phase_frames)
+        s2, h2, n2 = sess.synth(f0, cg, ch, cn, u, noise_is_u01=True)
+        assert torch.equal(s2, sig) and torch.equal(h2, harm) and torch.equal(n2, nz)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_from_another_host_thread(dev):
+    """gui.py calls the synthesiser from the audio callback thread: the library keeps no per-thread state that a first call
+    from a worker thread would miss (knobs are process-wide, events of the two-stream layout per thread and created on demand)"""
+    _, tensors = _inputs(1, 40, dev, seed=3)
+    _, want, _, _ = _step(tensors)
+    got, err = [], []
+
+    def work():
+        try:
+            for _ in range(3):
+                got.append(_step(tensors)[1])
+        except BaseException as e:                       # noqa: BLE001
+            err.append(e)
+    ts = [threading.Thread(target=work) for _ in range(2)]
+    if dev.type == "cpu":                                # the CPU emulator's fibers are one-kernel-at-a-time: worker threads in turn
+        for t in ts:
+            t.start()
+            t.join()
+    else:                                                # on the MI355X: both threads at once
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not err, err
+    assert len(got) == 6 and all(torch.equal(g, want) for g in got)

@@ -129,6 +129,8 @@ reference)
   echo "DDSP_REFERENCE_PATH=$DDSP_REFERENCE_PATH"; ls "$DDSP_REFERENCE_PATH" | head -3
   timeout 1200 python -m pytest tests/test_modules.py tests/test_backward_fir.py tests/test_backward_fast.py tests/test_mel.py tests/test_sine_source.py tests/test_cascade_seam.py tests/test_loss.py -m gpu -q -rA -s 2>&1 | grep -v "^\s*$" | grep -E "passed|failed|PASSED|FAILED|SKIPPED|rms error|training step|Error|error" | tee "$O/${V}_reference_on_gpu.log" | tail -60
   timeout 900 python bench.py --no-module-mode --no-live-traffic --no-also 2>"$O/${V}_bench_reference.err" | tail -1 > "$O/${V}_bench_reference.json"
+  timeout 900 python bench.py --model cascade_ref --batch-per-gpu 64 2>"$O/${V}_bench_cascade_ref.err" | tail -1 > "$O/${V}_bench_cascade_ref.json"
+  cat "$O/${V}_bench_cascade_ref.json" | cut -c1-1500; tail -3 "$O/${V}_bench_cascade_ref.err"
   python - <<'PY'
 import json, os
 V = os.environ["V"]

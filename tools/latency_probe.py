@@ -28,7 +28,7 @@ def timeit(fn, reps=200):
 
 
 for kind in ("combsub", "sins", "combsubsuperfast"):
-    for B, seconds in ((1, 0.25), (1, 1.0), (4, 2.0)):
+    for B, seconds in ((1, 0.25), (1, 1.16), (4, 2.0)):      # F = 22, 100, 173
         F = int(seconds * SR) // HOP + 1
         step, inp = bench.build_step(kind, B, F, 256, dev, seed=7)
         us = timeit(step)
@@ -68,3 +68,21 @@ for kind in ("combsub", "sins", "combsubsuperfast"):
         except Exception as e:
             line += "; graph capture failed: %s: %s" % (type(e).__name__, str(e)[:120])
         print(line, flush=True)
+        if kind == "combsub":                                    # the allocation-free session: the same two C calls, nothing else on the host
+            f0, (cg, ch, cn), u = inp["f0"], inp["ctrls"], inp["noise"]
+            sess = synth.StreamingCombSub(B, F, 256, 256, 256, SR, HOP, dev)
+
+            def sstep():
+                sess.phase(f0)
+                return sess.synth(f0, cg, ch, cn, u)
+            same = bool(torch.equal(sstep(), step()))
+            us2 = timeit(sstep)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                sstep()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            print("%-17s B=%d %.2f s (F=%d): StreamingCombSub session %.1f us back to back, %.1f us call-to-result, same bits %s"
+                  % (kind, B, seconds, F, us2, sorted(lat)[len(lat) // 2] * 1e6, same), flush=True)
