@@ -150,7 +150,7 @@ def test_module_training_step_matches_reference(dev, kind):
         o_sig, _, _ = ours(units.to(dev), f0.to(dev), vol.to(dev), infer=True)
     (r_sig * R).sum().backward()
     (o_sig * R.to(dev)).sum().backward()
-    tol = 2e-5 if dev.type == "cpu" else 2e-3                   # on the MI355X Unit2Control's own GEMMs round differently from the CPU's
+    tol = 2e-5 if dev.type == "cpu" else 2e-4                   # on the MI355X Unit2Control's own GEMMs round differently from the CPU's (measured: 8.8e-6)
     checked, worst = 0, 0.0
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), ours.named_parameters()):
         assert n1 == n2

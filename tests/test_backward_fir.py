@@ -228,7 +228,7 @@ def test_combsub_module_training_step_matches_reference(dev, kind):
     (r_sig * R).sum().backward()
     (o_sig * R.to(dev)).sum().backward()
     # on the MI355X Unit2Control's own float32 GEMMs (forward and backward) round differently from the CPU's
-    tol = 5e-5 if dev.type == "cpu" else 2e-3
+    tol = 5e-5 if dev.type == "cpu" else 2e-4                   # measured: 1.3e-5 (profiles/r04_v11_reference_on_gpu.log)
     checked, worst = 0, 0.0
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), ours.named_parameters()):
         assert n1 == n2

@@ -206,7 +206,7 @@ def test_against_reference_module(dev, kind):
     # Unit2Control itself runs as PyTorch on either device: on the GPU its float32 GEMMs round differently from the CPU's
     hid_tol = 1e-6 if dev.type == "cpu" else 2e-4
     assert rms((o_hid - r_hid).numpy()) <= hid_tol * max(rms(r_hid.numpy()), 1e-12) + 1e-7
-    sig_tol = 2e-5 if dev.type == "cpu" else 1e-3      # (controls that differ by 1e-4 relative move the waveform by as much)
+    sig_tol = 2e-5 if dev.type == "cpu" else 5e-5      # measured on the MI355X: 3.5e-6 (profiles/r04_v11_reference_on_gpu.log)
     for got, want, name in ((o_sig, r_sig, "signal"), (o_h, r_h, "harmonic"), (o_n, r_n, "noise")):
         e = rms((got - want).numpy())
         print("%s module on %s against the reference's CPU path: %s rms error %.2e (rms %.2e)" % (kind, dev, name, e, rms(want.numpy())))
@@ -261,7 +261,7 @@ def test_fast_against_reference_module(dev, kind):
     assert rms((o_hid - r_hid).numpy()) <= (1e-6 if on_cpu else 2e-4) * max(rms(r_hid.numpy()), 1e-12) + 1e-7
     e = rms((o_sig - r_sig).numpy())
     print("%s module on %s against the reference's CPU path: signal rms error %.2e (rms %.2e)" % (name, dev, e, rms(r_sig.numpy())))
-    assert e <= (2e-5 if on_cpu else 1e-3) * rms(r_sig.numpy()) and e <= 1e-4, (e, rms(r_sig.numpy()))
+    assert e <= (2e-5 if on_cpu else 5e-5) * rms(r_sig.numpy()) and e <= 1e-4, (e, rms(r_sig.numpy()))   # measured on the MI355X: 9e-7
 
 
 def test_patch_reference_swaps_classes_and_keeps_cpu_core():
@@ -352,7 +352,7 @@ def test_patch_reference_reaches_the_cascades(dev):
                     o_wav, o_hid, _ = ours.ddsp_model(units.to(dev), f0.to(dev), vol.to(dev), infer=True)
             e = rms((o_wav.cpu() - r_wav).numpy())
             print("%s.ddsp_model on %s against the reference's CPU path: rms error %.2e (rms %.2e)" % (type(ref).__name__, dev, e, rms(r_wav.numpy())))
-            tol = 2e-5 if dev.type == "cpu" else 1e-3    # Unit2Control's float32 GEMMs on the GPU against the CPU's
+            tol = 2e-5 if dev.type == "cpu" else 5e-5    # Unit2Control's float32 GEMMs on the GPU against the CPU's (measured: 9e-7)
             assert e <= tol * rms(r_wav.numpy()) and e <= 1e-4, (type(ref).__name__, e, rms(r_wav.numpy()))
     finally:
         V.unpatch_reference()

@@ -7,6 +7,7 @@
 #   libs "tagA tagB .."    same-box A/B of builds tools/ab/libddsp_hip_<tag>.so ("cur" = the in-tree library)
 #   kernel "tagA tagB .."  one bench run per tag: the step and the dominant kernel alone (ablation builds)
 #   gaps "tagA tagB .."    per-launch timeline of one steady-state step for every tag
+#   refresh                the round's final evidence in one call (suite, smoke, every bench row, traces, counters, training, latency)
 #   reference              (under tools/with_reference.sh) reference-class tests on the GPU + bench with the reference as CPU baseline
 #   tests                  the whole GPU suite + smoke()
 #   bench                  the driver's command (default bench.py) + kernel trace of the step
@@ -122,6 +123,37 @@ gaps)
       python "$R/tools/rocpd_gaps.py" "$f" 2>&1 | tee -a "$O/${V}_gaps_$(name_of $t)_$mode.txt"
       rm -rf "$O/gp" )
   done; done
+  ;;
+refresh)
+  # the round's final evidence on one box: GPU suite + smoke, the driver's command (with the reference as CPU baseline when
+  # DDSP_REFERENCE_PATH is set), the other bench rows, one-stream kernel traces, SQ counters of the CombSub step, the
+  # training steps, the streaming-shape latencies, cfg 4's per-GPU shape on a 1-rank communicator
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee "$O/${V}_pytest_gpu.log"
+  timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v Warning | tail -4 | tee "$O/${V}_smoke.log"
+  ( time timeout 600 python bench.py ) 2>"$O/${V}_bench_combsub.err" | tail -1 > "$O/${V}_bench_combsub.json"; tail -4 "$O/${V}_bench_combsub.err"
+  for m in sins combsubsuperfast combsubfast rssloss mel sinesrc; do
+    timeout 300 python bench.py --model $m --no-also --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > "$O/${V}_bench_$m.json"
+  done
+  timeout 300 python bench.py --cfg4 --no-also --no-cpu-baseline --no-live-traffic --no-module-mode 2>/dev/null | tail -1 > "$O/${V}_bench_cfg4_1rank.json"
+  summary
+  for m in combsub sins combsubsuperfast; do MODEL=$m; echo "== trace $m"; trace $m X=1 | head -8; done
+  MODEL=combsub
+  pmc combsub "ddsp::" X=1 > /dev/null; head -40 "$O/${V}_pmc_combsub.txt"
+  for k in combsub sins combsubsuperfast combsubfast; do timeout 120 python tools/train_step_probe.py $k 2>&1 | tail -1; done | tee "$O/${V}_train_ms.txt"
+  for k in combsub sins combsubsuperfast; do timeout 120 python tools/train_step_probe.py $k loss 2>&1 | tail -1; done | tee -a "$O/${V}_train_ms.txt"
+  timeout 300 python tools/latency_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee "$O/${V}_latency_small_shapes.txt"
+  python - <<'PY'
+import json, os
+V = os.environ["V"]
+d = json.loads(open("gpurun_out/%s_bench_combsub.json" % V).read())
+print({k: d[k] for k in ("value", "ms_per_step", "ms_per_step_events")})
+print("roofline", {k: d["roofline"][k] for k in ("kernel", "frac", "avg_ms", "traffic")})
+print("step traffic", (d.get("roofline_step_traffic") or {}).get("ratio"))
+print("also", {k: round(v["ms_per_step"], 4) for k, v in d.get("also", {}).items()})
+print("cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("kind", "value", "cores", "sample")})
+c = json.loads(open("gpurun_out/%s_bench_cfg4_1rank.json" % V).read()).get("cfg4")
+print("cfg4 (1 rank)", c and {k: c.get(k) for k in ("ms_per_step", "ms_per_step_with_gather", "value")})
+PY
   ;;
 reference)
   # with a reference checkout beside the snapshot (tools/with_reference.sh): the tests that hold the drop-in modules against the
