@@ -44,6 +44,20 @@ __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
   return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-b.y, b.x}, t);
 #endif
 }
+// a * k for a wave-uniform factor k (the W_8 constants of the radix-8 butterflies): k travels as an SGPR pair, so no v_mov
+// builds it in vector registers -- 28 of them per pass of k_fir_blk6 otherwise (the compiler rematerialises constants rather
+// than keep four registers for them)
+__device__ __forceinline__ f32x2 cmul_uniform(f32x2 a, f32x2 k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+  return r;
+#else
+  const f32x2 t = f32x2{a.x, a.x} * k;
+  return __builtin_elementwise_fma(f32x2{a.y, a.y}, f32x2{-k.y, k.x}, t);
+#endif
+}
 // the two halves of a * b apart, so that independent products can be issued between them (an instruction that consumes its
 // predecessor's result waits ~3 cycles for it, and behind a packed producer the compiler adds an s_nop on top -- about the
 // issue time of one more instruction each, tools/probes/valu_probe2.hip)
@@ -186,8 +200,8 @@ __device__ __forceinline__ void dft8(f32x2* v) {
   const float H = 0.70710678118654752f;
   f32x2 e0 = v[0] + v[4], e1 = v[1] + v[5], e2 = v[2] + v[6], e3 = v[3] + v[7];     // a' = 0
   f32x2 o0 = v[0] - v[4], o1 = v[1] - v[5], o2 = v[2] - v[6], o3 = v[3] - v[7];     // a' = 1, then * W8^b
-  o1 = cmul(o1, f32x2{H, -H});
-  o3 = cmul(o3, f32x2{-H, -H});
+  o1 = cmul_uniform(o1, f32x2{H, -H});
+  o3 = cmul_uniform(o3, f32x2{-H, -H});
   dft4(e0, e1, e2, e3);                    // X[0], X[2], X[4], X[6]
   dft4_rot2(o0, o1, o2, o3);               // X[1], X[3], X[5], X[7]   (o2 * W8^2 = o2 * -i inside)
   v[0] = e0; v[2] = e1; v[4] = e2; v[6] = e3;
@@ -199,7 +213,7 @@ __device__ __forceinline__ void dft8(f32x2* v) {
 __device__ __forceinline__ void dft8_lo4(f32x2* v) {
   const float H = 0.70710678118654752f;
   f32x2 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-  f32x2 o0 = v[0], o1 = cmul(v[1], f32x2{H, -H}), o2 = v[2], o3 = cmul(v[3], f32x2{-H, -H});
+  f32x2 o0 = v[0], o1 = cmul_uniform(v[1], f32x2{H, -H}), o2 = v[2], o3 = cmul_uniform(v[3], f32x2{-H, -H});
   dft4(e0, e1, e2, e3);
   dft4_rot2(o0, o1, o2, o3);
   v[0] = e0; v[2] = e1; v[4] = e2; v[6] = e3;

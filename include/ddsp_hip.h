@@ -57,7 +57,10 @@ const char* ddsp_hip_error_string(int code);
  * factors at 256, chirp-z from 112 to 1025, the dense contraction elsewhere; 1 = the dense contraction everywhere;
  * 2 = chirp-z wherever its plans reach), SINS_V1 (sinusoid bank generations), STFT_WPS (waves per SIMD of the short-time
  * spectral filter's variants), CZT_ROUNDS (rounds of resident workgroups of the loss kernels), CZT_TURNS (priority turns of a SIMD's waves in the loss's
- * backward kernel: 0 = on, 2 = off); the rest are run lengths. */
+ * backward kernel: 0 = on, 2 = off), BLK_WPS (the hop-block filter: 0 / 3 = k_fir_blk6, three waves per SIMD; 2 = round 3's
+ * two-wave kernel, kept for same-box A/B runs), SINS_NOSKIP (1 = the sinusoid bank also sums the harmonics that are masked
+ * to 1e-7 in both frames of a hop), SMALL_PATH (1 = never take the fused launches of the streaming shapes, B F < 4096: the
+ * batch layout at every size; the results are the same bits either way); the rest are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 
@@ -184,7 +187,9 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
  * created once per host thread and device and kept (the only objects the library creates). */
 
 /* workspace the two synth entry points need (bytes); n_max = largest n_mag among the filters.  `ws` must be 16-byte
- * aligned (the tap arrays carved out of it are written 16 bytes at a time); an unaligned pointer is DDSP_HIP_EINVAL. */
+ * aligned (the tap arrays carved out of it are written 16 bytes at a time); an unaligned pointer is DDSP_HIP_EINVAL.
+ * Streaming shapes (B F < 4096 frames, gui.py:118-133): the workspace holds one tap buffer more, and the tails issue the
+ * same kernels as three (CombSub) / four (Sins) dependent launches instead of seven / five -- same results, bit for bit. */
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
 
 /* exciters on their own (used by tests and by callers that want the intermediate):

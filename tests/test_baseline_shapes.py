@@ -153,7 +153,7 @@ def test_phase_10s_hip(dev, golden_dir, infer):
     dec = int(g["decim"])
     # infer: re-associated float64 scan -> at most a float32 rounding flip of the wrapped value (<= 1 ulp at 0.5).
     # train: the float32 outputs are roundings of a float64 running sum at |x| up to 8e3 (ulp 4.9e-4 cycles)
-    tol = 6e-8 if infer else 5e-4
+    tol = 6e-8 if infer else float(np.spacing(np.float32(8e3)))     # one float32 spacing at the largest running sum (4.9e-4)
     xd, xr = x[:, ::dec], g[f"x_dec_infer{int(infer)}"]
     assert np.abs(wrapdiff(xd, xr)).max() <= tol
     assert np.abs(wrapdiff(x[:, -2048:], g[f"x_tail_infer{int(infer)}"])).max() <= tol
