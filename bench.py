@@ -1413,7 +1413,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    used_impl = a.fir_impl if a.fir_impl else (5 if N <= 512 else 3)
+    used_impl = a.fir_impl if a.fir_impl else (5 if N <= 512 else (4 if N <= 1022 else 3))      # what launch_fir's AUTO picks at hop 512
     fir_ms = time_fir(used_impl)
     mfma_ms = time_fir(3) if used_impl != 3 else fir_ms
     fir_flops = 4.0 * N * B * T                      # direct form: 2N multiply-adds per output sample

@@ -420,6 +420,9 @@ int launch_fir(const float* x, int x_is_u01, const float* taps, const float* add
     const int r = launch_fir_blk(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
     if (r >= 0) return r;
   }
+  // 514 .. 1022 taps (n_mag up to 512: the harmonic filter of the classic CombSub configuration): the per-frame 2048-point
+  // form in its LONG variant -- the direct form on the matrix pipe costs ~3x as much at these tap counts
+  if (impl == 0 && hop == 512 && N > 512 && N <= 1022 && (long)F * hop < (1L << 30)) impl = 4;
   if (impl == 4) return launch_fir_fft(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
   if (impl == 5) return launch_fir_blk(x, x_is_u01, taps, addend, out, out_plain, B, F, hop, N, st);
   if (impl == 0) impl = fits(8) ? 3 : fits(4) ? 2 : 1;

@@ -2,7 +2,7 @@
 // does it -- per-frame block convolution in the frequency domain with overlap-add -- but as one fused
 // kernel whose spectra never leave the CU.
 //
-// Frame j (0..F, row F re-uses taps F-1, core.py:167) convolves its taps (N <= 512 here) with the chunk
+// Frame j (0..F, row F re-uses taps F-1, core.py:167) convolves its taps (N <= 512; 514 .. 1022 in the LONG variant) with the chunk
 // (x * tri_j)[(j-1) hop .. (j+1) hop)  (the periodic Bartlett window of core.py:161 IS tri_j) and adds the
 // 2 hop + N - 1 results at output position (j-1) hop - N/2 (crop of core.py:113-117).  With hop = 512 and
 // N <= 512 the linear convolution (<= 1535 samples) fits a 2048-point transform without time aliasing
@@ -43,14 +43,22 @@ __device__ __forceinline__ f32x2 packed_product(f32x2 a, f32x2 zneg, f32x2 q) {
   return fft::swap_scale(p, q);
 }
 
-__global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __restrict__ x, int x_is_u01,
-                                                          const float* __restrict__ taps,
-                                                          const float* __restrict__ addend, float* __restrict__ out,
-                                                          float* __restrict__ out_plain, FirFftGeom g) {
+// LONG: tap counts from 514 to 1022 (n_mag up to 512: the harmonic filter of the classic CombSub configuration,
+// n_mag_allpass 256 / n_mag_harmonic 512 / n_mag_noise 256).  A frame's linear convolution (2 hop + N - 1 <= 2045 samples)
+// still fits the 2048-point transform; what grows is its reach: four taps per thread instead of two, all eight slots of the
+// result are live, two consecutive frames span up to 2557 samples (a 4096-sample ring: 48 KB of LDS, three workgroups per
+// CU), and a run needs TWO warm-up pairs for its ring to hold the tails of the four frames that reach into it.  Without this
+// form such a filter ran on the direct MFMA form at ~3x the time.
+template <bool LONG>
+__global__ void __launch_bounds__(fft::THREADS, LONG ? 3 : 4) k_fir_fft(const float* __restrict__ x, int x_is_u01,
+                                                                     const float* __restrict__ taps,
+                                                                     const float* __restrict__ addend, float* __restrict__ out,
+                                                                     float* __restrict__ out_plain, FirFftGeom g) {
   constexpr int S = fft::SLOTS;                               // 8 complex points per thread, point k = 256 m + tid
+  constexpr int RING = LONG ? 4096 : 2048, TAPM = LONG ? 4 : 2, ACC_M = LONG ? 8 : 6;
   __shared__ __attribute__((aligned(16))) f32x2 exA[fft::EX_WORDS];
   __shared__ __attribute__((aligned(16))) f32x2 exB[fft::EX_WORDS];
-  __shared__ float ring[fft::N];             // 2 x 16 KB + 8 KB = 40 KB exactly: four workgroups per CU
+  __shared__ float ring[RING];               // 2 x 16 KB + 8 KB = 40 KB exactly: four workgroups per CU (LONG: 48 KB, three)
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.runs_per_utt;
   const int run_no = blockIdx.x - b * g.runs_per_utt;
@@ -66,21 +74,22 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
   fft::Twiddles tw;
   tw.init(tid);
 #pragma unroll
-  for (int m = 0; m < S; ++m) ring[256 * m + tid] = 0.f;
+  for (int m = 0; m < RING / 256; ++m) ring[256 * m + tid] = 0.f;
 
-  // inputs of one frame: 4 chunk samples (already Bartlett-weighted) and 2 taps per thread
-  struct Frame { float xv[4], hv[2]; };
+  // inputs of one frame: 4 chunk samples (already Bartlett-weighted) and 2 (LONG: 4) taps per thread
+  struct Frame { float xv[4], hv[TAPM]; };
   auto load_frame = [&](int j) -> Frame {
     Frame f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) f.xv[m] = 0.f;
-    f.hv[0] = f.hv[1] = 0.f;
+#pragma unroll
+    for (int m = 0; m < TAPM; ++m) f.hv[m] = 0.f;
     if (j <= g.F) {                                           // j == F + 1 only pads an odd frame count
       const int s0 = (j - 1) * FF_HOP;
       const int row = j < g.F ? j : g.F - 1;                  // core.py:167
       const float* tr = tb + (long)row * g.N;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < TAPM; ++m)
         if (256 * m + tid < g.N) f.hv[m] = tr[256 * m + tid];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -97,7 +106,7 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
     return f;
   };
 
-  const int pr0 = p_first > 0 ? p_first - 1 : 0;
+  const int pr0 = p_first > (LONG ? 1 : 0) ? p_first - (LONG ? 2 : 1) : 0;    // warm-up pairs: their output is discarded
   Frame nxt = load_frame(2 * pr0);
   for (int pr = pr0; pr < p_last; ++pr) {
     f32x2 V[S];
@@ -112,21 +121,22 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
 #pragma unroll
       for (int m = 0; m < 4; ++m) sx = fmaf(cur.xv[m], cur.xv[m], sx);
       sh = fmaf(cur.hv[0], cur.hv[0], cur.hv[1] * cur.hv[1]);
+      if (LONG) sh = fmaf(cur.hv[TAPM - 2], cur.hv[TAPM - 2], fmaf(cur.hv[TAPM - 1], cur.hv[TAPM - 1], sh));
       sx = wave_sum_dpp(sx);
       sh = wave_sum_dpp(sh);
       // the four waves meet through 8 ring slots at the far end of the window: they belong to samples this pair
       // only reaches with its second overlap-add, and are zeroed again before that (see below)
       float* red = ring;
-      const int rbase = (2 * pr - 1) * FF_HOP - D + fft::N - 8;
+      const int rbase = (2 * pr - 1) * FF_HOP - D + RING - 8;
       if ((tid & 63) == 0) {
-        red[(rbase + (tid >> 6) * 2) & (fft::N - 1)] = sx;
-        red[(rbase + (tid >> 6) * 2 + 1) & (fft::N - 1)] = sh;
+        red[(rbase + (tid >> 6) * 2) & (RING - 1)] = sx;
+        red[(rbase + (tid >> 6) * 2 + 1) & (RING - 1)] = sh;
       }
       __syncthreads();
-      sx = (red[rbase & (fft::N - 1)] + red[(rbase + 2) & (fft::N - 1)]) +
-           (red[(rbase + 4) & (fft::N - 1)] + red[(rbase + 6) & (fft::N - 1)]);
-      sh = (red[(rbase + 1) & (fft::N - 1)] + red[(rbase + 3) & (fft::N - 1)]) +
-           (red[(rbase + 5) & (fft::N - 1)] + red[(rbase + 7) & (fft::N - 1)]);
+      sx = (red[rbase & (RING - 1)] + red[(rbase + 2) & (RING - 1)]) +
+           (red[(rbase + 4) & (RING - 1)] + red[(rbase + 6) & (RING - 1)]);
+      sh = (red[(rbase + 1) & (RING - 1)] + red[(rbase + 3) & (RING - 1)]) +
+           (red[(rbase + 5) & (RING - 1)] + red[(rbase + 7) & (RING - 1)]);
       float sc = 1.0f, isc = 1.0f;
       if (sx > 0.f && sh > 0.f && sx < 3e38f && sh < 3e38f) {
         int e = (ilogbf(sx) - ilogbf(sh)) >> 1;               // sqrt of the energy ratio, as a power of two
@@ -137,7 +147,7 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
       const f32x2 q = {0.25f * isc, -0.25f * isc};
       f32x2 z[S];
 #pragma unroll
-      for (int m = 0; m < S; ++m) z[m] = f32x2{m < 4 ? cur.xv[m] : 0.f, m < 2 ? cur.hv[m] * sc : 0.f};
+      for (int m = 0; m < S; ++m) z[m] = f32x2{m < 4 ? cur.xv[m] : 0.f, m < TAPM ? cur.hv[m < TAPM ? m : 0] * sc : 0.f};
       fft::forward(z, tw, exA, exB, tid);
       // natural order to LDS (buffer B is free), then G[k] from Z[k] and Z[-k]
 #pragma unroll
@@ -159,16 +169,16 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
     const int a0 = (2 * pr - 1) * FF_HOP - D;                 // output position of frame 2 pr's first sample
     const float scale = 1.0f / 2048.0f;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {                             // the linear convolution ends at 2 hop + N - 2 < 1536
+    for (int m = 0; m < ACC_M; ++m) {                         // the linear convolution ends at 2 hop + N - 2 < 1536 (LONG: < 2048)
       const int n = 256 * m + tid;
-      ring[(a0 + n) & (fft::N - 1)] += V[m].x * scale;
+      ring[(a0 + n) & (RING - 1)] += V[m].x * scale;
     }
-    if (tid < 8) ring[(a0 + fft::N - 8 + tid) & (fft::N - 1)] = 0.f;     // the borrowed reduction slots
+    if (tid < 8) ring[(a0 + RING - 8 + tid) & (RING - 1)] = 0.f;         // the borrowed reduction slots
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
+    for (int m = 0; m < ACC_M; ++m) {
       const int n = 256 * m + tid;
-      ring[(a0 + FF_HOP + n) & (fft::N - 1)] -= V[m].y * scale;
+      ring[(a0 + FF_HOP + n) & (RING - 1)] -= V[m].y * scale;
     }
     __syncthreads();
     // samples [a0, a0 + 2 hop) are complete once both frames are in; the last pair also flushes the tail
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
     for (int m = 0; m < S; ++m) {
       if (m < n_emit) {
         const int t = a0 + 256 * m + tid;
-        const int ri = t & (fft::N - 1);
+        const int ri = t & (RING - 1);
         const float v = ring[ri];
         ring[ri] = 0.f;
         if (own && t >= 0 && t < g.T) {
@@ -198,13 +208,14 @@ __global__ void __launch_bounds__(fft::THREADS, 4) k_fir_fft(const float* __rest
 // returns the implementation id (4) or < 0 when the shape is outside this kernel
 int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st) {
-  if (hop != FF_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 30)) return -1;
+  if (hop != FF_HOP || N < 2 || (N & 1) || N > 1022 || (long)F * hop >= (1L << 30)) return -1;
+  const bool long_taps = N > 512;
   FirFftGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 2) / 2;
   // run length (own pairs per workgroup): as many workgroups as the chip holds at once (4 per CU at this
   // kernel's LDS budget), so all of them run in one round with equal work; every run pays one warm-up pair
-  const long slots = 4 * 256;
+  const long slots = (long_taps ? 3 : 4) * 256;
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
@@ -215,7 +226,10 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
-  hipLaunchKernelGGL(k_fir_fft, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+  if (long_taps)
+    hipLaunchKernelGGL(k_fir_fft<true>, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+  else
+    hipLaunchKernelGGL(k_fir_fft<false>, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
   return 4;
 }
 

@@ -367,6 +367,35 @@ def test_fft_convolve_hop_block_scheduling(dev, B, F, N, knobs):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F,N,run", [(1, 1, 1022, 12), (2, 2, 514, 12), (1, 9, 1022, 1), (2, 7, 766, 2), (1, 12, 1000, 3)])
+def test_fft_convolve_long_taps(dev, B, F, N, run, knobs):
+    """514 .. 1022 taps (n_mag up to 512: the classic CombSub harmonic filter): the per-frame 2048-point form in its LONG variant
+    (4096-sample ring, two warm-up pairs per run) -- explicitly (impl 4) and as what AUTO picks -- against the direct sum, with
+    short runs (every hand-over between workgroups) and the fused input / output options"""
+    from ddsp_svc_amd import _ffi, core
+    knobs("FFT_RUN", run)
+    rng = np.random.default_rng(B * 1000 + F * 10 + N)
+    T = F * HOP
+    u = rng.uniform(0, 1, size=(B, T)).astype(np.float32)
+    x = (u * np.float32(2) - np.float32(1)).astype(np.float32)
+    ir = (rng.normal(size=(B, F, N)) / np.sqrt(N) * rng.uniform(0.01, 3.0, size=(B, F, 1))).astype(np.float32)
+    add = rng.normal(size=(B, T)).astype(np.float32)
+    ref = O.ltv_fir_direct(x, ir)
+    ut, irt, addt = T_(u, dev), T_(ir, dev), T_(add, dev)
+    st = _ffi.stream_of(ut)
+    for impl in (4, 0):
+        out, plain = torch.empty(B, T, device=dev), torch.empty(B, T, device=dev)
+        _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ut.data_ptr(), 1, irt.data_ptr(), addt.data_ptr(), out.data_ptr(),
+                                                    plain.data_ptr(), B, F, HOP, N, impl, st))
+        assert rms(N_(plain) - ref) <= 2e-6 * rms(ref), (impl, rms(N_(plain) - ref), rms(ref))
+        assert rms(N_(out) - (ref + add)) <= 2e-6 * rms(ref + add)
+    # and through the reference's signature (what AUTO serves): identical to the explicit form
+    knobs("FFT_RUN", 0)
+    y = core.fft_convolve(T_(x, dev), irt)
+    assert rms(N_(y) - ref) <= 2e-6 * rms(ref)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_fft_convolve_errors(dev):
     from ddsp_svc_amd import core
     a = torch.zeros(2, 1024, device=dev)
