@@ -423,16 +423,18 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     const int i = P * m + tid - SH;
     tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
   }
-  auto load_taps = [&](int j) -> TapRow {
+  // live == false (workgroup-uniform): the run ends before this row / block would be used -- the descriptor then spans 0 bytes
+  // and the loads touch no memory (a load is issued a pass ahead of its use, so every run used to fetch 8 - 12 KB past its end)
+  auto load_taps = [&](int j, bool live = true) -> TapRow {
     TapRow r;
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
-    const BufF32 tr = BufF32::make(tb + (long)row * g.N, g.N);
+    const BufF32 tr = BufF32::make(tb + (long)row * g.N, live ? g.N : 0);
 #pragma unroll
     for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
     return r;
   };
   struct Blk { float v[4]; };
-  auto load_blk = [&](int bi) -> Blk {
+  auto load_blk = [&](int bi, bool live = true) -> Blk {
     Blk r;
     if (RNG) {
       const Quad q = philox_uniform4(rng, (unsigned)bu, (unsigned)bi, (unsigned)tid);
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
       for (int m = 0; m < 4; ++m) r.v[m] = bi < g.F ? q.u[m] : 0.f;
       return r;
     }
-    const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F ? FB_HOP : 0);
+    const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F && live ? FB_HOP : 0);
 #pragma unroll
     for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
     return r;
@@ -559,22 +561,23 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     // Every global load is issued a whole pass ahead of its use, into the registers its predecessor has just left (inside
     // a step the blocks and tap rows come from HBM, written by the kernel before: half a pass does not cover that --
     // measured alone, on inputs that sit in the memory-side cache, 76 us; inside the step 88; profiles/r04_v5_*)
+    const bool next_pass = q + 1 < q_last, pass_after = q + 2 < q_last;      // workgroup-uniform
     if (warm) {
       pack_taps(t1, t2, z0);                                    // rows b_w, b_w + 1
-      t1 = load_taps(b0 + 3);                                   // the rows whose transform rides behind THIS pass's inverse
-      t2 = load_taps(b0 + 4);
+      t1 = load_taps(b0 + 3, next_pass);                        // the rows whose transform rides behind THIS pass's inverse
+      t2 = load_taps(b0 + 4, next_pass);
     } else {
       pack_blk(x0, b0 < g.F, z0);
-      x0 = load_blk(b0 + 2);                                    // the next pass's first block
+      x0 = load_blk(b0 + 2, next_pass);                         // the next pass's first block
     }
     PL::template forward_s<true, true>(z0, tw, bX, bY, ix);
     if (warm) {
       pack_blk(x0, bw >= 0, z1);                                // block b_w
-      x0 = load_blk(b0 + 2);
+      x0 = load_blk(b0 + 2, next_pass);
     } else {
       pack_blk(x1, b0 + 1 < g.F, z1);
     }
-    x1 = load_blk(b0 + 3);
+    x1 = load_blk(b0 + 3, next_pass);
     PL::template forward_s<true, true>(z1, tw, bX, bY, ix);
 #endif
     if (warm) {
@@ -605,8 +608,8 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     f32x2 zt[S];
     pack_taps(t1, t2, zt);
 #if !defined(DDSP_B6_HALF_PASS_AHEAD)
-    t1 = load_taps(b0 + 5);                                     // the rows of the NEXT pass's second stage
-    t2 = load_taps(b0 + 6);
+    t1 = load_taps(b0 + 5, pass_after);                         // the rows of the NEXT pass's second stage (its transform serves the pass after)
+    t2 = load_taps(b0 + 6, pass_after);
 #endif
     PL::template transposed_then_forward_s<true>(z0, zt, tw, bY, bX, bC, ix);
     park(zt, bC);                                               // read by the next pass's product, behind its first stage's barriers
@@ -633,7 +636,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
 #pragma unroll
     for (int m = 0; m < 4; ++m) tail[m] = z0[4 + m].y;
 #if !defined(DDSP_B6_HALF_PASS_AHEAD)
-    if (has_add) {                                              // the NEXT pass's addend (times b0 + 2 on: never negative), a pass ahead like every load
+    if (has_add && q + 1 < q_last) {                            // the NEXT pass's addend (times b0 + 2 on: never negative), a pass ahead like every load
       const int n0 = e0 + 2 * FB_HOP;                           // the next pass's first emitted time; negative only for b0 + 2 = 0
       const int nx_a = b0 + 2 > 0 ? 4 * n0 : BufF32::kOutOfRange, nx_b = 4 * n0 + 8 * P;
 #pragma unroll

@@ -55,6 +55,46 @@ def test_fir_identity_and_delay(cuda, batch, impl):
     assert float(y[:, :d].abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("n_taps", [1022, 600])
+def test_fir_long_taps_full_size(cuda, batch, n_taps):
+    """514 .. 1022 taps at the BASELINE batch (the classic CombSub harmonic filter, n_mag 512): the per-frame FFT form's LONG
+    variant -- identity, delay, linearity in the signal, and the reach of one frame's taps (its triangle +- N/2, rounding-level
+    leakage inside its pair's window, exact zero beyond), what AUTO picks at these tap counts"""
+    from ddsp_svc_amd import core
+    _, _, x = batch
+    NL = n_taps
+    taps = torch.zeros(B, F, NL, device=cuda)
+    taps[:, :, NL // 2] = 1.0
+    y = core.fft_convolve(x, taps)
+    assert rms(y - x) <= 2e-7 * rms(x)
+    d = min(301, NL // 2 - 1)
+    taps.zero_()
+    taps[:, :, NL // 2 + d] = 1.0
+    y = core.fft_convolve(x, taps)
+    assert rms(y[:, d:] - x[:, :-d]) <= 2e-7 * rms(x)
+    assert float(y[:, :d].abs().max()) <= 1e-6
+    g = torch.Generator().manual_seed(5)
+    taps = (torch.randn(B, F, NL, generator=g) / NL ** 0.5).to(cuda)
+    x2 = torch.roll(x, 1, 0)
+    y1, y2 = core.fft_convolve(x, taps), core.fft_convolve(x2, taps)
+    y12 = core.fft_convolve(x + 0.5 * x2, taps)
+    assert rms(y12 - (y1 + 0.5 * y2)) <= 1e-6 * rms(y12)
+    assert torch.equal(core.fft_convolve(x, taps), y1)              # the same bits call after call
+    t2 = taps.clone()
+    t2[:, 400] += 1.0
+    y3 = core.fft_convolve(x, t2)
+    diff = (y3 - y1).abs().amax(0)
+    lo, hi = 399 * HOP - NL // 2, 401 * HOP + NL // 2
+    assert float(diff[:lo].max()) <= 2e-5 and float(diff[hi + 1:].max()) <= 2e-5
+    assert float(diff[:lo - 4 * HOP].max()) == 0.0 and float(diff[hi + 1 + 4 * HOP:].max()) == 0.0
+    assert float(diff[lo:hi].max()) > 0.1
+    # three utterances against the oracle's direct sum
+    for b in (0, 17):
+        ref = O.ltv_fir_direct(x[b:b + 1, :40 * HOP].cpu().numpy(), taps[b:b + 1, :40].cpu().numpy())
+        got = core.fft_convolve(x[b:b + 1, :40 * HOP].contiguous(), taps[b:b + 1, :40].contiguous()).cpu().numpy()
+        assert rms(got - ref) <= 2e-6 * rms(ref)
+
+
 @pytest.mark.parametrize("impl", [3, 4, 5])
 def test_fir_linearity_and_frame_locality(cuda, batch, impl):
     from ddsp_svc_amd import core

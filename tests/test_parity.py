@@ -396,6 +396,25 @@ def test_fft_convolve_long_taps(dev, B, F, N, run, knobs):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F", [(2, 9), (1, 30)])
+def test_combsub_classic_bin_counts(dev, B, F):
+    """the classic CombSub configuration, n_mag_allpass 256 / n_mag_harmonic 512 / n_mag_noise 256: prime-factor taps and the
+    hop-block filter for the 256-bin filters, chirp-z taps and the LONG per-frame FFT form (1022 taps) for the harmonic one --
+    the whole tail against the oracle"""
+    from ddsp_svc_amd import synth
+    f0 = O.synth_f0(B, F, SR, HOP, seed=F)
+    f0[0] = np.clip(f0[0] * 2.3, 65, 800)
+    cg, ch, cn = O.synth_controls(B, F, [256, 512, 256], seed=F + 1)
+    noise = O.synth_noise(B, F * HOP, seed=F + 2)
+    st = synth.phase(T_(f0, dev), SR, HOP)
+    out = synth.combsub_synth(T_(f0, dev), st, T_(cg, dev), T_(ch, dev), T_(cn, dev), T_(noise, dev), SR, HOP)
+    ref = O.combsub_dsp(f0, cg, ch, cn, noise, SR, HOP)
+    for got, key in zip(out, ("signal", "harmonic", "noise")):
+        e = rms(N_(got) - ref[key])
+        assert e <= 1e-5 * rms(ref[key]) and e <= 1e-4, (key, e, rms(ref[key]))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_fft_convolve_errors(dev):
     from ddsp_svc_amd import core
     a = torch.zeros(2, 1024, device=dev)
