@@ -247,7 +247,7 @@ def _fft_convolve_forward(x, ir, impl):
 
 def fft_convolve_backward(grad_out, audio, impulse_response, need_audio_grad=True):
     """Adjoints of ``fft_convolve``: ``(d_audio|None, d_impulse_response)`` for ``grad_out = dL/dout [B,T]``
-    (hop 512, N <= 512)."""
+    (hop 512, N <= 512: the hop-block FFT kernel; other shapes: direct correlations)."""
     x, ir, g = _f32c(audio), _f32c(impulse_response), _f32c(grad_out)
     B, T = x.shape
     _, F, N = ir.shape
@@ -279,7 +279,7 @@ class FftConvolveFunction(torch.autograd.Function):
 def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
     """core.py:120-182: time-varying FIR of ``audio [B,T]`` with ``impulse_response [B,F,N]``
     (or ``[B,N]`` for a single filter), ``T = F*hop``; returns ``[B,T]``.  Differentiable w.r.t. both arguments
-    (hop 512, N <= 512)."""
+    (every hop and even N; the fast adjoint kernel at hop 512, N <= 512)."""
     _ffi.check_device(audio, impulse_response)
     if impulse_response.dim() == 2:
         impulse_response = impulse_response.unsqueeze(1)

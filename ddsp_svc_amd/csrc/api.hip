@@ -385,7 +385,9 @@ int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float
   if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
   if (!audio || !taps || !grad_out || !d_taps) return DDSP_HIP_EINVAL;
-  if (launch_fir_blk_bwd(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0)
+  // hop 512, N <= 512: the hop-block form; every other shape: direct correlations (fir_bwd_direct.hip)
+  if (launch_fir_blk_bwd(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0 &&
+      launch_fir_bwd_direct(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0)
     return DDSP_HIP_ESHAPE;
   return finish();
 }

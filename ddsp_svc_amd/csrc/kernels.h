@@ -86,6 +86,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
                    const FirSecond* second = nullptr);
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st);
+// every hop / tap count (fir_bwd_direct.hip): direct correlations, behind launch_fir_blk_bwd as k_fir_simple is behind the forward forms
+int launch_fir_bwd_direct(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
+                          int B, int F, int hop, int N, hipStream_t st);
 int launch_fast_source(const float* f0_frames, int B, int F, int hop, double sr, float* rad_acc, float* phase_frames,
                        float* combtooth, hipStream_t st);
 int launch_fast_combtooth(const float* f0_frames, const float* rad_acc, int B, int F, int hop, double sr, float* out,

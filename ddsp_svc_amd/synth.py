@@ -140,7 +140,7 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
     uniform draw (``noise_is_u01``: raw ``rand_like`` output, else already ``2u-1``), or None: drawn inside the noise
     filter from ``(noise_seed, noise_offset)`` (``uniform_noise`` gives the same numbers as a tensor).
     Returns ``(signal, harmonic|None, noise|None)``.  With gradients enabled and a control that requires grad the
-    differentiable composition is used (hop 512, n_mag <= 257)."""
+    differentiable composition is used (the filters at every hop and bin count; their fast adjoint kernels at hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, amplitudes, group_delay, noise_magnitude, noise, state.phase0)
     _need_seed(noise, noise_seed)
     if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
@@ -312,7 +312,7 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
                   noise_seed=None, noise_offset=0):
     """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls; ``noise=None``: the uniform draw happens
     inside the noise filter from ``(noise_seed, noise_offset)`` (see ``sins_synth``).  With gradients enabled and a control
-    that requires grad the differentiable composition is used (hop 512, n_mag <= 257)."""
+    that requires grad the differentiable composition is used (the filters at every hop and bin count; their fast adjoint kernels at hop 512, n_mag <= 257)."""
     _ffi.check_device(f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, state.phase0)
     _need_seed(noise, noise_seed)
     if noise is None and torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):

@@ -141,7 +141,8 @@ int ddsp_hip_frequency_filter(const float* audio, const float* resp_re, long ld_
 
 /* What autograd returns for ddsp_hip_fft_convolve given grad_out[B,T] = dL/dout: d_taps[B,F,N] and, if
  * d_audio is not NULL, d_audio[B,T] (the adjoints of core.py:120-182; training back-propagates through them,
- * solver.py:93-103).  Supported: hop 512, N <= 512 (the hop-block FFT form). */
+ * solver.py:93-103).  hop 512, N <= 512: the hop-block FFT form; every other hop / even N: direct correlations
+ * (csrc/fir_bwd_direct.hip; ~1 ms per launch at B = 32 x 10 s, N = 1022). */
 int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float* taps, const float* grad_out,
                                    float* d_audio, float* d_taps, int B, int F, int hop, int N, void* stream);
 

@@ -62,6 +62,62 @@ def test_fft_convolve_backward(dev, B, F, N, run, knobs):
     assert none is None and torch.equal(dh2, dh)
 
 
+def _case_hop(B, F, N, hop, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.random((B, F * hop)) * 2 - 1).astype(np.float32)
+    ir = (rng.standard_normal((B, F, N)) / np.sqrt(N) * rng.uniform(0.05, 2.0, size=(B, F, 1))).astype(np.float32)
+    R = rng.standard_normal((B, F * hop)).astype(np.float32)
+    return x, ir, R
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F,N,hop", [(2, 5, 1022, 512), (1, 1, 1022, 512), (1, 3, 766, 512), (2, 7, 254, 256), (1, 4, 30, 100),
+                                       (1, 2, 2050, 512), (1, 3, 510, 1100), (3, 1, 2, 7)])
+def test_fft_convolve_backward_any_shape(dev, B, F, N, hop):
+    """outside hop 512 / N <= 512 the adjoints are direct correlations (csrc/fir_bwd_direct.hip): the classic CombSub
+    configuration's 512 harmonic bins (N = 1022), other block sizes, tap rows longer than a tile of the kernel (N > 1024),
+    hops longer than a chunk (hop > 1024), a single frame (the held last row takes both weights of its own block)"""
+    from ddsp_svc_amd import core
+    x, ir, R = _case_hop(B, F, N, hop, 7 * F + N + hop)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    dx, dh = core.fft_convolve_backward(t(R), t(x), t(ir))
+    rx, rh = O.ltv_fir_backward(R, x, ir)
+    assert rms(dx.cpu().numpy() - rx) <= 5e-6 * rms(rx)
+    assert rms(dh.cpu().numpy() - rh) <= 5e-6 * rms(rh)
+    none, dh2 = core.fft_convolve_backward(t(R), t(x), t(ir), need_audio_grad=False)
+    assert none is None and torch.equal(dh2, dh)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_classic_combsub_training_step(dev):
+    """CombSub at the classic bin counts 256 / 512 / 256 (N = 1022 for the harmonic filter): forward on the long-tap form,
+    backward through the direct adjoints -- gradients of all three controls against the float64 adjoints of the oracle's
+    operators, chained by hand (the same composition as synth._combsub_synth_train)"""
+    from ddsp_svc_amd import synth
+    B, F, SR = 1, 6, 44100
+    f0 = O.synth_f0(B, F, SR, HOP, seed=5)
+    cg, ch, cn = O.synth_controls(B, F, [256, 512, 256], seed=6)
+    u = np.random.default_rng(8).random((B, F * HOP), dtype=np.float32)
+    R = np.random.default_rng(9).standard_normal((B, F * HOP)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctrls = [t(c).requires_grad_(True) for c in (cg, ch, cn)]
+    f0t = t(f0)
+    st = synth.phase(f0t, SR, HOP)
+    sig, harm, nz = synth.combsub_synth(f0t, st, ctrls[0], ctrls[1], ctrls[2], t(u), SR, HOP, noise_is_u01=True)
+    ref = O.combsub_dsp(f0, cg, ch, cn, (u * np.float32(2) - np.float32(1)).astype(np.float32), SR, HOP)
+    assert rms(sig.detach().cpu().numpy() - ref["signal"]) <= 1e-5 * rms(ref["signal"])
+    (sig * t(R)).sum().backward()
+    # the same chain on the CPU in float64 torch (the reference's op order, oracle/aten_chain.py) gives the expected gradients
+    from oracle import aten_chain as A
+    c64 = [torch.from_numpy(c.astype(np.float64)).requires_grad_(True) for c in (cg, ch, cn)]
+    want = A.combsub_tail(torch.from_numpy(f0.astype(np.float64)).reshape(B, F, 1), c64[0], c64[1], c64[2],
+                          torch.from_numpy((u.astype(np.float64) * 2 - 1)), SR, HOP)[0]
+    (want * torch.from_numpy(R.astype(np.float64))).sum().backward()
+    for got, ref_c, name in zip(ctrls, c64, ("group delay", "harmonic", "noise")):
+        e = rms(got.grad.cpu().numpy() - ref_c.grad.numpy())
+        assert e <= (3e-5 if name == "group delay" else 1e-5) * rms(ref_c.grad.numpy()), (name, e, rms(ref_c.grad.numpy()))
+
+
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_fft_convolve_autograd(dev):
     from ddsp_svc_amd import core
