@@ -173,19 +173,24 @@ def aux_stream_of(t, rows):
     return None if s is None else s.cuda_stream
 
 
-def on_aux_stream(fn, ref, rows):
+def on_aux_stream(fn, ref, rows, defer_join=False):
     """Run ``fn()`` (a branch that is independent of what the caller's stream does next) on the second stream, forked
     behind the caller's stream and joined back into it; autograd runs the branch's backward on the same stream.
-    Returns ``fn``'s tensor."""
+    Returns ``fn``'s tensor -- with ``defer_join`` the pair ``(tensor, join)``: the caller's stream is NOT made to wait
+    yet, ``join()`` does that, and the caller invokes it right before the first consumer on its own stream (so the launches
+    in between really run beside the branch)."""
     aux = aux_torch_stream(ref, rows)
     if aux is None:
-        return fn()
+        out = fn()
+        return (out, lambda: None) if defer_join else out
     main = torch.cuda.current_stream(ref.device)
     aux.wait_stream(main)
     with torch.cuda.stream(aux):
         out = fn()
-    main.wait_stream(aux)
     out.record_stream(main)                                # allocated under the second stream, consumed on the first
+    if defer_join:
+        return out, (lambda: main.wait_stream(aux))
+    main.wait_stream(aux)
     return out
 
 

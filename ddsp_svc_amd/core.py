@@ -276,6 +276,43 @@ class FftConvolveFunction(torch.autograd.Function):
         return d_x, d_ir, None
 
 
+class FftConvolveAddFunction(torch.autograd.Function):
+    """``(fft_convolve(audio, ir) + addend, fft_convolve(audio, ir))`` from ONE launch (the kernel's ``addend`` /
+    ``out_plain`` arguments: vocoder.py:609,860 ``signal = harmonic + noise``), differentiable in all three inputs: the
+    training composition does not spend an elementwise kernel and a round trip of [B,T] on the sum."""
+
+    @staticmethod
+    def forward(ctx, audio, impulse_response, addend, impl):
+        x, ir, ad = _f32c(audio.detach()), _f32c(impulse_response.detach()), _f32c(addend.detach())
+        ctx.save_for_backward(x, ir)
+        ctx.need_x = audio.requires_grad
+        ctx.set_materialize_grads(False)
+        B, T = x.shape
+        _, F, N = ir.shape
+        out = torch.empty(B, T, dtype=torch.float32, device=x.device)
+        plain = torch.empty_like(out)
+        _ffi.check(_ffi.lib().ddsp_hip_fft_convolve(ptr(x), 0, ptr(ir), ptr(ad), ptr(out), ptr(plain), B, F, T // F, N, int(impl),
+                                                    _ffi.stream_of(x)))
+        return out, plain
+
+    @staticmethod
+    def backward(ctx, g_sum, g_plain):
+        x, ir = ctx.saved_tensors
+        if g_sum is None and g_plain is None:
+            return None, None, None, None
+        g = g_sum if g_plain is None else (g_plain if g_sum is None else g_sum + g_plain)
+        d_x, d_ir = fft_convolve_backward(g.contiguous(), x, ir, need_audio_grad=ctx.need_x)
+        return d_x, d_ir, g_sum, None
+
+
+def fft_convolve_add(audio, impulse_response, addend, impl=_ffi.FIR_AUTO):
+    """``(fft_convolve(audio, impulse_response) + addend, fft_convolve(audio, impulse_response))`` in one launch"""
+    _ffi.check_device(audio, impulse_response, addend)
+    if addend.shape != audio.shape:
+        raise ValueError("addend must have the shape of audio")
+    return FftConvolveAddFunction.apply(audio, impulse_response, addend, impl)
+
+
 def fft_convolve(audio, impulse_response, impl=_ffi.FIR_AUTO):
     """core.py:120-182: time-varying FIR of ``audio [B,T]`` with ``impulse_response [B,F,N]``
     (or ``[B,N]`` for a single filter), ``T = F*hop``; returns ``[B,T]``.  Differentiable w.r.t. both arguments

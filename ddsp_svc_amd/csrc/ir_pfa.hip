@@ -41,7 +41,13 @@ __global__ void k_set_pfa_timeline(long long* p) { g_pfa_timeline = p; }
 namespace pfa {
 
 constexpr int NB = 256, NT = 510, HALF = 255;
-constexpr int ROWS = 16, TR = 8;                 // frames and transforms per batch
+#ifndef DDSP_PFA_ROWS
+#define DDSP_PFA_ROWS 16
+#endif
+// workgroups per CU the LDS of a batch allows (2 ROWS KiB each, 160 KiB per CU less the allocation granule): the register bound follows
+#define DDSP_PFA_WGS (DDSP_PFA_ROWS >= 16 ? 4 : DDSP_PFA_ROWS >= 14 ? 5 : 6)
+constexpr int ROWS = DDSP_PFA_ROWS, TR = ROWS / 2;   // frames and transforms per batch (even; 16: 32 KiB of LDS, four workgroups per CU)
+static_assert(ROWS % 2 == 0 && ROWS <= 16 && ROWS >= 2, "batch of 2 .. 16 rows");
 // W[t][k1][n2], complex: row (t, k1) = 30 words, plus one pad word every 16 rows -- the 32 rows a 32-lane LDS access of stage B
 // touches then start in 32 different bank pairs (30 words = 60 banks = -4 mod 64: 16 rows a revolution, the pad shifts the
 // next 16 by one pair) -- and the array fits the 32 KiB the staged rows need anyway.  (Four workgroups per CU either way: a
@@ -201,9 +207,9 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   if (EXC && (int)blockIdx.y == jobs.n) {                  // workgroup-uniform; before any barrier
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll 1
-    for (int q = 0; q < ROWS / 4; ++q) {
+    for (int q = 0; q < (ROWS + 3) / 4; ++q) {
       const long fr = (long)blockIdx.x * ROWS + q * 4 + wave;
-      if (fr < exc.n_frames)
+      if (q * 4 + wave < ROWS && fr < exc.n_frames)
         combtooth_frame<8, true>(exc.f0_frames, exc.initial_phase, fr, exc.F, exc.hop, exc.up, exc.cfg, exc.phase0, exc.out, lane);
     }
     return;
@@ -238,7 +244,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
     auto load_row = [&](int q) -> float4 {
       const long gr = row0 + wave * 4 + q;
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < rows) {
+      if (gr < rows && wave * 4 + q < ROWS) {
         const float* src = a_re + gr * ld_re + 4 * lane;
         c.x = src[0]; c.y = src[1]; c.z = src[2]; c.w = src[3];
       }
@@ -250,6 +256,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       const float4 cv = nxt;
       if (q < 3) nxt = load_row(q + 1);
       const int r = wave * 4 + q;
+      if (r >= ROWS) break;                                // wave-uniform (batches of fewer than 16 rows)
       const bool live = row0 + r < rows;
       const float g[4] = {kPiF * tanhf(cv.x), kPiF * tanhf(cv.y), kPiF * tanhf(cv.z), kPiF * tanhf(cv.w)};
       const double local = (((double)g[0] + (double)g[1]) + (double)g[2]) + (double)g[3];
@@ -271,7 +278,8 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   } else {
     const int r = tid >> 4, c4 = (tid & 15) * 4;
     const long gr = row0 + r;
-    const bool live = gr < rows;
+    const bool live = gr < rows && r < ROWS;
+    const bool mine = r < ROWS;                             // batches of fewer than 16 rows: the last threads stage nothing
     const float sc = scale * inv_n;
     float v[4][4], w[4][4];
 #pragma unroll
@@ -304,12 +312,12 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
         v[q][e] = live ? v[q][e] * sc : 0.f;
         w[q][e] = live ? w[q][e] * sc : 0.f;
       }
-      if (KIND == KIND_COMPLEX) {
+      if (KIND == KIND_COMPLEX && mine) {
         if (k == 0) w[q][0] = 0.f;
         if (k + 3 == NB - 1) w[q][3] = 0.f;
         *reinterpret_cast<float4*>(im_s + r * NB + k) = make_float4(w[q][0], w[q][1], w[q][2], w[q][3]);
       }
-      *reinterpret_cast<float4*>(re_s + r * NB + k) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+      if (mine) *reinterpret_cast<float4*>(re_s + r * NB + k) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
     }
   }
   __syncthreads();
@@ -481,12 +489,12 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   PFA_STAMP(4);
 }
 
-__global__ void __launch_bounds__(256, 4) k_taps_pfa510(TapsJobs jobs) {
+__global__ void __launch_bounds__(256, DDSP_PFA_WGS) k_taps_pfa510(TapsJobs jobs) {
   __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
   taps_pfa510_body<false>(jobs, ExciterJob{}, U);
 }
 
-__global__ void __launch_bounds__(256, 4) k_front_small(TapsJobs jobs, ExciterJob exc) {
+__global__ void __launch_bounds__(256, DDSP_PFA_WGS) k_front_small(TapsJobs jobs, ExciterJob exc) {
   __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
   taps_pfa510_body<true>(jobs, exc, U);
 }

@@ -1,6 +1,7 @@
 """Functional layer over the fused C-ABI entry points: phase state, exciters and the two DSP tails
 (reference: ddsp/vocoder.py:564-611 Sins, :819-862 CombSub).  Tensors in, tensors out, all on
 the GPU; controls may be non-contiguous ``torch.split`` views (row stride is passed through)."""
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -9,6 +10,10 @@ import torch
 from . import _ffi
 from ._ffi import ptr
 from .core import _f32c, ir_table
+
+# same-box A/B switch (tools/train_step_probe.py): 1 = the noise branch of the training composition is joined into the
+# caller's stream as soon as it is launched (the order before round 4) instead of at its first consumer
+_EARLY_JOIN = os.environ.get("DDSP_HIP_TRAIN_EARLY_JOIN", "0") == "1"
 
 
 @dataclass
@@ -276,35 +281,43 @@ def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, nois
                          block_size, noise_is_u01):
     """CombSub DSP tail as a composition of differentiable primitives (training, solver.py:93-103): the same kernels as
     the fused entry point, intermediates kept for the backward pass.  Returns (signal, harmonic, noise)."""
-    from .core import fft_convolve
+    from .core import fft_convolve, fft_convolve_add
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
     B, F = f0.shape
     nz = _f32c(noise.reshape(B, -1))
     if noise_is_u01:
         nz = nz * 2 - 1                                                                        # :854
     # the noise branch does not meet the harmonic chain before the final sum: second stream (forward and backward)
-    noise_f = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
-        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), f0, B * F)                      # :855-858
+    noise_f, join = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
+        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), f0, B * F, defer_join=True)                     # :855-858
+    if _EARLY_JOIN:
+        join()
     comb = combtooth(f0_frames, state, sampling_rate, block_size)                             # vocoder.py:839-840
     h1 = fft_convolve(comb, AllpassTapsFunction.apply(group_delay))                           # :843-846
     hw = (1.5 * float(sampling_rate)) / (f0 + 1e-3)                                           # :851
-    harmonic = fft_convolve(h1, MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw))   # :847-851
-    return harmonic + noise_f, harmonic, noise_f
+    taps_h = MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw)      # :847-851
+    join()                                                                                    # the noise branch meets the chain here
+    signal, harmonic = fft_convolve_add(h1, taps_h, noise_f)                                  # :860: the sum rides in the filter
+    return signal, harmonic, noise_f
 
 
 def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude, noise, sampling_rate, block_size,
                       noise_is_u01):
     """Sins DSP tail as a composition of differentiable primitives (training).  Returns (signal, harmonic, noise)."""
-    from .core import fft_convolve
+    from .core import fft_convolve, fft_convolve_add
     B = f0_frames.shape[0]
     nz = _f32c(noise.reshape(B, -1))
     if noise_is_u01:
         nz = nz * 2 - 1                                                                                # :603
-    noise_f = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
-        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), nz, B * group_delay.shape[1])         # :604-607
+    noise_f, join = _ffi.on_aux_stream(lambda: fft_convolve(nz, MagnitudeTapsFunction.apply(
+        noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), nz, B * group_delay.shape[1], defer_join=True)       # :604-607
+    if _EARLY_JOIN:
+        join()
     sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)       # vocoder.py:585-594
-    harmonic = fft_convolve(sinus, AllpassTapsFunction.apply(group_delay))                            # :597-600
-    return harmonic + noise_f, harmonic, noise_f
+    taps_ap = AllpassTapsFunction.apply(group_delay)
+    join()
+    signal, harmonic = fft_convolve_add(sinus, taps_ap, noise_f)                                      # :597-600, :609
+    return signal, harmonic, noise_f
 
 
 def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude, noise_magnitude, noise,

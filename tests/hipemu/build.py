@@ -19,21 +19,25 @@ def _clang():
 
 
 def build(force=False, sanitize=False):
-    os.makedirs(OUT, exist_ok=True)
-    lib = LIB.replace(".so", "_asan.so") if sanitize else LIB
+    """DDSP_EMU_EXTRA_FLAGS (e.g. ``-DDDSP_PFA_ROWS=14``): a variant of the sources, built beside the default one under its own name"""
+    extra = os.environ.get("DDSP_EMU_EXTRA_FLAGS", "").split()
+    out = OUT if not extra else OUT + "_" + "".join(c if c.isalnum() else "_" for c in "".join(extra))
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, os.path.basename(LIB))
+    lib = lib.replace(".so", "_asan.so") if sanitize else lib
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
            [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
             os.path.join(ROOT, "include", "ddsp_hip.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
     flags = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC,
-             "-Wno-unknown-attributes", "-Wno-unused-function"]
+             "-Wno-unknown-attributes", "-Wno-unused-function", *extra]
     if sanitize:
         flags += ["-fsanitize=address", "-fno-omit-frame-pointer"]
     objs = []
     for s in SOURCES + ["../../tests/hipemu/hipemu.cpp"]:
         src = os.path.normpath(os.path.join(CSRC, s))
-        o = os.path.join(OUT, os.path.basename(s).replace(".hip", "").replace(".cpp", "") + ("_asan.o" if sanitize else ".o"))
+        o = os.path.join(out, os.path.basename(s).replace(".hip", "").replace(".cpp", "") + ("_asan.o" if sanitize else ".o"))
         subprocess.run([_clang(), *flags, "-c", src, "-o", o], check=True)
         objs.append(o)
     link = [_clang(), "-shared", "-fPIC", *objs, "-o", lib]

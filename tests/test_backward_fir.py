@@ -135,9 +135,55 @@ def test_fft_convolve_autograd(dev):
     h2 = torch.from_numpy(ir).to(dev).requires_grad_(True)
     (core.fft_convolve(torch.from_numpy(x).to(dev), h2) * torch.from_numpy(R).to(dev)).sum().backward()
     assert rms(h2.grad.cpu().numpy() - rh) <= 5e-6 * rms(rh)
-    with pytest.raises(RuntimeError):                       # shapes outside the hop-block form are refused loudly
+    with pytest.raises(RuntimeError):                       # an odd tap count is no output of core.py:254-270: refused loudly
         core.fft_convolve_backward(torch.zeros(1, 1024, device=dev), torch.zeros(1, 1024, device=dev),
-                                   torch.zeros(1, 4, 30, device=dev))
+                                   torch.zeros(1, 4, 31, device=dev))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_fft_convolve_add(dev):
+    """signal = filter(x) + addend with the sum riding in the filter launch (core.fft_convolve_add): values of both outputs and
+    gradients of all three inputs, with either output or both feeding the loss"""
+    from ddsp_svc_amd import core
+    x, ir, R = _case(2, 5, 510, 11)
+    ad = np.random.default_rng(12).standard_normal(x.shape).astype(np.float32)
+    R2 = np.random.default_rng(13).standard_normal(x.shape).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    want = O.ltv_fir_blockfft(x, ir)
+    for use_sum, use_plain in ((True, True), (True, False), (False, True)):
+        a, h, d = t(x).requires_grad_(True), t(ir).requires_grad_(True), t(ad).requires_grad_(True)
+        s, p = core.fft_convolve_add(a, h, d)
+        assert torch.equal(p.detach(), core.fft_convolve(t(x), t(ir)))                   # the plain output: the same launch without the sum
+        assert rms(s.detach().cpu().numpy() - (want + ad)) <= 2e-6 * rms(want + ad)
+        loss = (s * t(R)).sum() * float(use_sum) + (p * t(R2)).sum() * float(use_plain)
+        loss.backward()
+        g = R * float(use_sum) + R2 * float(use_plain)
+        rx, rh = O.ltv_fir_backward(g, x, ir)
+        assert rms(a.grad.cpu().numpy() - rx) <= 5e-6 * rms(rx)
+        assert rms(h.grad.cpu().numpy() - rh) <= 5e-6 * rms(rh)
+        assert np.array_equal(d.grad.cpu().numpy(), R * np.float32(use_sum))
+    with pytest.raises(ValueError):
+        core.fft_convolve_add(t(x), t(ir), t(ad)[:, :-1])
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_allpass_backward_256_same_bits(dev):
+    """the 256-bin form of the all-pass adjoint (16-byte accesses, tanh once per bin) against the general kernel, which a row
+    stride that is no multiple of four selects: the same operations in the same order -- the same bits"""
+    from ddsp_svc_amd import _ffi
+    from ddsp_svc_amd._ffi import ptr
+    rng = np.random.default_rng(3)
+    rows, n = 37, 256
+    c = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32)).to(dev)
+    d_re = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32)).to(dev)
+    d_im = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32)).to(dev)
+    wide = torch.zeros(rows, n + 1, dtype=torch.float32, device=dev)
+    wide[:, :n] = c
+    out_a, out_b = torch.empty_like(c), torch.empty_like(c)
+    lib, st = _ffi.lib(), _ffi.stream_of(c)
+    _ffi.check(lib.ddsp_hip_allpass_backward(ptr(c), n, rows, n, ptr(d_re), ptr(d_im), ptr(out_a), st))
+    _ffi.check(lib.ddsp_hip_allpass_backward(ptr(wide), n + 1, rows, n, ptr(d_re), ptr(d_im), ptr(out_b), st))
+    assert torch.equal(out_a, out_b) and float(out_a.abs().sum()) > 0
 
 
 # ---- tap synthesis backward + the CombSub training path ---------------------------------------------------------

@@ -11,7 +11,7 @@ import torch
 from ddsp_svc_amd import _ffi
 
 dev = torch.device("cuda:0")
-B, F, n, HOP = 32, 862, 256, 512
+B, F, n, HOP = 32, 862, int(os.environ.get("NBINS", 256)), 512
 T, N = F * HOP, 2 * (n - 1)
 L = _ffi.lib()
 st = torch.cuda.current_stream().cuda_stream

@@ -86,3 +86,18 @@ for kind in ("combsub", "sins", "combsubsuperfast"):
                 lat.append(time.perf_counter() - t0)
             print("%-17s B=%d %.2f s (F=%d): StreamingCombSub session %.1f us back to back, %.1f us call-to-result, same bits %s"
                   % (kind, B, seconds, F, us2, sorted(lat)[len(lat) // 2] * 1e6, same), flush=True)
+            # the real-time caller's order is phase -> Unit2Control -> DSP tail (vocoder.py:822-862): what it waits for after
+            # its network is the TAIL alone (three dependent launches); the phase call precedes the network
+            sess.phase(f0)
+            parts = {}
+            for name, fn in (("tail", lambda: sess.synth(f0, cg, ch, cn, u)), ("phase", lambda: sess.phase(f0))):
+                torch.cuda.synchronize()
+                lat = []
+                for _ in range(50):
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    lat.append(time.perf_counter() - t0)
+                parts[name] = (timeit(fn), sorted(lat)[len(lat) // 2] * 1e6)
+            print("%-17s B=%d %.2f s (F=%d): session, DSP tail alone %.1f us back to back, %.1f us call-to-result; phase alone %.1f / %.1f"
+                  % (kind, B, seconds, F, parts["tail"][0], parts["tail"][1], parts["phase"][0], parts["phase"][1]), flush=True)
