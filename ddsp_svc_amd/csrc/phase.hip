@@ -249,8 +249,8 @@ int launch_phase(const float* f0_frames, const float* initial_phase, int B, int 
   Upsampler up = make_upsampler(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   dim3 grid((unsigned)((n_frames + 3) / 4)), block(256);
-  if (!x_or_null && spl == 8 && up.shift > 0 && F <= PH_SMALL_MAX_F && (n_frames < kSmallRows || knob(KNOB_SMALL_PATH) == 2) &&
-      knob(KNOB_SMALL_PATH) != 1) {   // knob 2: the one-launch form at any row count (same-box A/B at batch shapes)
+  if (!x_or_null && spl == 8 && up.shift > 0 && F <= PH_SMALL_MAX_F && n_frames < kSmallRows && knob(KNOB_SMALL_PATH) != 1) {
+    // (at batch shapes the one-launch form loses: B workgroups do not fill the chip -- 52 us against 10 + 5 at B = 32 x 10 s, r04_v22)
     hipLaunchKernelGGL(k_phase_small, dim3((unsigned)B), dim3(1024), 0, st, f0_frames, initial_phase, F, hop, up, cfg, frame_sums,
                        phase0, phase_frames);
     return 0;
