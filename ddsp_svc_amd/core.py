@@ -308,8 +308,16 @@ class FftConvolveAddFunction(torch.autograd.Function):
 def fft_convolve_add(audio, impulse_response, addend, impl=_ffi.FIR_AUTO):
     """``(fft_convolve(audio, impulse_response) + addend, fft_convolve(audio, impulse_response))`` in one launch"""
     _ffi.check_device(audio, impulse_response, addend)
+    if impulse_response.dim() == 2:
+        impulse_response = impulse_response.unsqueeze(1)
     if addend.shape != audio.shape:
         raise ValueError("addend must have the shape of audio")
+    if impulse_response.shape[0] != audio.shape[0]:
+        raise ValueError("Batch size of audio ({}) and impulse response ({}) must be the same.".format(
+            audio.shape[0], impulse_response.shape[0]))
+    if audio.shape[1] % impulse_response.shape[1] != 0:
+        raise ValueError("audio length {} is not a multiple of the {} impulse-response frames".format(
+            audio.shape[1], impulse_response.shape[1]))
     return FftConvolveAddFunction.apply(audio, impulse_response, addend, impl)
 
 
