@@ -188,6 +188,19 @@ __device__ __forceinline__ unsigned wave_max_dpp(unsigned v) {
             mx((unsigned)__builtin_amdgcn_readlane(x, 32), (unsigned)__builtin_amdgcn_readlane(x, 48)));
 }
 
+// a / b in float32 for a normal b > 0 and a quotient far from the range limits (the exciters' sr x / (f0 + 1e-3), vocoder.py:839-840,
+// :649): the hardware reciprocal r (v_rcp_f32, 1 ulp), q0 = a r, e = a - q0 b (exact in the fma), q = q0 + e r.  e r is off by at
+// most 2^-23 of itself and |e r| <= 1.5 ulp(q0), so q is the correctly rounded quotient unless q0 + e r falls within ~2^-24 ulp of
+// a rounding boundary: ~1 argument pair in 10^7 gets the neighbouring float (the IEEE sequence the compiler emits for `/`
+// is v_div_scale x 2, v_rcp, four fmas, v_div_fmas, v_div_fixup: 10 instructions against 4 -- and the exciter kernels run at the
+// vector pipe's rate, EXPERIMENTS 4.2).
+__device__ __forceinline__ float div_pos(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q0 = a * r;
+  const float e = fmaf(-q0, b, a);
+  return fmaf(e, r, q0);
+}
+
 // torch.sinc on a float32 tensor: sin(p) / p with p = fl32(pi32 * z), 1 at z == 0 (vocoder.py:839, :649).
 // |p| < 2: the Taylor series in p^2 to p^12 (truncation 1.2e-8); beyond, the hardware sine (two-constant reduction
 // of the float32 p to revolutions, v_sin_f32: abs error <= 3.9e-7) times v_rcp_f32, i.e. error <= 2e-7 / |p|.

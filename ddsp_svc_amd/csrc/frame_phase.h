@@ -70,7 +70,7 @@ __device__ __forceinline__ void combtooth_frame(const float* __restrict__ f0_fra
   for (int r = 0; r < SPL; ++r) {
     float num = cfg.sr_f * ph.x[r];
     float den = ph.f0u[r] + 1e-3f;
-    v[r] = sinc_f32(num / den);
+    v[r] = sinc_f32(div_pos(num, den));
   }
   store_frame<SPL>(out + fr * (long)hop, hop, lane, v);
 }

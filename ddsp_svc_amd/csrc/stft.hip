@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_fast_combtooth(const float* __restrict_
     const float s0n = s0 + (ds0 * (float)n) / (float)cfg.hop;                      // :644
     rad = rad + shift;                                                             // :647
     rad = rad - rintf(rad);                                                        // :648
-    return sinc_f32(rad / (s0n + 1e-5f));                                          // :649
+    return sinc_f32(div_pos(rad, s0n + 1e-5f));                                    // :649
   };
   if ((cfg.hop & 3) == 0 && i0 + 3 < total) {
     const long b = i0 / T;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_fast_combtooth4(const float* __restrict
     const float s0n = s0 + (POW2 ? dn * rhop : dn / hopf);                           // :644
     rad = rad + acc;                                                                 // :647
     rad = rad - rintf(rad);                                                          // :648
-    v[r] = sinc_f32(rad / (s0n + 1e-5f));                                            // :649
+    v[r] = sinc_f32(div_pos(rad, s0n + 1e-5f));                                      // :649
   }
   *reinterpret_cast<float4*>(out + b * (long)T + t) = make_float4(v[0], v[1], v[2], v[3]);
 }
