@@ -146,21 +146,38 @@ struct BufF32 {
   }
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+// A float64 through the DPP path of the vector ALU (two 32-bit moves): CTRL / ROW_MASK as in the ISA manual; lanes that the row mask
+// disables and -- unless BOUND -- lanes without a source lane read 0.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, BOUND);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave on the VALU: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8: lanes
+// without a source add 0), then the total of row 0 / 2 onto row 1 / 3 (row_bcast15) and of rows 0 - 1 onto rows 2 - 3 (row_bcast31):
+// 6 additions and 12 DPP moves where the __shfl_up form went through the LDS crossbar twelve times with a compare and two
+// selects per step (~80 instructions; it was 9 % of k_combtooth, a kernel that runs at the vector pipe's rate).
+__device__ __forceinline__ double wave_incl_scan(double v) {
+  v += dpp_f64<0x111, 0xF, true>(v);
+  v += dpp_f64<0x112, 0xF, true>(v);
+  v += dpp_f64<0x114, 0xF, true>(v);
+  v += dpp_f64<0x118, 0xF, true>(v);
+  v += dpp_f64<0x142, 0xA, false>(v);
+  v += dpp_f64<0x143, 0xC, false>(v);
   return v;
 }
 
 // exclusive prefix over the 64 lanes of a wave
-__device__ __forceinline__ double wave_excl_scan(double v, int lane) {
-  double inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double u = __shfl_up(inc, d);
-    if (lane >= d) inc += u;
-  }
-  return inc - v;
+__device__ __forceinline__ double wave_excl_scan(double v, int /*lane*/) { return wave_incl_scan(v) - v; }
+
+// sum over the 64 lanes, returned wave-uniform: lane 63 of the inclusive scan
+__device__ __forceinline__ double wave_sum(double v) {
+  const long long b = __builtin_bit_cast(long long, wave_incl_scan(v));
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
 // sum of a float over the 64 lanes of a wave, returned wave-uniform.  Four DPP butterflies (quad_perm,

@@ -163,15 +163,24 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane_emu(T v) {
   return hipemu::peek<T>(s, 0);
 }
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
-// DPP subset used by the kernels: quad_perm (ctrl < 0x100), row_half_mirror (0x141), row_mirror (0x140); full masks
-static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+// DPP subset used by the kernels: quad_perm (ctrl < 0x100), row_shr:n (0x111 .. 0x11F), row_mirror (0x140), row_half_mirror
+// (0x141), row_bcast15 (0x142), row_bcast31 (0x143).  A lane whose row (bank) the row_mask (bank_mask) disables keeps `old`; a lane
+// without a source lane gets 0 with bound_ctrl, `old` without.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   auto s = hipemu::exchange(src);
-  int l = hipemu::g.cur->lane, from;
+  const int l = hipemu::g.cur->lane;
+  int from = -1;
   if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = (l & 15) >= n ? l - n : -1; }
   else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
   else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+  else if (ctrl == 0x142) from = (l >> 4) >= 1 ? ((l >> 4) - 1) * 16 + 15 : -1;
+  else if (ctrl == 0x143) from = (l >> 5) >= 1 ? 31 : -1;
   else { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
-  return hipemu::peek<int>(s, from);
+  const int got = from >= 0 ? hipemu::peek<int>(s, from) : 0;       // (every lane takes part in the exchange)
+  if (!((row_mask >> (l >> 4)) & 1) || !((bank_mask >> ((l & 15) >> 2)) & 1)) return old;
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return got;
 }
 static inline int __builtin_amdgcn_mov_dpp(int src, int ctrl, int rm, int bm, bool bc) {
   return __builtin_amdgcn_update_dpp(0, src, ctrl, rm, bm, bc);
