@@ -90,6 +90,8 @@ struct Upsampler {
   }
 };
 
+__device__ __forceinline__ float div_pos(float a, float b);   // a / b, b > 0 (below)
+
 // Phase bookkeeping shared by the scan kernels and every consumer that re-derives x[t].
 // infer != 0: terms and running sum in float64 (vocoder.py:566); infer == 0: float32 terms, float64
 // running sum rounded to float32 per output as ATen's CPU cumsum does, then float32 wrap (vocoder.py:568).
@@ -104,7 +106,7 @@ struct PhaseCfg {
   // exhaustively against IEEE division over 1.5 M float32 f0 values for the common sampling rates) at 3 float64
   // operations instead of the ~15 of the hardware division sequence.
   __device__ __forceinline__ double term(float f0u) const {
-    if (!infer) return (double)(f0u / sr_f);
+    if (!infer) return (double)div_pos(f0u, sr_f);               // float32 terms (vocoder.py:568); f0u >= 0, sr_f a normal positive
     const double a = (double)f0u;
     const double q0 = a * rsr_d;
     const double e = fma(-q0, sr_d, a);
@@ -216,6 +218,20 @@ __device__ __forceinline__ float div_pos(float a, float b) {
   const float q0 = a * r;
   const float e = fmaf(-q0, b, a);
   return fmaf(e, r, q0);
+}
+
+// exp(x) on the hardware base-2 exponential: x log2(e) is split into its float32 rounding t and the residual r (two-constant
+// log2(e)), exp2(t) (1 + r ln 2).  Relative error ~1e-7 for |x| <= 80 (a bare exp2(x * log2e) is off by |x| * 6e-8); 3 fma / mul +
+// v_exp_f32 + 2 fma against the ~24 instructions of expf.  The control activations exp(c) of every module (vocoder.py:580, :603,
+// :835-836, :661-664) go through it.
+__device__ __forceinline__ float exp_hw(float x) {
+  const float l2e_hi = 1.44269502f;                  // fl32(log2 e)
+  const float l2e_lo = 1.92596303e-8f;               // log2 e - l2e_hi
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147182f, e);
 }
 
 // torch.sinc on a float32 tensor: sin(p) / p with p = fl32(pi32 * z), 1 at z == 0 (vocoder.py:839, :649).

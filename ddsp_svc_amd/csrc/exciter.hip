@@ -266,8 +266,9 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
   __shared__ double wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long fr = blockIdx.x;
-  const long b = fr / F;
-  const int f = (int)(fr - b * F);
+  const unsigned bu = (unsigned)blockIdx.x / (unsigned)F;      // 32-bit frame indices (launcher): a 64-bit division is ~160 instructions
+  const long b = bu;                                           // of a workgroup that lives for one frame
+  const int f = (int)((unsigned)blockIdx.x - bu * (unsigned)F);
   const float* f0_row = f0_frames + b * F;
   const float nyq = cfg.sr_f / 2.0f;
   const int f1 = f + 1 < F ? f + 1 : F - 1;           // last frame held (core.py:68)
@@ -292,8 +293,8 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
     a1 = 0.f;
     if (k >= 1 && k <= H) {
       const float kk = (float)k;
-      a0 = (expf(row0[k - 1]) / 128.0f) * ((fa * kk < nyq ? 1.0f : 0.0f) + 1e-7f);   // vocoder.py:580, core.py:75-76
-      a1 = (expf(row1[k - 1]) / 128.0f) * ((fb * kk < nyq ? 1.0f : 0.0f) + 1e-7f);
+      a0 = (exp_hw(row0[k - 1]) / 128.0f) * ((fa * kk < nyq ? 1.0f : 0.0f) + 1e-7f);   // vocoder.py:580, core.py:75-76
+      a1 = (exp_hw(row1[k - 1]) / 128.0f) * ((fb * kk < nyq ? 1.0f : 0.0f) + 1e-7f);
     }
   };
   // one staging item per (block, j), j = 0 the centre, j = 1..8 a mirrored pair; the frame-to-frame steps are kept beside
@@ -534,8 +535,9 @@ __global__ void __launch_bounds__(64) k_sins_bank_bwd_mfma(const float* __restri
   __shared__ float s_theta[HOP], s_gw[2][HOP];
   const int lane = threadIdx.x;
   const long fr = blockIdx.x;
-  const long b = fr / F;
-  const int f = (int)(fr - b * F);
+  const unsigned bu = (unsigned)blockIdx.x / (unsigned)F;      // 32-bit frame indices (launcher)
+  const long b = bu;
+  const int f = (int)((unsigned)blockIdx.x - bu * (unsigned)F);
   const float* f0_row = f0_frames + b * F;
   {
     // wrapped phase (vocoder.py:564-574) and weighted cotangent of the lane's eight consecutive samples
@@ -600,13 +602,16 @@ __global__ void __launch_bounds__(64) k_sins_bank_bwd_mfma(const float* __restri
 __global__ void __launch_bounds__(256) k_sins_bank_bwd_combine(const float* __restrict__ f0_frames,
                                                                const float* __restrict__ c_amp, long ld_amp,
                                                                const float* __restrict__ partial, int F, int H, int HP,
-                                                               float nyq, long total, float* __restrict__ d_c) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int k = (int)(i % H);
-  const long fr = i / H;
-  const int f = (int)(fr % F);
-  const long b = fr / F;
+                                                               float nyq, float* __restrict__ d_c) {
+  // workgroup = (frame, 256 harmonics): no per-thread index arithmetic (as a flat index over [B F H] every thread paid two
+  // 64-bit divisions and two remainders, ~600 instructions for five memory accesses: 34 us per launch)
+  const int k = (int)blockIdx.y * 256 + (int)threadIdx.x;
+  if (k >= H) return;
+  const long fr = blockIdx.x;
+  const unsigned bu = (unsigned)blockIdx.x / (unsigned)F;      // 32-bit frame indices (launcher)
+  const int f = (int)((unsigned)blockIdx.x - bu * (unsigned)F);
+  const long b = bu;
+  const long i = fr * H + k;
   float dA = partial[(fr * HP + k) * 2];
   if (f > 0) dA += partial[((fr - 1) * HP + k) * 2 + 1];
   if (f == F - 1) dA += partial[(fr * HP + k) * 2 + 1];         // the held last frame (core.py:68)
@@ -701,9 +706,8 @@ int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, con
   else
     hipLaunchKernelGGL(k_sins_bank2_bwd, dim3((unsigned)((long)B * F)), dim3(256), 0, st, f0_frames, initial_phase, grad_out, F,
                        H, up, cfg, phase0, scratch);
-  const long total = (long)B * F * H;
-  hipLaunchKernelGGL(k_sins_bank_bwd_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0_frames, c_amp,
-                     ld_amp, scratch, F, H, HP, (float)sr / 2.0f, total, d_c);
+  hipLaunchKernelGGL(k_sins_bank_bwd_combine, dim3((unsigned)((long)B * F), (unsigned)((H + 255) / 256)), dim3(256), 0, st, f0_frames,
+                     c_amp, ld_amp, scratch, F, H, HP, (float)sr / 2.0f, d_c);
   return 0;
 }
 

@@ -155,17 +155,6 @@ __device__ __forceinline__ float cos_turns_w(float a) {
   return __builtin_amdgcn_cosf(r);
 }
 
-// exp(x) on the hardware base-2 exponential: x log2(e) split into its float32 rounding and the residual (two-constant
-// log2 e), exp2(t) (1 + r ln 2): relative error ~1e-7 (stft.hip uses the same form)
-__device__ __forceinline__ float exp_hw(float x) {
-  const float l2e_hi = 1.44269502f, l2e_lo = 1.92596303e-8f;
-  const float t = x * l2e_hi;
-  float r = fmaf(x, l2e_hi, -t);
-  r = fmaf(x, l2e_lo, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147182f, e);
-}
-
 // a / b with one true division per ROW instead of one per tap: rb = RN(1 / b); q0 = a rb; e = a - q0 b (exact in fma);
 // q = q0 + e rb is the correctly rounded quotient except for ~1 argument pair in 10^6 (off by one ulp).  The only place
 // where an ulp matters is the window's one-sided clamp u > 1 (core.py:245: the factor jumps from 0 to 1 there), so

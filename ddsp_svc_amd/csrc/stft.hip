@@ -173,18 +173,6 @@ __global__ void __launch_bounds__(256) k_fast_combtooth4(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // the spectral filter itself
 // ------------------------------------------------------------------------------------------------
-// exp(x) on the hardware base-2 exponential: x log2(e) is split into its float32 rounding t and the residual r
-// (two-constant log2(e)), exp2(t) (1 + r ln 2).  Relative error ~1e-7 for |x| <= 80 (a bare exp2(x * log2e) is
-// off by |x| * 6e-8).  3 fma/mul + v_exp_f32 + 2 fma.
-__device__ __forceinline__ float exp_hw(float x) {
-  const float l2e_hi = 1.44269502f;                  // fl32(log2 e)
-  const float l2e_lo = 1.92596303e-8f;               // log2 e - l2e_hi
-  const float t = x * l2e_hi;
-  float r = fmaf(x, l2e_hi, -t);
-  r = fmaf(x, l2e_lo, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147182f, e);
-}
 // (cos, sin) of pi * p on v_cos_f32 / v_sin_f32, which take revolutions; fract keeps the argument in their range
 __device__ __forceinline__ f32x2 cis_pi(float p) {
   const float rev = __builtin_amdgcn_fractf(0.5f * p);
