@@ -126,6 +126,22 @@ __device__ __forceinline__ void cis_product(float k, float theta, float& co, flo
   si = __builtin_amdgcn_sinf(r);
 }
 
+// the same for the two samples of a thread at once: the multiplies and fmas packed (the same operations on each half, so the same
+// bits as two calls), the rounding and the hardware sine / cosine per half
+__device__ __forceinline__ void cis_product2(float k, f32x2 theta, f32x2& co, f32x2& si) {
+  const f32x2 inv_hi = {0.15915494f, 0.15915494f}, inv_lo = {6.4206383e-9f, 6.4206383e-9f};
+  const f32x2 kk = {k, k};
+  const f32x2 p_hi = kk * theta;
+  const f32x2 p_lo = __builtin_elementwise_fma(kk, theta, -p_hi);
+  const f32x2 t = p_hi * inv_hi;
+  const f32x2 n = {rintf(t.x), rintf(t.y)};
+  f32x2 r = __builtin_elementwise_fma(p_hi, inv_hi, -n);
+  r = __builtin_elementwise_fma(p_hi, inv_lo, r);
+  r = __builtin_elementwise_fma(p_lo, inv_hi, r);
+  co = f32x2{__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
+  si = f32x2{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
+}
+
 // (lam.x ad.y + ad.x, lam.y ad.y + ad.x): both halves of the result take A from the low and dA from the high half of `ad`
 __device__ __forceinline__ f32x2 lerp_pair(f32x2 lam, f32x2 ad) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -340,11 +356,7 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
   f32x2 tc[SB3_J], ts[SB3_J];
   f32x2 rc, rs;
   {
-    float c0, s0, c1, s1;
-    cis_product(1.0f, theta.x, c0, s0);
-    cis_product(1.0f, theta.y, c1, s1);
-    tc[0] = f32x2{c0, c1};
-    ts[0] = f32x2{s0, s1};
+    cis_product2(1.0f, theta, tc[0], ts[0]);
 #pragma unroll
     for (int j = 1; j < SB3_J; ++j) {
       tc[j] = __builtin_elementwise_fma(tc[j - 1], tc[0], -(ts[j - 1] * ts[0]));
@@ -361,12 +373,7 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
   f32x2 Cb = {1.f, 1.f}, Sb = {0.f, 0.f};            // cis(c theta) of the block
   for (int blk = 0; blk < nblk; ++blk) {
     if ((blk & 3) == 0) {                           // accurate seed
-      const float c = (float)(SB3_J + 1 + SB3_W * blk);
-      float c0, s0, c1, s1;
-      cis_product(c, theta.x, c0, s0);
-      cis_product(c, theta.y, c1, s1);
-      Cb = f32x2{c0, c1};
-      Sb = f32x2{s0, s1};
+      cis_product2((float)(SB3_J + 1 + SB3_W * blk), theta, Cb, Sb);
     } else {                                        // rotate by cis(17 theta)
       const f32x2 cn = __builtin_elementwise_fma(Cb, rc, -(Sb * rs));
       Sb = __builtin_elementwise_fma(Sb, rc, Cb * rs);
@@ -389,11 +396,10 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
   }
   for (int q = 0; q < nsingle; ++q) {               // one or two harmonics beyond the last whole block
     const float k = (float)(SB3_W * nblk_all + 1 + q);
-    float c0, s0, c1, s1;
-    cis_product(k, theta.x, c0, s0);
-    cis_product(k, theta.y, c1, s1);
+    f32x2 ck, sk;
+    cis_product2(k, theta, ck, sk);
     const float2 ad = *reinterpret_cast<const float2*>(amp + nblk * SB3_LD + 2 * q);
-    S = __builtin_elementwise_fma(f32x2{s0, s1}, lerp_pair(lam, f32x2{ad.x, ad.y}), S);
+    S = __builtin_elementwise_fma(sk, lerp_pair(lam, f32x2{ad.x, ad.y}), S);
   }
   const float r[2] = {S.x, S.y};
   float* dst = out + b * (long)F * HOP + t0;
