@@ -149,7 +149,7 @@ struct BufF32 {
 };
 
 // A float64 through the DPP path of the vector ALU (two 32-bit moves): CTRL / ROW_MASK as in the ISA manual; lanes that the row mask
-// disables and -- unless BOUND -- lanes without a source lane read 0.
+// disables and lanes without a source lane read 0 (`old` is 0; BOUND = bound_ctrl:0 says the same for the lanes without a source).
 template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ __forceinline__ double dpp_f64(double v) {
   const long long b = __builtin_bit_cast(long long, v);
