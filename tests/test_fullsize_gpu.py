@@ -4,6 +4,8 @@ The oracle needs minutes for a batch of this size, so parity here goes through s
 the operators plus an oracle comparison of a few utterances cut out of the full batch (utterances are
 independent, so row b of the batched result must equal the single-utterance result).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -185,6 +187,8 @@ def test_tail_second_stream_full_size(cuda, batch, kind, monkeypatch):
     f0, (c0, c1, c2), noise = batch
     fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
     st = synth.phase(f0, SR, HOP)
+    if os.environ.get("DDSP_HIP_ONE_STREAM") == "1":
+        pytest.skip("the second stream is switched off (DDSP_HIP_ONE_STREAM=1)")
     assert _ffi.aux_stream_of(f0, B * F) is not None
     with monkeypatch.context() as m:
         m.setattr(_ffi, "aux_stream_of", lambda t, rows: None)
@@ -213,6 +217,8 @@ def test_training_second_stream_full_size(cuda, batch, kind, monkeypatch):
         (sig * R).sum().backward()
         return sig.detach(), [x.grad for x in c]
 
+    if os.environ.get("DDSP_HIP_ONE_STREAM") == "1":
+        pytest.skip("the second stream is switched off (DDSP_HIP_ONE_STREAM=1)")
     assert _ffi.aux_torch_stream(f0, B * F) is not None
     with monkeypatch.context() as m:
         m.setattr(_ffi, "aux_torch_stream", lambda t, rows: None)
