@@ -386,51 +386,120 @@ def also_lines(a, device, B, F, n, want_traffic):
 
 def cfg4_line(a, rank, world, device, F, n, comm):
     """BASELINE cfg 4 (combsub, 512 utterances sharded over 8 GPUs = 64 per GPU, RCCL gather over xGMI): samples/s of the
-    sharded synthesis alone and with the gather of every step's waveforms to rank 0, max over ranks."""
+    sharded synthesis alone (A) and with the gather of every step's waveforms to rank 0 (B), max over ranks.  Measured as
+    INTERLEAVED rounds A B A B .. after a clock ramp-up and warm-up steps of both forms, wall clock (between fences) beside HIP
+    events, at least 50 steps of each: a drift of the box moves both columns alike, and the reported figures are medians over the
+    rounds with the paired difference B - A beside them (round 4 timed 20 cold steps of A, then 20 of B, and read B < A)."""
     import torch.distributed as dist
     from ddsp_svc_amd import sharding
     B4 = a.cfg4_batch
     T = F * HOP
     step, _ = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
-    steps, warm = max(5, min(a.steps, 20)), 3
+    per = max(2, min(10, a.steps))
+    rounds = 6 if a.steps >= 20 else 2
+    if not dist.is_initialized() and world == 1 and not a.no_cfg4_gather:
+        # the default N = 1 command times the gather too: a 1-rank communicator, the same call path (a failure to open it
+        # costs the gather column, not the line)
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            RT.init_process_group(rank, world, device)
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)
+            comm["rccl_ranks"] = int(probe.item())
+        except Exception as e:                                           # noqa: BLE001
+            comm["cfg4_communicator_error"] = "%s: %s" % (type(e).__name__, e)
+    have_pg = dist.is_initialized()
 
     def fence():
-        if dist.is_initialized() and world > 1:
+        if have_pg and world > 1:
             dist.barrier()
         RT.synchronize()
 
     def reduce_max(*vals):
-        if not (dist.is_initialized() and world > 1):
+        if not (have_pg and world > 1):
             return vals
         tt = torch.tensor(vals, dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return tuple(float(v) for v in tt)
-    el, ev_ms, out = time_steps(step, steps, warm, fence)
-    (el,) = reduce_max(el)
+
+    def step_g():
+        return sharding.gather_utterances(step(), B4 * world, dst=0)
+    prewarm(step, min(a.prewarm_seconds, 0.3))
+    forms = [("plain", step)] + ([("gather", step_g)] if have_pg else [])
+    wall = {k: [] for k, _ in forms}
+    ev = {k: [] for k, _ in forms}
+    for _, fn in forms:                                                  # warm-up of both forms (allocator, communicator buffers)
+        for _ in range(3):
+            out = fn()
+    fence()
+    for _ in range(rounds):
+        for k, fn in forms:
+            el, ev_ms, out = time_steps(fn, per, 0, fence)
+            el, ev_ms = reduce_max(el, ev_ms)
+            wall[k].append(el / per * 1e3)
+            ev[k].append(ev_ms)
+    med = lambda v: float(np.median(v))
+    ms = med(wall["plain"])
     res = {"workload": "combsub B=%d/GPU x %.0f s on %d GPU(s): %d utterances, n_mag %d/%d/%d (BASELINE cfg 4)"
                        % (B4, a.seconds, world, B4 * world, n, n, n),
-           "batch_per_gpu": B4, "n_gpus": world, "steps": steps, "warmup": warm,
-           "ms_per_step": el / steps * 1e3, "value": B4 * world * T * steps / el, "unit": "samples/s",
-           "rccl_ranks": comm.get("rccl_ranks")}
-    if dist.is_initialized():
-        def step_g():
-            return sharding.gather_utterances(step(), B4 * world, dst=0)
-        elg, _, full = time_steps(step_g, steps, warm, fence)
-        t1 = time.perf_counter()
-        full = sharding.gather_utterances(out, B4 * world, dst=0)
+           "batch_per_gpu": B4, "n_gpus": world, "steps": per * rounds, "rounds": rounds, "steps_per_round": per, "warmup": 3,
+           "method": "interleaved rounds (plain, gather, plain, ..) of %d steps after clock ramp-up; medians over rounds" % per,
+           "ms_per_step": ms, "ms_per_step_events": med(ev["plain"]), "value": B4 * world * T / (ms * 1e-3), "unit": "samples/s",
+           "rounds_ms": [round(v, 4) for v in wall["plain"]], "rccl_ranks": comm.get("rccl_ranks")}
+    if have_pg:
+        alone, y = [], step()
         fence()
-        g_ms = (time.perf_counter() - t1) * 1e3
-        elg, g_ms = reduce_max(elg, g_ms)
+        for _ in range(3):                                               # the gather alone, between fences
+            t1 = time.perf_counter()
+            full = sharding.gather_utterances(y, B4 * world, dst=0)
+            fence()
+            alone.append((time.perf_counter() - t1) * 1e3)
+        (g_alone,) = reduce_max(med(alone))
         if rank == 0:
             assert full.shape == (B4 * world, T) and torch.isfinite(full[::8, ::4096]).all()
             res["gather_checked_rows"] = int(full.shape[0])
-        res.update({"ms_per_step_with_gather": elg / steps * 1e3, "value_with_gather": B4 * world * T * steps / elg,
-                    "gather_ms": g_ms, "gather_bytes_per_rank": 4.0 * B4 * T,
+        msg = med(wall["gather"])
+        res.update({"ms_per_step_with_gather": msg, "ms_per_step_with_gather_events": med(ev["gather"]),
+                    "value_with_gather": B4 * world * T / (msg * 1e-3),
+                    "rounds_ms_with_gather": [round(v, 4) for v in wall["gather"]],
+                    "gather_ms": g_alone,
+                    "gather_overhead_ms": med([g - p for g, p in zip(wall["gather"], wall["plain"])]),
+                    "gather_bytes_per_rank": 4.0 * B4 * T,
                     "gather": "torch.distributed.gather (%s) of every step's [%d, T] waveforms into slices of the "
-                              "result on rank 0" % ("nccl = RCCL" if RT.backend == "nccl" else RT.backend, B4)})
+                              "result on rank 0; gather_ms = one gather alone between fences (median of 3), "
+                              "gather_overhead_ms = median of the rounds' paired differences (what a step pays for it)"
+                              % ("nccl = RCCL" if RT.backend == "nccl" else RT.backend, B4)})
     else:
-        res["gather"] = "not timed: no process group (run with --gather or N > 1)"
+        res["gather"] = "not timed: no process group (%s)" % comm.get("cfg4_communicator_error", "--no-cfg4-gather")
     return res
+
+
+def parity_gate(kind, f0, ctrls, noise, out, rows=None):
+    """no timing is printed for an output that is not the reference's.  Utterances ``rows`` (default: the
+    first and the last -- the last one is where a wrong sub-batch offset would land) of the TIMED step's output against the
+    oracle's restatement of the reference on the same f0 / controls / noise: <= 1e-4 RMS absolute (the north star's bar) and
+    <= 1e-5 relative, else SystemExit.  Returns the record that goes into the line as ``parity_vs_oracle``."""
+    from oracle import ddsp_oracle as O
+    B = f0.shape[0]
+    rows = sorted(set(rows if rows is not None else (0, B - 1)))
+    t0 = time.perf_counter()
+    fn = O.combsub_dsp if kind == "combsub" else O.sins_dsp
+    worst_abs = worst_rel = 0.0
+    for b in rows:
+        args = [t[b:b + 1].detach().cpu().numpy() for t in (f0, ctrls[0], ctrls[1], ctrls[2], noise)]
+        ref = fn(np.ascontiguousarray(args[0]), *(np.ascontiguousarray(c) for c in args[1:4]),
+                 np.ascontiguousarray(args[4]), SR, HOP)["signal"].astype(np.float64)
+        got = out[b:b + 1].detach().cpu().numpy().astype(np.float64)
+        e = float(np.sqrt(np.mean((got - ref) ** 2)))
+        r = e / max(float(np.sqrt(np.mean(ref ** 2))), 1e-30)
+        worst_abs, worst_rel = max(worst_abs, e), max(worst_rel, r)
+    rec = {"rows": rows, "rms_abs": worst_abs, "rms_rel": worst_rel, "bar_abs": 1e-4, "bar_rel": 1e-5,
+           "oracle": "oracle/ddsp_oracle.py %s_dsp (numpy restatement of the reference, pinned to its fixtures)" % kind,
+           "seconds": time.perf_counter() - t0}
+    if not (worst_abs <= 1e-4 and worst_rel <= 1e-5) or not np.isfinite(worst_abs):
+        raise SystemExit("bench.py: the timed output is NOT the reference's: %s" % json.dumps(rec))
+    return rec
 
 
 def cpu_baseline(kind, F, sizes, budget_s=12.0):
@@ -1311,6 +1380,10 @@ def main(argv=None):
     ap.add_argument("--cfg4", action="store_true",
                     help="also run BASELINE cfg 4's per-GPU shape (64 utterances per GPU) -- default at --gpus 8")
     ap.add_argument("--cfg4-batch", type=int, default=64, help="utterances per GPU of the cfg-4 line (BASELINE: 64)")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg-4 line (part of the default N = 1 and N = 8 runs)")
+    ap.add_argument("--no-cfg4-gather", action="store_true", help="cfg-4 line without opening a 1-rank communicator at N = 1")
+    ap.add_argument("--no-parity-gate", action="store_true",
+                    help="do not hold the timed output against the oracle before printing (A/B runs of broken ablation builds)")
     a = ap.parse_args(argv)
     if a.only_steps:
         a.prewarm_seconds = 0.0
@@ -1423,7 +1496,15 @@ def main(argv=None):
     blk = "k_fir_blk<" if os.environ.get("DDSP_HIP_BLK_WPS", "").strip() == "2" else "k_fir_blk6"
     kname = {4: "k_fir_fft", 5: blk}.get(used_impl, "k_fir_mfma")
     # BASELINE cfg 4's per-GPU shape: every rank takes part (collectives inside)
-    cfg4 = cfg4_line(a, rank, world, device, F, n, comm) if a.model == "combsub" and (world == 8 or a.cfg4) else None
+    # (every rank takes part; at N = 1 it is part of the default command, so that the driver's run records the per-GPU shape
+    # every multi-GPU point is made of)
+    want_cfg4 = a.model == "combsub" and not a.no_cfg4 and (world == 8 or a.cfg4 or (world == 1 and (B, F, n) == (32, 862, 256)
+                                                                                   and not a.no_also))
+    cfg4 = cfg4_line(a, rank, world, device, F, n, comm) if want_cfg4 else None
+    # parity gate: rank 0's timed output against the oracle BEFORE any number is printed
+    parity = None
+    if rank == 0 and not a.no_parity_gate:
+        parity = parity_gate(a.model, f0, ctrls, noise, out)
     # arithmetic the FFT forms actually execute (5 N log2 N per complex transform + spectral products): per frame pair
     # three 2048-point transforms (k_fir_fft) or per hop-block pair four 1024-point ones (k_fir_blk)
     if used_impl == 5:
@@ -1482,6 +1563,7 @@ def main(argv=None):
                                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0},
         }
         res.update(comm)
+        res["parity_vs_oracle"] = parity
         res["roofline_step_traffic"] = None if tr is None else {
             "pmc_bytes_per_step": tr["hbm_bytes"], "algorithmic_bytes_per_step": alg_bytes,
             "ratio": tr["hbm_bytes"] / alg_bytes, "launches_per_step": tr.get("launches_per_step"), "source": tr["source"],
@@ -1528,9 +1610,14 @@ def main(argv=None):
                 try:
                     g_ = aten_chain_on_gpu(a.model, f0, ctrls, noise, out, device)
                     g_["hip_over_eager"] = value / g_["value"]
-                except Exception as e:                                  # a baseline must not take the line down
+                except Exception as e:                                  # a baseline that cannot RUN must not take the line down
                     g_ = {"error": "%s: %s" % (type(e).__name__, e)}
                 res["cpu_baseline_aten_chain"]["same_chain_on_gpu"] = g_
+                # ... but one that ran is a second, full-batch parity gate: the reference's op chain on the same GPU
+                if not a.no_parity_gate and g_.get("rel_rms_vs_hip_path") is not None and not g_["rel_rms_vs_hip_path"] <= 1e-5:
+                    raise SystemExit("bench.py: the timed output differs from the reference's op chain on the same inputs: "
+                                     "rel RMS %.3e > 1e-5" % g_["rel_rms_vs_hip_path"])
+                g_["gate"] = "rel_rms_vs_hip_path <= 1e-5 or no line"
         emit((res))
     finish_ranks()
 

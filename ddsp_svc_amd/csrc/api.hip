@@ -15,7 +15,7 @@ namespace ddsp {
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -131,6 +131,71 @@ struct Branch {
     forked = false;
   }
 };
+
+// ---- Sub-batches and lanes (round 5) ---------------------------------------------------------------------------------
+// Utterances are independent (core.py:120-182 has no op across the batch), so a large call is issued as SUB-BATCHES of
+// ~kLaneRows frames that alternate between two LANES: lane 0 = the caller's stream pair, lane 1 = a pair of streams this
+// library owns (created once per host thread and device, beside the fork / join events).  Each lane has ONE workspace slot
+// that its sub-batches re-use in stream order, so (a) the prefix of sub-batch k+1 (exciter, tap syntheses) runs beside the
+// filters of sub-batch k instead of after them, (b) the scratch of a call is two slots of a sub-batch whatever B is
+// (B = 64 x 10 s: the bytes of B = 32), and the intermediates of a sub-batch (three tap tensors, exciter, two [B,T]
+// signals: 170 MB at 16 utterances) stay inside the 256 MB memory-side cache between their producer and their consumer.
+// The samples are those of the unsplit call bit for bit (tests/test_lanes.py).  Knobs: LANE_ROWS = frames per sub-batch
+// (1: never split), LANES = 1: one lane (sub-batches in sequence on the caller's streams, one slot).
+constexpr long kLaneRows = 14336;
+
+struct LanePlan { int nsub, Bs, slots; };
+
+LanePlan lane_plan(int B, int F) {
+  LanePlan p{1, B, 1};
+  long target = knob(KNOB_LANE_ROWS);
+  if (target == 0) target = kLaneRows;
+  const long R = (long)B * F;
+  if (target <= 1 || B < 2) return p;
+  if (2 * R < 3 * target) return p;                       // below one and a half sub-batches: not worth two half-empty lanes
+  long nsub = (R + target - 1) / target;                  // sub-batches of at most `target` frames, evenly sized
+  if (nsub > B) nsub = B;
+  p.Bs = (int)((B + nsub - 1) / nsub);
+  // the tap syntheses transform two ROWS per complex transform (ir_pfa.hip, ir_czt.hip), and a row's last bits depend on its
+  // partner: a sub-batch starts on an even row, so that every row keeps the partner it has in the unsplit call
+  if ((F & 1) && (p.Bs & 1)) ++p.Bs;
+  p.nsub = (B + p.Bs - 1) / p.Bs;
+  if (p.nsub < 2) return LanePlan{1, B, 1};
+  p.slots = knob(KNOB_LANES) == 1 ? 1 : 2;
+  if (p.slots > p.nsub) p.slots = p.nsub;
+  return p;
+}
+
+struct LaneSet {
+  hipStream_t main1 = nullptr, aux1 = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+// the second lane's stream pair of this host thread on the current device, or null (then every sub-batch takes lane 0)
+LaneSet* second_lane() {
+  static thread_local LaneSet per_device[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  LaneSet& l = per_device[dev];
+  if (!l.join) {
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool ok = hipStreamCreateWithFlags(&s0, hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      if (s0) (void)hipStreamDestroy(s0);
+      if (s1) (void)hipStreamDestroy(s1);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    l.main1 = s0; l.aux1 = s1; l.fork = e0; l.join = e1;
+  }
+  return &l;
+}
 
 // Whether this call uses the dense contraction at 256 bins too (knob TAPS_GEMM): read ONCE per entry point into this
 // thread-local, so that the stream layout and every tap synthesis of one call agree even if another thread changes
@@ -429,12 +494,168 @@ int ddsp_hip_sinusoid_bank_backward(const float* f0_frames, const float* initial
   return finish();
 }
 
+}  // extern "C"
+
+namespace {
+
+// one synthesiser call as data: what a sub-batch of it is (rows b0 .. b0 + Bn of every per-utterance array)
+struct TailCall {
+  const float* f0_frames; const float* initial_phase; const double* phase0;
+  const float* c0; long ld0;          // Sins: amplitudes            CombSub: group delay
+  const float* c1; long ld1;          // Sins: group delay           CombSub: harmonic magnitude
+  const float* c2; long ld2;          // noise magnitude
+  const float* noise; int noise_is_u01;
+  int B, F, hop; double sr; int infer;
+  int n0, n1, n2;                     // Sins: H, n_ap, n_nz         CombSub: n_ap, n_harm, n_nz
+  const float* t0; const float* t1; const float* t2;       // basis tables (Sins: t0 unused)
+  float* signal; float* harmonic; float* noise_out;
+  int fir_impl;
+  NoiseGen gen;
+};
+
+TailCall rows_of(const TailCall& a, int b0, int Bn) {
+  TailCall s = a;
+  const long r0 = (long)b0 * a.F, t0 = r0 * a.hop;
+  s.B = Bn;
+  s.f0_frames += r0;
+  if (s.initial_phase) s.initial_phase += b0;
+  s.phase0 += r0;
+  s.c0 += r0 * a.ld0; s.c1 += r0 * a.ld1; s.c2 += r0 * a.ld2;
+  if (s.noise) s.noise += t0;
+  s.signal += t0;
+  if (s.harmonic) s.harmonic += t0;
+  if (s.noise_out) s.noise_out += t0;
+  s.gen.utt0 = a.gen.utt0 + (unsigned)b0;
+  return s;
+}
+
+typedef int (*TailFn)(const TailCall&, SynthWs&, hipStream_t, void*);
+
+// Issue `one` over the sub-batches of `a` (lane_plan): sub-batch k on lane k mod 2 with that lane's workspace slot.  Lane 1's
+// streams wait for everything the caller's stream holds at entry (the inputs' producers) and are joined back into it before
+// the call returns, as the branch stream is: whatever the caller's stream does next is ordered behind the whole call.
+int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, int n_max, hipStream_t st, void* aux_stream,
+              TailFn one) {
+  SynthWs w[2];
+  {
+    Carver c(ws, ws_bytes);
+    for (int l = 0; l < p.slots; ++l) carve_synth(c, p.Bs, a.F, a.hop, n_max, w[l]);
+    if (!c.ok) return DDSP_HIP_EWS;
+  }
+  // a second lane needs a stream pair of its own; without a branch stream (one-stream mode, emulator) the sub-batches run in
+  // sequence on the caller's stream, alternating between the slots
+  LaneSet* lane1 = (p.slots == 2 && aux_stream && S(aux_stream) != st) ? second_lane() : nullptr;
+  if (lane1) {
+    if (hipEventRecord(lane1->fork, st) != hipSuccess || hipStreamWaitEvent(lane1->main1, lane1->fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      lane1 = nullptr;
+    }
+  }
+  int rc = 0;
+  for (int k = 0; k < p.nsub; ++k) {
+    const int b0 = k * p.Bs, Bn = a.B - b0 < p.Bs ? a.B - b0 : p.Bs;
+    const TailCall sub = rows_of(a, b0, Bn);
+    const int l = p.slots == 2 ? (k & 1) : 0;
+    const int r = (l == 1 && lane1) ? one(sub, w[1], lane1->main1, lane1->aux1) : one(sub, w[l], st, aux_stream);
+    if (r != 0 && rc == 0) rc = r;
+    if (rc != 0) break;
+  }
+  if (lane1) {                                           // always joined, also on the error path
+    (void)hipEventRecord(lane1->join, lane1->main1);
+    (void)hipStreamWaitEvent(st, lane1->join, 0);
+  }
+  return rc;
+}
+
+// the batch layout of the Sins tail (vocoder.py:580-611) on one (sub-)batch
+int sins_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
+  const int B = a.B, F = a.F, hop = a.hop, H = a.n0, n_ap = a.n1, n_nz = a.n2;
+  const long R = (long)B * F;
+  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
+  float* nz = a.noise_out ? a.noise_out : w.nzbuf;
+  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
+  // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
+  // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
+  const bool ap_ahead = n_ap == 256 && !t_taps_gemm && knob(KNOB_STREAM_LAYOUT) != 1;
+  if (ap_ahead) synth_allpass_taps(a.c1, a.ld1, a.t1, R, n_ap, w.re, w.im, w.taps, br.aux);
+  synth_taps(a.c2, a.ld2, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R,
+             n_nz, w.taps_nz, br.aux);
+  const int rn = launch_fir(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), a.fir_impl,
+                            br.aux, &a.gen);
+  if (!ap_ahead) synth_allpass_taps(a.c1, a.ld1, a.t1, R, n_ap, w.re, w.im, w.taps, st);
+  // exciter: sinusoid bank (vocoder.py:585-594)
+  const int r = launch_sins_bank(a.f0_frames, a.initial_phase, a.c0, a.ld0, B, F, hop, H, a.sr, a.infer, a.phase0, w.buf0, st);
+  br.join();                                           // always joined, also on the error paths below
+  if (r == -1) return DDSP_HIP_EHOP;
+  if (r == -2 || rn < 0) return DDSP_HIP_ESHAPE;
+  // harmonic = all-pass(sinusoids) (vocoder.py:597-600); signal = harmonic + noise (:609)
+  if (launch_fir(w.buf0, 0, w.taps, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_ap - 1), a.fir_impl, st) < 0)
+    return DDSP_HIP_ESHAPE;
+  return 0;
+}
+
+// the batch layout of the CombSub tail (vocoder.py:834-862) on one (sub-)batch
+int combsub_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
+  const int B = a.B, F = a.F, hop = a.hop, n_ap = a.n0, n_harm = a.n1, n_nz = a.n2;
+  const long R = (long)B * F;
+  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
+  float* nz = a.noise_out ? a.noise_out : w.nzbuf;
+  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
+  // Stream layout (knob STREAM_LAYOUT).  1: the noise branch -- its taps and its filter -- on the second stream beside the
+  // harmonic chain, joined into the last filter as its addend.  4 (default where every filter has 256 bins; otherwise the
+  // all-pass response is staged in the exciter buffer and 1 is used): as 1 with the exciter on the second stream too, ahead
+  // of the noise branch, so the (vector-ALU bound) exciter runs beside the (latency bound) all-pass tap synthesis instead
+  // of after it.  Same-box A/Bs at B = 32 x 10 s, ms per step: 1 / 4 0.401 / 0.388 (profiles/r02_v14_*); three more that
+  // lost (all taps ahead on the second stream, 0.424; the second harmonic filter's taps there too, 0.403; the harmonic
+  // chain's front on the second stream, 0.439 against 0.422) are in DESIGN.md section 7 and no longer in the code.
+  long layout = knob(KNOB_STREAM_LAYOUT);
+  if (layout != 1) layout = 4;
+  if (!all256) layout = 1;
+  int rc = 0;
+  if (layout == 4) {                                       // exciter: combtooth (vocoder.py:839-840)
+    rc = launch_combtooth(a.f0_frames, a.initial_phase, B, F, hop, a.sr, a.infer, a.phase0, w.buf0, br.aux);
+    br.publish(0);
+  }
+  // noise branch (vocoder.py:854-858)
+  synth_taps(a.c2, a.ld2, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
+             w.taps_nz, br.aux);
+  const int rn = launch_fir(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), a.fir_impl,
+                            br.aux, &a.gen);
+  // all-pass taps (vocoder.py:843-846; at other bin counts their response lives in buf0 until the exciter overwrites it)
+  synth_allpass_taps(a.c0, a.ld0, a.t0, R, n_ap, w.re, w.im, w.taps, st);
+  if (layout == 4) br.await(0);
+  else rc = launch_combtooth(a.f0_frames, a.initial_phase, B, F, hop, a.sr, a.infer, a.phase0, w.buf0, st);
+  int r1 = 0;
+  if (rc == 0) {
+    r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), a.fir_impl, st);
+    // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851); half_width_frames = 1.5 sr / (f0 + 1e-3)
+    // (:851) is formed in the kernel's epilogue
+    synth_taps(a.c1, a.ld1, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, a.t1, DDSP_HIP_MODE_DYNAMIC, a.f0_frames, R, n_harm,
+               w.taps, st, (float)a.sr);
+  }
+  br.join();                                             // always joined, also on the error paths below
+  if (rc != 0) return DDSP_HIP_EHOP;
+  if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
+  // signal = harmonic + noise (vocoder.py:860): the second harmonic filter adds the branch's result
+  if (launch_fir(w.buf1, 0, w.taps, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_harm - 1), a.fir_impl, st) < 0)
+    return DDSP_HIP_ESHAPE;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max) {
   if (B <= 0 || F <= 0 || hop <= 0 || n_max < 2) return 0;
   Carver c(nullptr, (size_t)-1);
   c.base = nullptr;
   SynthWs w;
-  return carve_synth(c, B, F, hop, n_max, w);
+  const LanePlan p = lane_plan(B, F);                    // a split call: one slot per lane, each of one sub-batch
+  if (p.nsub == 1) return carve_synth(c, B, F, hop, n_max, w);
+  size_t end = 0;
+  for (int l = 0; l < p.slots; ++l) end = carve_synth(c, p.Bs, F, hop, n_max, w);
+  return end;
 }
 
 int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,
@@ -452,21 +673,28 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   // 16 bytes at a time: the taps carved out of ws must be 16-byte aligned (ddsp_hip.h states the contract)
   if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return DDSP_HIP_EINVAL;
   // noise == NULL: the uniform draw happens inside the noise filter (philox.h) from (noise_seed, noise_offset)
-  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};
+  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1, 0u};
   if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   const int n_max = n_ap > n_nz ? n_ap : n_nz;
+  hipStream_t st = S(stream);
+  const long R = (long)B * F;
+  const TapsFormScope form;
+  const TailCall call{f0_frames, initial_phase, phase0, c_amp, ld_amp, c_gd, ld_gd, c_nz, ld_nz, noise, noise_is_u01,
+                      B, F, hop, sr, infer, H, n_ap, n_nz, nullptr, table_ap, table_nz, signal, harmonic_or_null,
+                      noise_out_or_null, fir_impl, gen};
+  const LanePlan plan = lane_plan(B, F);
+  if (plan.nsub > 1) {
+    const int rc = run_lanes(call, plan, ws, ws_bytes, n_max, st, aux_stream, sins_rows);
+    return rc != 0 ? rc : finish();
+  }
   Carver c(ws, ws_bytes);
   SynthWs w;
   carve_synth(c, B, F, hop, n_max, w);
   if (!c.ok) return DDSP_HIP_EWS;
-  hipStream_t st = S(stream);
-  const long R = (long)B * F;
-  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
-  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-  const TapsFormScope form;
   // Streaming shapes (as ddsp_hip_combsub_synth below): both tap syntheses in one launch -- four dependent launches instead of
   // five: sinusoid bank | taps (grid.y) | noise filter | all-pass filter + noise.  Same kernels, same arguments, same bits.
   if (R < kSmallRows && n_ap == 256 && n_nz == 256 && !t_taps_gemm && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
     const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
     if (r == -1) return DDSP_HIP_EHOP;
     if (r == -2) return DDSP_HIP_ESHAPE;
@@ -483,25 +711,8 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
       return DDSP_HIP_ESHAPE;
     return finish();
   }
-  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
-  // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
-  // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
-  const bool ap_ahead = n_ap == 256 && !t_taps_gemm && knob(KNOB_STREAM_LAYOUT) != 1;
-  if (ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, br.aux);
-  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-             n_nz, w.taps_nz, br.aux);
-  const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                            br.aux, &gen);
-  if (!ap_ahead) synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-  // exciter: sinusoid bank (vocoder.py:585-594)
-  const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
-  br.join();                                           // always joined, also on the error paths below
-  if (r == -1) return DDSP_HIP_EHOP;
-  if (r == -2 || rn < 0) return DDSP_HIP_ESHAPE;
-  // harmonic = all-pass(sinusoids) (vocoder.py:597-600); signal = harmonic + noise (:609)
-  if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
-    return DDSP_HIP_ESHAPE;
-  return finish();
+  const int rc = sins_rows(call, w, st, aux_stream);
+  return rc != 0 ? rc : finish();
 }
 
 int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_gd,
@@ -517,19 +728,26 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   if (!f0_frames || !phase0 || !c_gd || !c_harm || !c_nz || !table_ap || !table_harm || !table_nz || !signal)
     return DDSP_HIP_EINVAL;
   if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return DDSP_HIP_EINVAL;      // as ddsp_hip_sins_synth
-  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1};   // noise == NULL: drawn inside the noise filter (philox.h)
+  const NoiseGen gen{noise_seed, noise_offset, noise ? 0 : 1, 0u};   // noise == NULL: drawn inside the noise filter (philox.h)
   if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   int n_max = n_ap > n_nz ? n_ap : n_nz;
   if (n_harm > n_max) n_max = n_harm;
+  hipStream_t st = S(stream);
+  const long R = (long)B * F;
+  const TapsFormScope form;
+  const TailCall call{f0_frames, initial_phase, phase0, c_gd, ld_gd, c_harm, ld_harm, c_nz, ld_nz, noise, noise_is_u01,
+                      B, F, hop, sr, infer, n_ap, n_harm, n_nz, table_ap, table_harm, table_nz, signal, harmonic_or_null,
+                      noise_out_or_null, fir_impl, gen};
+  const LanePlan plan = lane_plan(B, F);
+  if (plan.nsub > 1) {
+    const int rc = run_lanes(call, plan, ws, ws_bytes, n_max, st, aux_stream, combsub_rows);
+    return rc != 0 ? rc : finish();
+  }
   Carver c(ws, ws_bytes);
   SynthWs w;
   carve_synth(c, B, F, hop, n_max, w);
   if (!c.ok) return DDSP_HIP_EWS;
-  hipStream_t st = S(stream);
-  const long R = (long)B * F;
-  const TapsFormScope form;
   const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
-  float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
   // Streaming shapes (B = 1, a fraction of a second per call: gui.py:118-133): the step's latency is its chain of DEPENDENT
   // launches (~9 us each on the GPU whatever the length), so the same kernels are issued as THREE launches instead of seven:
   // exciter and the three tap syntheses (k_front_small, grid.y) | all-pass filter beside the noise filter (grid.y) | harmonic
@@ -537,6 +755,7 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   // Same kernels, same arguments, same bits as the batch layout below (tests/test_small_shapes.py); knob SMALL_PATH = 1: off.
   if (R < kSmallRows && all256 && hop == 512 && !gen.on && (fir_impl == 0 || fir_impl == 5) && w.taps3 &&
       knob(KNOB_SMALL_PATH) != 1 && knob(KNOB_BLK_WPS) != 2 && knob(KNOB_BLK_PADLDS) == 0) {
+    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
     ExciterJob exc;
     if (make_exciter_job(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
     TapsJobs jobs;
@@ -555,46 +774,8 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
       return DDSP_HIP_ESHAPE;
     return finish();
   }
-  Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
-  // Stream layout (knob STREAM_LAYOUT).  1: the noise branch -- its taps and its filter -- on the second stream beside the
-  // harmonic chain, joined into the last filter as its addend.  4 (default where every filter has 256 bins; otherwise the
-  // all-pass response is staged in the exciter buffer and 1 is used): as 1 with the exciter on the second stream too, ahead
-  // of the noise branch, so the (vector-ALU bound) exciter runs beside the (latency bound) all-pass tap synthesis instead
-  // of after it.  Same-box A/Bs at B = 32 x 10 s, ms per step: 1 / 4 0.401 / 0.388 (profiles/r02_v14_*); three more that
-  // lost (all taps ahead on the second stream, 0.424; the second harmonic filter's taps there too, 0.403; the harmonic
-  // chain's front on the second stream, 0.439 against 0.422) are in DESIGN.md section 7 and no longer in the code.
-  long layout = knob(KNOB_STREAM_LAYOUT);
-  if (layout != 1) layout = 4;
-  if (!all256) layout = 1;
-  int rc = 0;
-  if (layout == 4) {                                       // exciter: combtooth (vocoder.py:839-840)
-    rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, br.aux);
-    br.publish(0);
-  }
-  // noise branch (vocoder.py:854-858)
-  synth_taps(c_nz, ld_nz, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R, n_nz,
-             w.taps_nz, br.aux);
-  const int rn = launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl,
-                            br.aux, &gen);
-  // all-pass taps (vocoder.py:843-846; at other bin counts their response lives in buf0 until the exciter overwrites it)
-  synth_allpass_taps(c_gd, ld_gd, table_ap, R, n_ap, w.re, w.im, w.taps, st);
-  if (layout == 4) br.await(0);
-  else rc = launch_combtooth(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, st);
-  int r1 = 0;
-  if (rc == 0) {
-    r1 = launch_fir(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), fir_impl, st);
-    // harmonic magnitude filter with the f0-dependent window (vocoder.py:847-851); half_width_frames = 1.5 sr / (f0 + 1e-3)
-    // (:851) is formed in the kernel's epilogue
-    synth_taps(c_harm, ld_harm, nullptr, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R, n_harm,
-               w.taps, st, (float)sr);
-  }
-  br.join();                                             // always joined, also on the error paths below
-  if (rc != 0) return DDSP_HIP_EHOP;
-  if (r1 < 0 || rn < 0) return DDSP_HIP_ESHAPE;
-  // signal = harmonic + noise (vocoder.py:860): the second harmonic filter adds the branch's result
-  if (launch_fir(w.buf1, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-    return DDSP_HIP_ESHAPE;
-  return finish();
+  const int rc = combsub_rows(call, w, st, aux_stream);
+  return rc != 0 ? rc : finish();
 }
 
 size_t ddsp_hip_stft_workspace_bytes(int B, int F, int hop) {

@@ -15,13 +15,14 @@ namespace ddsp {
 struct NoiseGen {
   unsigned long long seed, offset;
   int on;
+  unsigned utt0;      // utterance number of the launch's first row (a sub-batch of a larger call draws ITS utterances' numbers)
 };
 
 struct Quad { float u[4]; };
 
 __device__ __forceinline__ Quad philox_uniform4(const NoiseGen& g, unsigned utterance, unsigned block, unsigned lane) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  uint32_t c0 = 128u * block + lane, c1 = utterance, c2 = (uint32_t)g.offset, c3 = (uint32_t)(g.offset >> 32);
+  uint32_t c0 = 128u * block + lane, c1 = utterance + g.utt0, c2 = (uint32_t)g.offset, c3 = (uint32_t)(g.offset >> 32);
   uint32_t k0 = (uint32_t)g.seed, k1 = (uint32_t)(g.seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {

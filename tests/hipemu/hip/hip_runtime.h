@@ -60,6 +60,9 @@ template <class K>                                                              
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }   // chunks per row
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { static int token; *e = &token; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int token; *s = &token; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }

@@ -185,3 +185,37 @@ def test_no_gpu_no_run():
         assert "no CPU fallback" in str(e.value)
     finally:
         os.environ.update(env)
+
+
+def _gate_worker(q):
+    try:
+        bench = _install_emulator()
+        B, F, n = 3, 9, 65
+        step, inp = bench.build_step("combsub", B, F, n, torch.device("cpu"), seed=5)
+        out = step()
+        rec = bench.parity_gate("combsub", inp["f0"], inp["ctrls"], inp["noise"], out)
+        broken = out.clone()
+        broken[-1, 100:] = out[-1, :-100]                # the last utterance shifted by 100 samples: a wrong row offset
+        try:
+            bench.parity_gate("combsub", inp["f0"], inp["ctrls"], inp["noise"], broken)
+            refused = False
+        except SystemExit as e:
+            refused = "NOT the reference's" in str(e)
+        q.put(("ok", rec, refused))
+    except BaseException as e:
+        import traceback
+        q.put(("error", "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()), False))
+
+
+def test_parity_gate_refuses_a_wrong_output():
+    """bench.py prints no timing for an output that is not the reference's: the gate passes the emulated step
+    and raises SystemExit for the same output with its last utterance shifted"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_gate_worker, args=(q,))
+    p.start()
+    status, rec, refused = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", rec
+    assert rec["rows"] == [0, 2] and rec["rms_abs"] <= 1e-4 and rec["rms_rel"] <= 1e-5
+    assert refused

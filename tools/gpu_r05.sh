@@ -1,0 +1,93 @@
+#!/bin/bash
+# Round 5's GPU experiments (same conventions as gpu_r04.sh, whose modes stay available: `bash tools/gpu_r04.sh <mode> ..`):
+#     gpurun -- 'V=r05_v1 bash tools/gpu_r05.sh lanes'
+# modes
+#   lanes        sub-batch lanes (csrc/api.hip): GPU tests, same-box A/B of LANE_ROWS / LANES at B = 32 and 64 (interleaved, 2 reps),
+#                the B sweep {16,32,64,128,256} split / unsplit, a multi-stream timeline of one step, the driver's command
+#   sweep        only the B sweep
+#   default      the driver's command + its kernel trace
+# Every output goes to gpurun_out/${V}_*; copy what is quoted into profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O="$R/gpurun_out"; mkdir -p "$O"; export TMPDIR=/tmp
+export V=${V:-r05}
+MODEL=${MODEL:-combsub}
+BENCH="python bench.py --model $MODEL --no-cpu-baseline --no-module-mode --no-live-traffic --no-also --no-cfg4"
+
+line() {  # line <file>: ms_per_step, events, kernel
+python - "$1" <<'PY'
+import json, sys, os
+f = sys.argv[1]
+try:
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    r = d.get("roofline") or {}
+    print("%-52s ms %.4f events %.4f  %.3e samples/s  kernel_ms %.4f" % (os.path.basename(f), d["ms_per_step"], d.get("ms_per_step_events") or 0,
+          d["value"], r.get("avg_ms") or 0))
+except Exception as e:
+    print(f, "ERR", e, open(f).read()[-400:])
+PY
+}
+
+ab() {  # ab <B> <tag:ENV=VAL,ENV=VAL> ...   interleaved, 2 reps
+  B=$1; shift
+  for rep in 1 2; do
+    for t in "$@"; do
+      name=${t%%:*}; envs=$(echo "${t#*:}" | tr ',' ' ')
+      f="$O/${V}_bench_B${B}_${name}_$rep.json"
+      env $envs timeout 300 $BENCH --batch-per-gpu $B 2>&1 | tail -1 > "$f"
+      line "$f"
+    done
+  done
+}
+
+sweep() {
+  for B in 16 32 64 128 256; do
+    for t in "split:X=1" "unsplit:DDSP_HIP_LANE_ROWS=1"; do
+      name=${t%%:*}; envs=${t#*:}
+      f="$O/${V}_sweep_B${B}_${name}.json"
+      env $envs timeout 300 $BENCH --batch-per-gpu $B --steps 60 2>&1 | tail -1 > "$f"
+      line "$f"
+    done
+  done
+}
+
+gaps() {  # gaps <tag> [env..]: per-launch timeline of steady-state steps, all streams
+  tag=$1; shift
+  ( cd /tmp; rm -rf "$O/gp"
+    env "$@" timeout 300 rocprofv3 --kernel-trace -d "$O/gp" -o g -- python "$R/bench.py" --model $MODEL --only-steps --steps 12 --warmup 3 ${GAPS_ARGS:-} > "$O/${V}_gp.log" 2>&1
+    f=$(find "$O/gp" -name "*.db" | head -1)
+    python "$R/tools/rocpd_gaps.py" "$f" 2>&1 > "$O/${V}_gaps_$tag.txt"
+    python "$R/tools/rocpd_stats.py" "$f" 2>&1 | head -14 > "$O/${V}_${tag}_kernel_stats.csv"
+    rm -rf "$O/gp" )
+  head -60 "$O/${V}_gaps_$tag.txt"; cat "$O/${V}_${tag}_kernel_stats.csv"
+}
+
+mode=${1:-lanes}
+case $mode in
+lanes)
+  timeout 900 python -m pytest tests/test_lanes.py tests/test_small_shapes.py tests/test_noise_rng.py tests/test_fullsize_gpu.py -m gpu -x -q 2>&1 | tail -4 | tee "$O/${V}_pytest_lanes.log"
+  echo "== B = 32"; ab 32 "off:DDSP_HIP_LANE_ROWS=1" "lanes16:X=1" "serial16:DDSP_HIP_LANES=1" "lanes8:DDSP_HIP_LANE_ROWS=7000"
+  echo "== B = 64"; ab 64 "off:DDSP_HIP_LANE_ROWS=1" "lanes16:X=1" "lanes32:DDSP_HIP_LANE_ROWS=28000" "serial16:DDSP_HIP_LANES=1"
+  echo "== sweep"; sweep
+  echo "== timeline, lanes"; gaps lanes X=1 | head -80
+  echo "== timeline, unsplit"; gaps unsplit DDSP_HIP_LANE_ROWS=1 | head -50
+  echo "== the driver's command"
+  ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
+  python - <<'PY'
+import json, os
+V = os.environ["V"]
+d = json.loads(open("gpurun_out/%s_bench_default.json" % V).read())
+print({k: d[k] for k in ("value", "ms_per_step", "ms_per_step_events")})
+print("parity", d.get("parity_vs_oracle"))
+print("roofline", {k: d["roofline"][k] for k in ("kernel", "frac", "avg_ms", "traffic")})
+print("cfg4", d.get("cfg4"))
+print("also", {k: round(v["ms_per_step"], 4) for k, v in d.get("also", {}).items()})
+print("gpu chain", (d.get("cpu_baseline_aten_chain") or {}).get("same_chain_on_gpu"))
+PY
+  ;;
+sweep) sweep ;;
+default)
+  ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
+  line "$O/${V}_bench_default.json"
+  ;;
+*) echo "unknown mode $mode"; exit 2;;
+esac
