@@ -12,6 +12,7 @@ using namespace ddsp;
 
 // ---- tuning knobs (csrc/tuning.h): environment read once, afterwards only ddsp_hip_set_tuning() ----------------------
 namespace ddsp {
+thread_local int t_geometry_batch = 0;
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
@@ -132,24 +133,27 @@ struct Branch {
   }
 };
 
-// ---- Sub-batches and lanes (round 5) ---------------------------------------------------------------------------------
-// Utterances are independent (core.py:120-182 has no op across the batch), so a large call is issued as SUB-BATCHES of
-// ~kLaneRows frames that alternate between two LANES: lane 0 = the caller's stream pair, lane 1 = a pair of streams this
+// ---- Sub-batches and lanes (round 5; OPT-IN: knob LANE_ROWS) -------------------------------------------------------------
+// Utterances are independent (core.py:120-182 has no op across the batch), so a large call CAN be issued as sub-batches of
+// ~LANE_ROWS frames that alternate between two LANES: lane 0 = the caller's stream pair, lane 1 = a pair of streams this
 // library owns (created once per host thread and device, beside the fork / join events).  Each lane has ONE workspace slot
-// that its sub-batches re-use in stream order, so (a) the prefix of sub-batch k+1 (exciter, tap syntheses) runs beside the
-// filters of sub-batch k instead of after them, (b) the scratch of a call is two slots of a sub-batch whatever B is
-// (B = 64 x 10 s: the bytes of B = 32), and the intermediates of a sub-batch (three tap tensors, exciter, two [B,T]
-// signals: 170 MB at 16 utterances) stay inside the 256 MB memory-side cache between their producer and their consumer.
-// The samples are those of the unsplit call bit for bit (tests/test_lanes.py).  Knobs: LANE_ROWS = frames per sub-batch
-// (1: never split), LANES = 1: one lane (sub-batches in sequence on the caller's streams, one slot).
-constexpr long kLaneRows = 14336;
+// that its sub-batches re-use in stream order, so the scratch of a call is two slots of a sub-batch whatever B is (B = 64 x
+// 10 s with LANE_ROWS = 14336: the bytes of B = 32) and the prefix of sub-batch k+1 (exciter, tap syntheses) runs beside the
+// filters of sub-batch k.  The samples are those of the unsplit call bit for bit (tests/test_lanes.py).
+// MEASURED (same box, profiles/r05_v1_*): it LOSES at every batch size -- B = 32: 0.351 ms against 0.317 unsplit (two lanes of
+// 16), 0.371 in sequence on one lane; B = 64: 0.676 (four of 16) / 0.646 (two of 32) against 0.617; B = 256: 2.62 against 2.28.
+// Every kernel of the step already fills the chip, and two of them side by side take as long as one after the other plus the
+// contention (filter launches 135 - 159 us beside each other against 84 alone); what a step pays per launch (ramp, drain,
+// dependency latency) is paid per sub-batch.  Unsplit, the step's rate RISES with B (3.76e10 samples/s at 16 utterances,
+// 4.46e10 at 32, 4.59e10 at 64, 4.95e10 at 256): t = 36 us + 8.77 us per utterance.  So the default is ONE batch; the split
+// stays for callers that must bound the scratch (0.34 GB per 32 utterances of 10 s).
+// Knobs: LANE_ROWS = frames per sub-batch (0 / 1: never split), LANES = 1: one lane (sub-batches in sequence, one slot).
 
 struct LanePlan { int nsub, Bs, slots; };
 
 LanePlan lane_plan(int B, int F) {
   LanePlan p{1, B, 1};
-  long target = knob(KNOB_LANE_ROWS);
-  if (target == 0) target = kLaneRows;
+  const long target = knob(KNOB_LANE_ROWS);
   const long R = (long)B * F;
   if (target <= 1 || B < 2) return p;
   if (2 * R < 3 * target) return p;                       // below one and a half sub-batches: not worth two half-empty lanes
@@ -552,6 +556,7 @@ int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, i
     }
   }
   int rc = 0;
+  t_geometry_batch = a.B;                                // the filters split an utterance into runs as the unsplit call would
   for (int k = 0; k < p.nsub; ++k) {
     const int b0 = k * p.Bs, Bn = a.B - b0 < p.Bs ? a.B - b0 : p.Bs;
     const TailCall sub = rows_of(a, b0, Bn);
@@ -560,6 +565,7 @@ int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, i
     if (r != 0 && rc == 0) rc = r;
     if (rc != 0) break;
   }
+  t_geometry_batch = 0;
   if (lane1) {                                           // always joined, also on the error path
     (void)hipEventRecord(lane1->join, lane1->main1);
     (void)hipStreamWaitEvent(st, lane1->join, 0);

@@ -231,7 +231,10 @@ __device__ __forceinline__ float exp_hw(float x) {
   float r = fmaf(x, l2e_hi, -t);
   r = fmaf(x, l2e_lo, r);
   const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147182f, e);
+  const float v = fmaf(e, r * 0.693147182f, e);
+  // the limits of torch.exp: beyond the finite range e is inf / 0 and the correction term would make inf - inf (x > 88.72) or
+  // take r = -inf + inf at x = -inf; a NaN argument fails both compares and stays NaN
+  return t >= 128.0f ? __builtin_inff() : (t < -150.0f ? 0.0f : v);
 }
 
 // torch.sinc on a float32 tensor: sin(p) / p with p = fl32(pi32 * z), 1 at z == 0 (vocoder.py:839, :649).

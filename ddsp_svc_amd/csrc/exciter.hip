@@ -626,6 +626,60 @@ __global__ void __launch_bounds__(256) k_sins_bank_bwd_combine(const float* __re
   d_c[i] = dA * (a * ((p < nyq ? 1.0f : 0.0f) + 1e-7f));
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same adjoint at every other hop (the forward there is k_sins_bank): one wave per frame, each lane its SPL samples, the
+// sine of every harmonic evaluated as the forward kernel does -- sin(fl32(k phase)), the reference's own rounding
+// (vocoder.py:590) -- and the frame's two sums R0[k], R1[k] formed by a wave reduction per harmonic.  A fallback's speed
+// (H sines per sample, as the forward one); k_sins_bank_bwd_combine finishes it as it does for the hop-512 forms.
+// ------------------------------------------------------------------------------------------------
+template <int SPL>
+__global__ void __launch_bounds__(256) k_sins_bank_bwd_any(const float* __restrict__ f0_frames,
+                                                           const float* __restrict__ initial_phase,
+                                                           const float* __restrict__ grad_out, int F, int hop, int H, int HP,
+                                                           Upsampler up, PhaseCfg cfg, const double* __restrict__ phase0,
+                                                           float* __restrict__ partial /* [B*F][HP][2] */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int groups = (F + 3) / 4;
+  const long b = blockIdx.x / groups;
+  const int f = (int)(blockIdx.x % groups) * 4 + wave;
+  if (f >= F) return;                               // wave-uniform; the kernel has no barrier
+  const long fr = b * F + f;
+  const float ip = cfg.has_ip ? initial_phase[b] : 0.0f;
+  FramePhase<SPL> ph;
+  frame_phase<SPL>(f0_frames + b * F, f, hop, up, cfg, phase0[fr], ip, lane, ph);
+  float phase[SPL], gw0[SPL], gw1[SPL];
+#pragma unroll
+  for (int r = 0; r < SPL; ++r) {
+    const int j = lane * SPL + r;
+    phase[r] = kTwoPiF * ph.x[r];                   // vocoder.py:574
+    gw0[r] = gw1[r] = 0.f;
+    if (j < hop) {
+      const long t = (long)f * hop + j;
+      int i0, i1;
+      float w0, w1;
+      up.locate(t, i0, i1, w0, w1);
+      const float g = grad_out[b * (long)F * hop + t];
+      gw0[r] = g * w0;
+      gw1[r] = g * w1;
+    }
+  }
+  for (int k = 0; k < H; ++k) {
+    const float kf = (float)(k + 1);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < SPL; ++r) {
+      const float sv = sin_turns(phase[r] * kf);
+      a0 = fmaf(sv, gw0[r], a0);
+      a1 = fmaf(sv, gw1[r], a1);
+    }
+    const float r0 = wave_sum_dpp(a0), r1 = wave_sum_dpp(a1);
+    if (lane == 0) {
+      partial[(fr * HP + k) * 2] = r0;
+      partial[(fr * HP + k) * 2 + 1] = r1;
+    }
+  }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 Upsampler make_upsampler_pub(int F, int hop);
 PhaseCfg make_phase_cfg(double sr, int infer, int has_ip);
@@ -701,12 +755,21 @@ size_t sins_bank_bwd_scratch_floats(int B, int F, int H) { return (size_t)B * F 
 int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, const float* c_amp, long ld_amp,
                          const float* grad_out, int B, int F, int hop, int H, double sr, int infer, const double* phase0,
                          float* scratch, float* d_c, hipStream_t st) {
-  if (hop != 512 || (long)B * F > 0x7fffffffL) return -1;
+  const int spl = spl_for_hop(hop);
+  if (!spl || (long)B * F > 0x7fffffffL) return -1;
   if ((long)B * F == 0) return 0;
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   const int HP = (H + 15) & ~15;
-  if (up.shift > 0 && knob(KNOB_SINS_V1) == 0)                  // matrix-pipe form: one wave per frame
+  if (hop != 512) {                                             // every other hop: one wave per frame, direct sines
+    const dim3 grid((unsigned)((long)B * ((F + 3) / 4))), block(256);
+    if (spl == 8)
+      hipLaunchKernelGGL(k_sins_bank_bwd_any<8>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);
+    else if (spl == 16)
+      hipLaunchKernelGGL(k_sins_bank_bwd_any<16>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);
+    else
+      hipLaunchKernelGGL(k_sins_bank_bwd_any<32>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);
+  } else if (up.shift > 0 && knob(KNOB_SINS_V1) == 0)                  // matrix-pipe form: one wave per frame
     hipLaunchKernelGGL(k_sins_bank_bwd_mfma, dim3((unsigned)((long)B * F)), dim3(64), 0, st, f0_frames, initial_phase, grad_out,
                        F, H, HP, up, cfg, phase0, scratch);
   else

@@ -682,12 +682,13 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   // run length: as many workgroups as the chip holds at once (2 waves each), one round, equal work; every run
   // but an utterance's first pays one warm-up block (three transforms; a pair costs four)
   const long slots = (long)wps * 2 * 256;
-  long per_utt = slots / (B > 0 ? B : 1);
+  const int Bg = t_geometry_batch > 0 ? t_geometry_batch : B;          // kernels.h: a sub-batch keeps the whole call's split
+  long per_utt = slots / (Bg > 0 ? Bg : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   // at least three pairs per workgroup (each pays a warm-up block and its twiddles) -- except at streaming shapes, where every
   // workgroup is resident at once anyway and the launch is as long as its longest workgroup: one pair each
-  if (run < 3 && (long)B * F >= kSmallRows) run = 3;
+  if (run < 3 && (long)Bg * F >= kSmallRows) run = 3;
   if (const long v = knob(KNOB_BLK_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;

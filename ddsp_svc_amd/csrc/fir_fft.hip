@@ -216,7 +216,8 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
   // run length (own pairs per workgroup): as many workgroups as the chip holds at once (4 per CU at this
   // kernel's LDS budget), so all of them run in one round with equal work; every run pays one warm-up pair
   const long slots = (long_taps ? 3 : 4) * 256;
-  long per_utt = slots / (B > 0 ? B : 1);
+  const int Bg = t_geometry_batch > 0 ? t_geometry_batch : B;          // kernels.h: a sub-batch keeps the whole call's split
+  long per_utt = slots / (Bg > 0 ? Bg : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   if (run < 3) run = 3;

@@ -6,6 +6,11 @@
 #include "tuning.h"
 
 namespace ddsp {
+// Batch size the filters choose their run length from.  A run's first tap spectrum comes out of a differently packed transform,
+// so the LAST BITS of a filter's output depend on how an utterance's block pairs are split into runs, and that split follows B
+// (one round of resident workgroups).  A sub-batch of a split call (api.hip, lanes) sets this to the WHOLE call's B, so that
+// its samples are those of the unsplit call bit for bit; 0 = the launch's own B.
+extern thread_local int t_geometry_batch;
 int spl_for_hop(int hop);
 void launch_upsample(const float* sig, int B, int F, int C, int hop, float* out, hipStream_t st);
 void launch_remove_above_fmax(const float* amps, const float* pitch, long rows, int H, float fmax, int level_start,

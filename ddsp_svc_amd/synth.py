@@ -175,7 +175,8 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
 
 
 class SinusoidBankFunction(torch.autograd.Function):
-    """``sinusoid_bank`` with the gradient back to the raw ``amplitudes`` control (hop 512)."""
+    """``sinusoid_bank`` with the gradient back to the raw ``amplitudes`` control (every hop the forward takes: the
+    matrix-pipe adjoint at hop 512, one wave per frame with direct sines elsewhere)."""
 
     @staticmethod
     def forward(ctx, f0_frames, state, amplitudes_ctrl, sampling_rate, block_size):

@@ -202,7 +202,8 @@ int ddsp_hip_sinusoid_bank(const float* f0_frames, const float* initial_phase, c
                            float* out, void* stream);
 
 /* Adjoint of ddsp_hip_sinusoid_bank w.r.t. the raw amplitude control: grad_out[B,T] -> d_c_amp[B,F,H]
- * (contiguous).  scratch: ddsp_hip_sinusoid_bank_backward_scratch_bytes(B, F, H) bytes.  Supported: hop 512. */
+ * (contiguous).  scratch: ddsp_hip_sinusoid_bank_backward_scratch_bytes(B, F, H) bytes.  Every hop <= 2048 (hop 512: the
+ * matrix-pipe form; other hops: one wave per frame, direct sines, as the forward bank there). */
 size_t ddsp_hip_sinusoid_bank_backward_scratch_bytes(int B, int F, int H);
 int ddsp_hip_sinusoid_bank_backward(const float* f0_frames, const float* initial_phase, const double* phase0,
                                     const float* c_amp, long ld_amp, const float* grad_out, int B, int F, int hop,

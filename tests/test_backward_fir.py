@@ -344,3 +344,52 @@ def test_combsub_module_training_step_matches_reference(dev, kind):
         checked += 1
     print("training step %s on %s: %d parameter gradients, worst relative rms error %.2e" % (kind, dev, checked, worst))
     assert checked > 10
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("hop,H,F", [(256, 40, 5), (128, 17, 4), (1000, 33, 2), (2048, 8, 2)])
+def test_sinusoid_bank_backward_other_hops(dev, hop, H, F):
+    """the adjoint of the sinusoid bank at block sizes other than 512 (train.py with a config whose block_size is not 512:
+    the reference back-propagates through vocoder.py:585-594 at any block size): k_sins_bank_bwd_any against the oracle"""
+    from ddsp_svc_amd import synth
+    B = 2
+    f0 = O.synth_f0(B, F, 44100, hop, seed=3 + H)
+    f0[0] *= 2.5
+    f0 = np.clip(f0, 65, 800).astype(np.float32)
+    (c_amp,) = O.synth_controls(B, F, [H], seed=6)
+    R = np.random.default_rng(hop).standard_normal((B, F * hop)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = synth.phase(t(f0), 44100, hop)
+    c = t(c_amp).requires_grad_(True)
+    out = synth.SinusoidBankFunction.apply(t(f0), st, c, 44100, hop)
+    (out * t(R)).sum().backward()
+    x, _ = O.wrapped_phase(f0, 44100, hop)
+    want = O.sinusoid_bank_backward(R, x, f0, c_amp, 44100, hop)
+    assert rms(c.grad.cpu().numpy() - want) <= 1e-5 * rms(want), (rms(c.grad.cpu().numpy() - want), rms(want))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_sins_trains_at_hop_256(dev):
+    """a patched Sins at block size 256 must train where the reference trains -- every control gets a gradient, equal to
+    float64 autograd through the reference's op chain (oracle/aten_chain.py) on the same inputs"""
+    from ddsp_svc_amd import synth
+    from oracle import aten_chain as A
+    hop, B, F, H, n = 256, 2, 6, 24, 65
+    f0 = O.synth_f0(B, F, 44100, hop, seed=8)
+    ca, cg, cn = O.synth_controls(B, F, [H, n, n], seed=9)
+    u = np.random.default_rng(10).random((B, F * hop), dtype=np.float32)
+    R = np.random.default_rng(11).standard_normal((B, F * hop)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctrls = [t(a).requires_grad_(True) for a in (ca, cg, cn)]
+    st = synth.phase(t(f0), 44100, hop)
+    sig = synth.sins_synth(t(f0), st, *ctrls, t(u), 44100, hop, noise_is_u01=True)[0]
+    assert sig.requires_grad
+    (sig * t(R)).sum().backward()
+    ref_c = [torch.from_numpy(a).double().requires_grad_(True) for a in (ca, cg, cn)]
+    nz = torch.from_numpy(u).double() * 2 - 1
+    ref = A.sins_tail(torch.from_numpy(f0).double(), *ref_c, nz, 44100, hop, True)[0]
+    assert rms(sig.detach().cpu().numpy() - ref.detach().numpy()) <= 1e-5 * rms(ref.detach().numpy())
+    (ref * torch.from_numpy(R).double()).sum().backward()
+    for got, want, name in zip(ctrls, ref_c, ("amplitudes", "group_delay", "noise_magnitude")):
+        e, w = rms(got.grad.cpu().numpy() - want.grad.numpy()), rms(want.grad.numpy())
+        assert e <= 3e-5 * w, (name, e, w)

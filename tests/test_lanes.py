@@ -1,5 +1,6 @@
-"""Sub-batches and lanes (csrc/api.hip, round 5).  Utterances are independent (core.py:120-182 has no op across the batch), so
-a large CombSub / Sins tail is issued as sub-batches of ~LANE_ROWS frames alternating between two lanes (the caller's stream
+"""Sub-batches and lanes (csrc/api.hip, round 5; opt-in through knob LANE_ROWS -- measured slower than one batch at every size, kept
+for callers that must bound the scratch).  Utterances are independent (core.py:120-182 has no op across the batch), so
+a large CombSub / Sins tail can be issued as sub-batches of ~LANE_ROWS frames alternating between two lanes (the caller's stream
 pair and a pair the library owns), each lane re-using ONE workspace slot.  The samples must be those of the unsplit call BIT
 FOR BIT -- every split (even, ragged, one utterance per sub-batch), every output (signal, harmonic, noise), supplied noise and
 the in-kernel draw (whose counter carries the utterance number), with and without the second lane -- and the scratch of a
@@ -121,7 +122,9 @@ def test_workspace_is_two_slots_of_a_sub_batch(knobs):
     try:
         lib.ddsp_hip_set_tuning(b"LANE_ROWS", 1)
         unsplit = {B: lib.ddsp_hip_synth_workspace_bytes(B, F, HOP, 256) for B in (16, 32, 64)}
-        lib.ddsp_hip_set_tuning(b"LANE_ROWS", 0)
+        lib.ddsp_hip_set_tuning(b"LANE_ROWS", 0)                         # the default: never split
+        assert lib.ddsp_hip_synth_workspace_bytes(64, F, HOP, 256) == unsplit[64]
+        lib.ddsp_hip_set_tuning(b"LANE_ROWS", 14336)
         ws = {B: lib.ddsp_hip_synth_workspace_bytes(B, F, HOP, 256) for B in (8, 16, 32, 48, 64, 256)}
     finally:
         lib.ddsp_hip_set_tuning(b"LANE_ROWS", 0)
@@ -132,7 +135,7 @@ def test_workspace_is_two_slots_of_a_sub_batch(knobs):
 
 @pytest.mark.gpu
 def test_full_size_split_same_bits_gpu(knobs):
-    """BASELINE cfg 2 / cfg 4 shapes on the MI355X: default lanes against the unsplit call, bit for bit, twice (a race between
+    """BASELINE cfg 2 / cfg 4 shapes on the MI355X: lanes of ~16 utterances against the unsplit call, bit for bit, twice (a race between
     the lanes' workspace slots would show as a difference between repeats)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -141,7 +144,7 @@ def test_full_size_split_same_bits_gpu(knobs):
         _, tensors = _combsub_inputs(B, 862, dev, seed=B)
         knobs("LANE_ROWS", 1)
         whole = _combsub(tensors)
-        knobs("LANE_ROWS", 0)
+        knobs("LANE_ROWS", 14336)
         for _ in range(3):
             split = _combsub(tensors)
             for a, b in zip(whole, split):
