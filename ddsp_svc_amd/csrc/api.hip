@@ -760,7 +760,11 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   // filter + noise.
   // Same kernels, same arguments, same bits as the batch layout below (tests/test_small_shapes.py); knob SMALL_PATH = 1: off.
   if (R < kSmallRows && all256 && hop == 512 && !gen.on && (fir_impl == 0 || fir_impl == 5) && w.taps3 &&
-      knob(KNOB_SMALL_PATH) != 1 && knob(KNOB_BLK_WPS) != 2 && knob(KNOB_BLK_PADLDS) == 0) {
+      knob(KNOB_SMALL_PATH) != 1
+#ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: the same
+      && (knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0        //  predicate as launch_fir_blk's)
+#endif
+      ) {
     float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
     ExciterJob exc;
     if (make_exciter_job(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;

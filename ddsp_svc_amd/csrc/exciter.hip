@@ -153,6 +153,7 @@ __device__ __forceinline__ f32x2 lerp_pair(f32x2 lam, f32x2 ad) {
 #endif
 }
 
+#ifdef DDSP_AB_GENERATIONS                       // round 1 / 2's 16-harmonic blocks: A/B builds only (tools/build_variant.sh)
 __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0_frames,
                                                     const float* __restrict__ initial_phase,
                                                     const float* __restrict__ c_amp, long ld_amp, int F, int H,
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(256) k_sins_bank2(const float* __restrict__ f0
   if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
   else { dst[0] = r[0]; dst[1] = r[1]; }
 }
+#endif  // DDSP_AB_GENERATIONS
 
 // ------------------------------------------------------------------------------------------------
 // sinusoid bank, mirrored-pair form (hop = 512; the default): blocks of 17 harmonics AROUND a centre c,
@@ -417,6 +419,7 @@ __global__ void __launch_bounds__(256) k_sins_bank3(const float* __restrict__ f0
 // two chunks of a wave meet by one cross-lane exchange, the four waves through a second small LDS array.
 // k_sins_bank_bwd_combine then forms dc[f][k] = A[f][k] (R0[f][k] + R1[f-1][k] (+ R1[F-1][k] on the last row)).
 // ------------------------------------------------------------------------------------------------
+#ifdef DDSP_AB_GENERATIONS                       // the LDS-tile adjoint the matrix-pipe form replaced: A/B builds only
 constexpr int SB_TILE_LD = 257;
 
 __global__ void __launch_bounds__(256) k_sins_bank2_bwd(const float* __restrict__ f0_frames,
@@ -512,6 +515,7 @@ __global__ void __launch_bounds__(256) k_sins_bank2_bwd(const float* __restrict_
     // the next block's tile writes come after this barrier pair; part[] is rewritten only after the next first barrier
   }
 }
+#endif  // DDSP_AB_GENERATIONS
 
 // ------------------------------------------------------------------------------------------------
 // The same adjoint on the matrix pipe (hop = 512; the default).  R_r[k] = sum_t g[t] w_r[t] sin(k theta_t) is a reduction
@@ -724,12 +728,14 @@ int launch_sins_bank(const float* f0_frames, const float* initial_phase, const f
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   if (hop == 512 && up.shift > 0 && (long)B * F <= 0x7fffffffL && knob(KNOB_SINS_V1) != 1) {
     // block angle-addition forms: one workgroup per frame
-    if (knob(KNOB_SINS_V1) == 2) {                  // the 16-harmonic blocks of round 1 / 2 (tests, same-box A/B)
+#ifdef DDSP_AB_GENERATIONS
+    if (knob(KNOB_SINS_V1) == 2) {                  // the 16-harmonic blocks of round 1 / 2 (same-box A/B builds)
       const size_t sh2 = (size_t)2 * ((H + 15) & ~15) * sizeof(float);
       hipLaunchKernelGGL(k_sins_bank2, dim3((unsigned)((long)B * F)), dim3(256), sh2, st, f0_frames, initial_phase, c_amp,
                          ld_amp, F, H, up, cfg, phase0, out);
       return 0;
     }
+#endif
     // mirrored pairs around a centre, 17 harmonics per block; a remainder of one or two harmonics is evaluated on its own
     const int rem = H % SB3_W;
     const int nblk = H / SB3_W + (rem > 2 ? 1 : 0), nsingle = rem > 2 ? 0 : rem;
@@ -769,12 +775,15 @@ int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, con
       hipLaunchKernelGGL(k_sins_bank_bwd_any<16>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);
     else
       hipLaunchKernelGGL(k_sins_bank_bwd_any<32>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);
-  } else if (up.shift > 0 && knob(KNOB_SINS_V1) == 0)                  // matrix-pipe form: one wave per frame
-    hipLaunchKernelGGL(k_sins_bank_bwd_mfma, dim3((unsigned)((long)B * F)), dim3(64), 0, st, f0_frames, initial_phase, grad_out,
-                       F, H, HP, up, cfg, phase0, scratch);
-  else
+  }
+#ifdef DDSP_AB_GENERATIONS
+  else if (knob(KNOB_SINS_V1) != 0)
     hipLaunchKernelGGL(k_sins_bank2_bwd, dim3((unsigned)((long)B * F)), dim3(256), 0, st, f0_frames, initial_phase, grad_out, F,
                        H, up, cfg, phase0, scratch);
+#endif
+  else                                                          // hop 512 (a power of two): the matrix-pipe form, one wave per frame
+    hipLaunchKernelGGL(k_sins_bank_bwd_mfma, dim3((unsigned)((long)B * F)), dim3(64), 0, st, f0_frames, initial_phase, grad_out,
+                       F, H, HP, up, cfg, phase0, scratch);
   hipLaunchKernelGGL(k_sins_bank_bwd_combine, dim3((unsigned)((long)B * F), (unsigned)((H + 255) / 256)), dim3(256), 0, st, f0_frames,
                      c_amp, ld_amp, scratch, F, H, HP, (float)sr / 2.0f, d_c);
   return 0;

@@ -60,6 +60,9 @@ struct FirBlkGeom {
   int turns;              // waves sharing a SIMD alternate priority (knob BLK_TURNS: 1 = off)
 };
 
+// (round 3's two-wave kernel: compiled only into the A/B builds of tools/build_variant.sh, -DDDSP_AB_GENERATIONS; the product ships
+// ONE generation per kernel)
+#ifdef DDSP_AB_GENERATIONS
 // RNG: the input is not read but drawn in the load path (philox.h; the uniform draw of the noise branch, mapped to 2u-1)
 // An addend added to the stored result and a second, plain output (the options of a step's last filter) are run-time,
 // workgroup-uniform switches: ONE code object serves every filter of a step, so that it stays in the instruction cache
@@ -354,6 +357,7 @@ __global__ void __launch_bounds__(128, WPS) k_fir_blk(const float* __restrict__ 
     BLK_STAMP(3 + q - q_first);
   }
 }
+#endif  // DDSP_AB_GENERATIONS
 
 // ---- the same operator at three waves per SIMD (six workgroups per CU) ---------------------------------------------------
 // k_fir_blk above holds 226 registers and 32 KB of LDS per workgroup: four workgroups per CU, two waves per SIMD, and at two
@@ -678,7 +682,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   // three waves per SIMD (k_fir_blk6, six workgroups per CU) unless knob BLK_WPS = 2 asks for the two-wave kernel
   // (k_fir_blk, four per CU: the round-3 form, kept for same-box A/B runs)
   int wps = 3;
+#ifdef DDSP_AB_GENERATIONS
   if (const long v = knob(KNOB_BLK_WPS)) { if (v >= 1) wps = (int)v; }
+#endif
   // run length: as many workgroups as the chip holds at once (2 waves each), one round, equal work; every run
   // but an utterance's first pays one warm-up block (three transforms; a pair costs four)
   const long slots = (long)wps * 2 * 256;
@@ -704,8 +710,13 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
     if (second) return -1;
     rng = *noise_gen;
     jobs.j[0].x_is_u01 = 0;
-    if (wps >= 3) hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
-    else hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+#ifdef DDSP_AB_GENERATIONS
+    if (wps < 3) {
+      hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
+      return 5;
+    }
+#endif
+    hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
     return 5;
   }
   if (second && wps >= 3) {                                     // two independent filters of this shape in one launch
@@ -714,12 +725,15 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
     return 5;
   }
   if (second) return -1;
+#ifdef DDSP_AB_GENERATIONS
   size_t pad = 0;                                               // occupancy probe: extra dynamic LDS per workgroup
   if (const long v = knob(KNOB_BLK_PADLDS)) { if (v > 0) pad = (size_t)v; }
-  if (wps >= 3 && pad == 0)
-    hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
-  else
+  if (wps < 3 || pad != 0) {
     hipLaunchKernelGGL((k_fir_blk<2, false>), dim3((unsigned)wgs), dim3(128), pad, st, x, x_is_u01, taps, addend, out, out_plain, g, rng);
+    return 5;
+  }
+#endif
+  hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
   return 5;
 }
 

@@ -209,7 +209,11 @@ __global__ void __launch_bounds__(fft::THREADS, LONG ? 3 : 4) k_fir_fft(const fl
 int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st) {
   if (hop != FF_HOP || N < 2 || (N & 1) || N > 1022 || (long)F * hop >= (1L << 30)) return -1;
-  const bool long_taps = N > 512;
+#ifdef DDSP_AB_GENERATIONS
+  const bool long_taps = N > 512;                 // A/B builds keep round 2's short form (two taps per thread, 2048-sample ring)
+#else
+  const bool long_taps = true;                    // ONE form: four taps per thread, 4096-sample ring -- every N up to 1022
+#endif
   FirFftGeom g;
   g.F = F; g.N = N; g.T = F * hop;
   g.pairs = (F + 2) / 2;
@@ -227,10 +231,13 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
   g.runs_per_utt = (g.pairs + run - 1) / run;
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
-  if (long_taps)
-    hipLaunchKernelGGL(k_fir_fft<true>, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
-  else
+#ifdef DDSP_AB_GENERATIONS
+  if (!long_taps) {
     hipLaunchKernelGGL(k_fir_fft<false>, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
+    return 4;
+  }
+#endif
+  hipLaunchKernelGGL(k_fir_fft<true>, dim3((unsigned)wgs), dim3(fft::THREADS), 0, st, x, x_is_u01, taps, addend, out, out_plain, g);
   return 4;
 }
 

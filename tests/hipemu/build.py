@@ -28,8 +28,19 @@ def build(force=False, sanitize=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
            [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
             os.path.join(ROOT, "include", "ddsp_hip.h")]
-    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+    fresh = lambda: os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps)
+    if not force and fresh():
         return lib
+    # one builder at a time (pytest-xdist workers all arrive here after a source change): the others wait, then find it fresh
+    import fcntl
+    with open(os.path.join(out, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return lib
+        return _build_locked(out, lib, extra, sanitize)
+
+
+def _build_locked(out, lib, extra, sanitize):
     flags = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC,
              "-Wno-unknown-attributes", "-Wno-unused-function", *extra]
     if sanitize:
