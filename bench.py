@@ -72,6 +72,9 @@ class _HipRuntime:
     def event(self):
         return torch.cuda.Event(enable_timing=True)
 
+    def empty_cache(self):
+        torch.cuda.empty_cache()
+
     def init_process_group(self, rank, world, device):
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -394,8 +397,10 @@ def cfg4_line(a, rank, world, device, F, n, comm):
     from ddsp_svc_amd import sharding
     B4 = a.cfg4_batch
     T = F * HOP
+    if not a.cfg4_keep_cache and hasattr(RT, "empty_cache"):
+        RT.empty_cache()                 # the headline's cached blocks go back to the driver: this line's buffers get fresh segments
     step, _ = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
-    per = max(2, min(10, a.steps))
+    per = max(2, min(a.cfg4_round_steps, a.steps))
     rounds = 6 if a.steps >= 20 else 2
     if not dist.is_initialized() and world == 1 and not a.no_cfg4_gather:
         # the default N = 1 command times the gather too: a 1-rank communicator, the same call path (a failure to open it
@@ -1380,6 +1385,8 @@ def main(argv=None):
     ap.add_argument("--cfg4", action="store_true",
                     help="also run BASELINE cfg 4's per-GPU shape (64 utterances per GPU) -- default at --gpus 8")
     ap.add_argument("--cfg4-batch", type=int, default=64, help="utterances per GPU of the cfg-4 line (BASELINE: 64)")
+    ap.add_argument("--cfg4-round-steps", type=int, default=10, help="steps per interleaved round of the cfg-4 line")
+    ap.add_argument("--cfg4-keep-cache", action="store_true", help="(A/B) do not release the allocator's cached blocks before the cfg-4 line")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg-4 line (part of the default N = 1 and N = 8 runs)")
     ap.add_argument("--no-cfg4-gather", action="store_true", help="cfg-4 line without opening a 1-rank communicator at N = 1")
     ap.add_argument("--no-parity-gate", action="store_true",

@@ -293,11 +293,14 @@ def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, nois
         noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), f0, B * F, defer_join=True)                     # :855-858
     if _EARLY_JOIN:
         join()
-    comb = combtooth(f0_frames, state, sampling_rate, block_size)                             # vocoder.py:839-840
-    h1 = fft_convolve(comb, AllpassTapsFunction.apply(group_delay))                           # :843-846
-    hw = (1.5 * float(sampling_rate)) / (f0 + 1e-3)                                           # :851
-    taps_h = MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw)      # :847-851
-    join()                                                                                    # the noise branch meets the chain here
+    try:
+        comb = combtooth(f0_frames, state, sampling_rate, block_size)                         # vocoder.py:839-840
+        h1 = fft_convolve(comb, AllpassTapsFunction.apply(group_delay))                       # :843-846
+        hw = (1.5 * float(sampling_rate)) / (f0 + 1e-3)                                       # :851
+        taps_h = MagnitudeTapsFunction.apply(harmonic_magnitude, 1.0, _ffi.MODE_DYNAMIC, hw)  # :847-851
+    finally:
+        join()                        # the noise branch meets the chain here -- also when a launch above raised: the branch still
+                                      # reads the noise and the controls, and the caller's stream must stay ordered behind it
     signal, harmonic = fft_convolve_add(h1, taps_h, noise_f)                                  # :860: the sum rides in the filter
     return signal, harmonic, noise_f
 
@@ -314,9 +317,11 @@ def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude
         noise_magnitude, 1.0 / 128.0, _ffi.MODE_HANN, None)), nz, B * group_delay.shape[1], defer_join=True)       # :604-607
     if _EARLY_JOIN:
         join()
-    sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)       # vocoder.py:585-594
-    taps_ap = AllpassTapsFunction.apply(group_delay)
-    join()
+    try:
+        sinus = SinusoidBankFunction.apply(f0_frames, state, amplitudes, sampling_rate, block_size)   # vocoder.py:585-594
+        taps_ap = AllpassTapsFunction.apply(group_delay)
+    finally:
+        join()                                                   # always: see _combsub_synth_train
     signal, harmonic = fft_convolve_add(sinus, taps_ap, noise_f)                                      # :597-600, :609
     return signal, harmonic, noise_f
 
@@ -380,10 +385,33 @@ class StreamingCombSub:
         self._tables = tuple(ir_table(n, dev) for n in self.n)
         self._lib = _ffi.lib()
         _ffi.check_device(self.signal)
+        self._dev = self.signal.device
+        # the buffers are ordered on the stream the session was made on: a call from another stream would race with them
+        self._stream = _ffi.stream_of(self.signal)
+
+    def _check(self, t, shape, what):
+        """one cheap look per argument and call: a wrong shape / dtype / device / stride handed to the C ABI as a raw pointer is a
+        silent out-of-bounds read on the GPU, not an exception"""
+        if t.device != self._dev or t.dtype != torch.float32 or tuple(t.shape) != shape or t.stride(-1) != 1:
+            raise ValueError("StreamingCombSub: %s must be a float32 %s tensor on %s with a contiguous last dimension (got %s %s on %s, "
+                             "strides %s)" % (what, shape, self._dev, t.dtype, tuple(t.shape), t.device, tuple(t.stride())))
+
+    def _check_ctrl(self, t, n, what):
+        self._check(t, (self.B, self.F, n), what)
+        if t.stride(1) < n or (self.B > 1 and t.stride(0) != self.F * t.stride(1)):
+            raise ValueError("StreamingCombSub: %s needs one uniform frame stride >= %d (a torch.split view is fine)" % (what, n))
+
+    def _check_stream(self, t):
+        if _ffi.stream_of(t) != self._stream:
+            raise RuntimeError("StreamingCombSub: called on a stream other than the one the session was created on")
 
     def phase(self, f0_frames):
         """``synth.phase`` into the session's state (what ``Unit2Control`` needs is ``.phase_frames``)"""
+        if f0_frames.numel() != self.B * self.F or not f0_frames.is_contiguous():
+            raise ValueError("StreamingCombSub: f0_frames must be a contiguous [%d, %d(, 1)] tensor" % (self.B, self.F))
         f0 = f0_frames.reshape(self.B, self.F)
+        self._check(f0, (self.B, self.F), "f0_frames")
+        self._check_stream(f0)
         st = self.state
         _ffi.check(self._lib.ddsp_hip_phase(f0.data_ptr(), None, self.B, self.F, self.hop, self.sr, int(self.infer),
                                             self._sums.data_ptr(), st.phase0.data_ptr(), st.phase_frames.data_ptr(), None,
@@ -392,7 +420,16 @@ class StreamingCombSub:
 
     def synth(self, f0_frames, group_delay, harmonic_magnitude, noise_magnitude, noise, noise_is_u01=False):
         """``combsub_synth`` on the session's state and buffers -> ``signal`` (and the components, if asked for)"""
+        if f0_frames.numel() != self.B * self.F or not f0_frames.is_contiguous():
+            raise ValueError("StreamingCombSub: f0_frames must be a contiguous [%d, %d(, 1)] tensor" % (self.B, self.F))
         f0 = f0_frames.reshape(self.B, self.F)
+        self._check(f0, (self.B, self.F), "f0_frames")
+        self._check_ctrl(group_delay, self.n[0], "group_delay")
+        self._check_ctrl(harmonic_magnitude, self.n[1], "harmonic_magnitude")
+        self._check_ctrl(noise_magnitude, self.n[2], "noise_magnitude")
+        self._check(noise.reshape(self.B, -1) if noise.numel() == self.B * self.F * self.hop and noise.is_contiguous() else noise,
+                    (self.B, self.F * self.hop), "noise")
+        self._check_stream(f0)
         t = self._tables
         _ffi.check(self._lib.ddsp_hip_combsub_synth(
             f0.data_ptr(), None, self.state.phase0.data_ptr(), group_delay.data_ptr(), group_delay.stride(1),

@@ -192,58 +192,79 @@ def _tensors(args, kwargs):
             yield v
 
 
+def _rebind_everywhere(mapping, skip=()):
+    """Every module that bound one of ``mapping``'s keys by name (``from ddsp.core import upsample`` in flask_api.py:12,
+    gui_diff.py:10, main_reflow.py:13, ...; ``from ddsp.vocoder import CombSubFast`` in diffusion/vocoder.py:13) gets the value
+    instead -- found by IDENTITY over ``sys.modules``, so no list of importers has to be kept up to date.  Attributes whose name
+    starts with ``_reference_`` (where the originals are parked) and the modules in ``skip`` are left alone.  Returns the
+    bindings it changed as ``(module, name, old value, new value)`` -- ``unpatch_reference`` undoes exactly those."""
+    import sys
+    ids = {id(k): v for k, v in mapping.items()}
+    changed = []
+    for mod in list(sys.modules.values()):
+        if mod is None or mod in skip:
+            continue
+        try:
+            items = list(vars(mod).items())
+        except TypeError:                                # a module-like object without a __dict__
+            continue
+        for name, val in items:
+            new = ids.get(id(val))
+            if new is not None and not name.startswith("_reference_"):
+                try:
+                    setattr(mod, name, new)
+                    changed.append((mod, name, val, new))
+                except Exception:                        # noqa: BLE001  (read-only module objects)
+                    pass
+    return changed
+
+
+_REBOUND = []                                            # what patch_reference() rebound outside ddsp.core / ddsp.vocoder
+
+
 def patch_reference():
     """Swap these classes (and the ddsp.core functions on the path) into an already-importable
     reference checkout so ``ddsp.vocoder.load_model``, ``main.py``, ``main_diff.py`` ... pick them up
-    without edits.  The cascades bind ``CombSubFast`` / ``CombSubSuperFast`` by name when they are imported
-    (diffusion/vocoder.py:13, reflow/vocoder.py:12), so either call this first or rely on the rebinding of
-    the already-imported modules done here.
+    without edits.  Modules that bound the names at import time (``from ddsp.core import upsample``: flask_api.py:12,
+    flask_api_diff.py:12, gui_diff.py:10, gui_reflow.py:8, main_reflow.py:13, ...; the cascades' ``CombSubFast`` /
+    ``CombSubSuperFast``: diffusion/vocoder.py:13, reflow/vocoder.py:12) are rebound wherever they are in ``sys.modules``,
+    by identity of the original object, so the call may come before or after those imports.
 
     Dispatch rule of the patched ``ddsp.core`` functions: GPU tensors go to the HIP kernels (all of them are
     differentiable where the reference's are -- ``upsample`` / ``remove_above_fmax`` through small autograd functions,
     the filters through the adjoint kernels); anything else -- host tensors, dtypes other than float32 / complex64 --
     keeps the reference's own code.  The module classes route host tensors to the reference's ``forward``."""
-    import sys
-
     import ddsp.core as rcore
     import ddsp.vocoder as rvoc
     from . import core as hcore
     mine = {"Sins": Sins, "CombSub": CombSub, "CombSubFast": CombSubFast, "CombSubSuperFast": CombSubSuperFast}
+    swapped = {}
     for name, cls in mine.items():
         if not hasattr(rvoc, "_reference_" + name):
             setattr(rvoc, "_reference_" + name, getattr(rvoc, name))
         cls._reference_cls = getattr(rvoc, "_reference_" + name)
         setattr(rvoc, name, cls)
-    for modname in ("diffusion.vocoder", "reflow.vocoder", "train"):
-        mod = sys.modules.get(modname)
-        if mod is not None:
-            for name, cls in mine.items():
-                if hasattr(mod, name):
-                    setattr(mod, name, cls)
+        swapped[cls._reference_cls] = cls
     for name in PATCHED_CORE_FUNCTIONS:
-        if hasattr(rcore, "_reference_" + name) or not hasattr(rcore, name):
-            continue                                     # already patched
-        setattr(rcore, "_reference_" + name, getattr(rcore, name))
+        if not hasattr(rcore, name):
+            continue
+        if not hasattr(rcore, "_reference_" + name):
+            setattr(rcore, "_reference_" + name, getattr(rcore, name))
 
-        def dispatch(*a, __h=getattr(hcore, name), __r=getattr(rcore, name), **k):
-            ts = list(_tensors(a, k))
-            on_gpu = bool(ts) and all(t.is_cuda for t in ts)
-            plain = all(t.dtype in (torch.float32, torch.complex64) for t in ts)
-            return __h(*a, **k) if on_gpu and plain else __r(*a, **k)
-        dispatch.__name__ = name
-        setattr(rcore, name, dispatch)
-    for name in PATCHED_CORE_FUNCTIONS:                  # names the importing modules bound at import time (vocoder.py:16, ...)
-        for modname in ("ddsp.vocoder", "ddsp.loss", "main", "main_diff", "batch_infer", "gui"):
-            mod = sys.modules.get(modname)
-            if mod is not None and hasattr(mod, name) and hasattr(rcore, name):
-                setattr(mod, name, getattr(rcore, name))
+            def dispatch(*a, __h=getattr(hcore, name), __r=getattr(rcore, name), **k):
+                ts = list(_tensors(a, k))
+                on_gpu = bool(ts) and all(t.is_cuda for t in ts)
+                plain = all(t.dtype in (torch.float32, torch.complex64) for t in ts)
+                return __h(*a, **k) if on_gpu and plain else __r(*a, **k)
+            dispatch.__name__ = name
+            setattr(rcore, name, dispatch)
+        swapped[getattr(rcore, "_reference_" + name)] = getattr(rcore, name)
+    _REBOUND.extend(_rebind_everywhere(swapped))
     return rvoc
 
 
 def unpatch_reference():
     """Undo ``patch_reference()``: the reference's own classes and functions are bound again everywhere."""
-    import sys
-
     import ddsp.core as rcore
     import ddsp.vocoder as rvoc
     for name, cls in (("Sins", Sins), ("CombSub", CombSub), ("CombSubFast", CombSubFast), ("CombSubSuperFast", CombSubSuperFast)):
@@ -251,20 +272,15 @@ def unpatch_reference():
         if ref is None:
             continue
         setattr(rvoc, name, ref)
-        for modname in ("diffusion.vocoder", "reflow.vocoder", "train"):
-            mod = sys.modules.get(modname)
-            if mod is not None and getattr(mod, name, None) is cls:
-                setattr(mod, name, ref)
         delattr(rvoc, "_reference_" + name)
         cls._reference_cls = None
     for name in PATCHED_CORE_FUNCTIONS:
         ref = getattr(rcore, "_reference_" + name, None)
         if ref is None:
             continue
-        patched = getattr(rcore, name)
         setattr(rcore, name, ref)
         delattr(rcore, "_reference_" + name)
-        for modname in ("ddsp.vocoder", "ddsp.loss", "main", "main_diff", "batch_infer", "gui"):
-            mod = sys.modules.get(modname)
-            if mod is not None and getattr(mod, name, None) is patched:
-                setattr(mod, name, ref)
+    while _REBOUND:                                      # exactly the bindings patch_reference() changed, if they are still its
+        mod, name, old, new = _REBOUND.pop()
+        if getattr(mod, name, None) is new:
+            setattr(mod, name, old)

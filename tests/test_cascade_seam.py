@@ -103,14 +103,19 @@ def _fake_reference():
     voc.upsample, voc.remove_above_fmax, voc.frequency_filter = core.upsample, core.remove_above_fmax, core.frequency_filter  # vocoder.py:16
     dvoc.CombSubFast, dvoc.CombSubSuperFast = voc.CombSubFast, voc.CombSubSuperFast                                       # diffusion/vocoder.py:13
     ddsp.core, ddsp.vocoder, ddsp.unit2control, dif.vocoder = core, voc, u2c, dvoc
+    # the scripts that bind `upsample` by name (flask_api.py:12, flask_api_diff.py:12, gui_diff.py:10, gui_reflow.py:8,
+    # main_reflow.py:13: `from ddsp.core import upsample`), one of them under an alias
+    for n in ("flask_api", "flask_api_diff", "gui_diff", "gui_reflow", "main_reflow"):
+        mod(n).upsample = core.upsample
+    mods["gui_reflow"].core_upsample = core.upsample
     return mods
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 def test_patch_reference_rebinding_with_standins(dev, monkeypatch):
-    for name in ("ddsp", "ddsp.core", "ddsp.vocoder", "ddsp.unit2control", "diffusion", "diffusion.vocoder"):
-        monkeypatch.delitem(sys.modules, name, raising=False)
     mods = _fake_reference()
+    for name in mods:
+        monkeypatch.delitem(sys.modules, name, raising=False)
     for name, m in mods.items():
         monkeypatch.setitem(sys.modules, name, m)
     from ddsp_svc_amd import vocoder as V
@@ -120,6 +125,10 @@ def test_patch_reference_rebinding_with_standins(dev, monkeypatch):
         V.patch_reference()
         assert dvoc.CombSubSuperFast is V.CombSubSuperFast and voc.CombSub is V.CombSub       # names bound at import are rebound
         assert voc.upsample is core.upsample and core.upsample is not core._reference_upsample
+        # ... wherever they are: no list of importing modules, the originals are found by identity over sys.modules
+        for n in ("flask_api", "flask_api_diff", "gui_diff", "gui_reflow", "main_reflow"):
+            assert mods[n].upsample is core.upsample, n
+        assert mods["gui_reflow"].core_upsample is core.upsample
         # the cascade constructs its DDSP stage by name (diffusion/vocoder.py:282) -> the HIP-backed class, built on the
         # Unit2Control the (fake) checkout provides
         stage = dvoc.CombSubSuperFast(SR, HOP, 2048, 16, 1).to(dev).eval()
@@ -148,3 +157,7 @@ def test_patch_reference_rebinding_with_standins(dev, monkeypatch):
         V.unpatch_reference()
     assert dvoc.CombSubSuperFast is ref_super and not hasattr(core, "_reference_upsample")
     assert voc.upsample is core.upsample
+    assert all(mods[n].upsample is core.upsample for n in ("flask_api", "gui_diff", "main_reflow"))
+    assert mods["gui_reflow"].core_upsample is core.upsample
+    from ddsp_svc_amd import vocoder as V2
+    assert V2.CombSub.__module__ == "ddsp_svc_amd.vocoder" and V2.CombSub is V.CombSub      # this package keeps its own names

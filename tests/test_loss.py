@@ -314,3 +314,34 @@ def test_full_size_properties():
         covered = (1 + (441344 - n_fft) // hop - 1) * hop + n_fft
         assert torch.isfinite(ga).all() and float(ga[:, covered:].abs().max()) == 0.0
         assert float(ga[:, :covered].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rss_loss_under_autocast(dev, dtype, golden_dir, monkeypatch):
+    """diffusion/solver_new.py:132 evaluates the DDSP loss inside torch.autocast: the loss is the float32 one (torch.stft is on
+    autocast's float32 list, and so is this path: it upcasts what it is given), also for a prediction that arrives in reduced
+    precision, whose gradient comes back in ITS dtype"""
+    from ddsp_svc_amd import loss as L
+    g = np.load(os.path.join(golden_dir, "sssloss.npz"))
+    sizes = torch.from_numpy(g["rss_sizes"])
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: sizes)
+    rss = L.RSSLoss(256, 300, 4, device=dev)
+    xt = torch.from_numpy(g["x_true"]).to(dev)
+    xp = torch.from_numpy(g["x_pred"]).to(dev).requires_grad_(True)
+    with torch.autocast("cuda" if dev.type == "cuda" else "cpu", dtype=dtype):
+        loss = rss(xp, xt)
+    assert loss.dtype == torch.float32
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["rss_loss"])) <= LOSS_RTOL * float(g["rss_loss"])
+    assert xp.grad.dtype == torch.float32 and _rel_rms(xp.grad.cpu().numpy(), g["rss_grad"].astype(np.float64)) <= GRAD_RTOL
+    # a reduced-precision prediction: the loss of its upcast values, the gradient in its dtype
+    xh = xp.detach().to(dtype).requires_grad_(True)
+    with torch.autocast("cuda" if dev.type == "cuda" else "cpu", dtype=dtype):
+        lh = rss(xh, xt)
+    lh.backward()
+    xu = xh.detach().float().requires_grad_(True)
+    lu = rss(xu, xt)
+    lu.backward()
+    assert lh.dtype == torch.float32 and float(lh) == float(lu)
+    assert xh.grad.dtype == dtype and torch.equal(xh.grad, xu.grad.to(dtype))

@@ -112,6 +112,19 @@ def test_streaming_session_same_bits(dev):
         assert torch.equal(pst.phase0, st.phase0) and torch.equal(pst.phase_frames, st.phase_frames)
         s2, h2, n2 = sess.synth(f0, cg, ch, cn, u, noise_is_u01=True)
         assert torch.equal(s2, sig) and torch.equal(h2, harm) and torch.equal(n2, nz)
+    # the session hands raw pointers to the C ABI: what does not fit its bound shape is refused, not read out of bounds
+    packed = torch.cat([cg, ch, cn], -1)
+    v = torch.split(packed, [256, 256, 256], -1)                          # views with frame stride 768: accepted
+    s3, _, _ = sess.synth(f0, v[0], v[1], v[2], u, noise_is_u01=True)
+    assert torch.equal(s3, sig)
+    for bad in (lambda: sess.synth(f0, cg[:, :-1], ch, cn, u),            # a frame short
+                lambda: sess.synth(f0, cg[..., :255], ch, cn, u),         # wrong bin count
+                lambda: sess.synth(f0, cg.double(), ch, cn, u),           # wrong dtype
+                lambda: sess.synth(f0, cg.transpose(1, 2).contiguous().transpose(1, 2), ch, cn, u),   # last dim not contiguous
+                lambda: sess.synth(f0, cg, ch, cn, u[:, :-512]),          # noise of another length
+                lambda: sess.phase(f0[:, :-1])):
+        with pytest.raises(ValueError):
+            bad()
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
