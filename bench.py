@@ -866,7 +866,11 @@ def flush_emit():
 
 
 def bench_sinesrc(a, rank, world, device):
-    """harmonic source of NSF-HiFiGAN (SURVEY.md 8-f #4): SineGen + merge for B x 10 s, 9 harmonics, noise resident"""
+    """harmonic source of NSF-HiFiGAN: SineGen + merge for B x 10 s, 9 harmonics.  What the caller PAYS per
+    call is timed, i.e. with the standard-normal draw of models.py:168 inside the step, in both forms: (a) the reference's way,
+    ``torch.randn(B, T, 9)`` into HBM and the kernel reading it back (36 B per sample written, 36 read, 4 written); (b) opt-in,
+    the draw inside the kernel (Philox + Box-Muller: 4 B per sample written, nothing of size [B, T, 9] allocated).  ``value`` is
+    (a), the default of the drop-in; (b) is ``in_kernel_noise``; the kernel alone on a resident draw (round 4's line) ``kernel_only``."""
     import torch.distributed as dist
     from ddsp_svc_amd import nsf_source as S
     B = a.batch_per_gpu
@@ -878,44 +882,69 @@ def bench_sinesrc(a, rank, world, device):
     b = torch.zeros(1, device=device)
     ri = torch.rand(9, generator=g).to(device)
     ri[0] = 0
-    noise = torch.randn(B, T, 9, device=device)
+    calls = [0]
 
-    def step():
-        return S.sine_source(f0, HOP, SR, w, b, ri, noise)
+    def step_randn():
+        return S.sine_source(f0, HOP, SR, w, b, ri, torch.randn(B, T, 9, device=device))
+
+    def step_drawn():
+        calls[0] += 1
+        return S.sine_source(f0, HOP, SR, w, b, ri, None, noise_seed=1234 + rank, noise_offset=calls[0])
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    prewarm(step, a.prewarm_seconds)
-    for _ in range(a.warmup):
-        out = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+
+    def timed(step):
+        prewarm(step, a.prewarm_seconds)
+        torch.cuda.reset_peak_memory_stats(device)
+        base = torch.cuda.memory_allocated(device)
+        el, ev_ms, out = time_steps(step, a.steps, a.warmup, fence)
+        peak = torch.cuda.max_memory_allocated(device) - base
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        assert torch.isfinite(out).all()
+        return el, ev_ms, peak, out
+    el_a, ev_a, peak_a, out_a = timed(step_randn)
+    el_b, ev_b, peak_b, out_b = timed(step_drawn)
+    noise = torch.randn(B, T, 9, device=device)
+    el_k, ev_k, _, _ = timed(lambda: S.sine_source(f0, HOP, SR, w, b, ri, noise))
+    # the drawn variant is the same kernel fed its own numbers (bit for bit), and those numbers are standard normal
+    z = S.normal_noise(min(B, 2), T, 9, 1234 + rank, calls[0], device)
+    same = torch.equal(out_b[:z.shape[0]], S.sine_source(f0[:z.shape[0]], HOP, SR, w, b, ri, z))
+    moments = (float(z.mean()), float(z.var()))
+    del noise, z
     if rank != 0:
         return
-    alg = 40.0 * B * T                                            # 9 noise values in, one sample out
-    ms = elapsed / a.steps * 1e3
+    if not same or abs(moments[0]) > 1e-2 or abs(moments[1] - 1.0) > 1e-2:
+        raise SystemExit("bench.py: the in-kernel draw is not what the kernel fed the written-out draw gives (%s, moments %s)" % (same, moments))
+    ms_a, ms_b, ms_k = el_a / a.steps * 1e3, el_b / a.steps * 1e3, el_k / a.steps * 1e3
+    alg_a, alg_b = (36.0 + 36.0 + 4.0) * B * T, 4.0 * B * T + 4.0 * B * F
     emit(({
         "metric": "audio samples/sec, NSF-HiFiGAN harmonic source 44.1kHz upp512 9 harmonics",
-        "value": B * world * T * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "prewarm_s": a.prewarm_seconds, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SourceModuleHnNSF.forward for B=%d/GPU x %.0f s (T=%d), 9 harmonics, resident noise draw"
-                               % (B, a.seconds, T), "batch_per_gpu": B, "samples_per_utterance": T,
+        "value": B * world * T * a.steps / el_a, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "prewarm_s": a.prewarm_seconds, "ms_per_step": ms_a, "ms_per_step_events": ev_a, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SourceModuleHnNSF.forward for B=%d/GPU x %.0f s (T=%d), 9 harmonics, torch.randn draw INSIDE the "
+                               "timed step (models.py:168)" % (B, a.seconds, T), "batch_per_gpu": B, "samples_per_utterance": T,
                    "parallelism": "utterance-shard x%d" % world},
-        "roofline": {"kernel": "k_sinegen<9>", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
-                     "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg, "avg_ms": ms, "launches_per_step": 1}}))
+        "peak_bytes_per_call": peak_a,
+        "roofline": {"kernel": "randn + k_sinegen<9,false>", "bound": "hbm", "achieved": alg_a / (ms_a * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": alg_a / (ms_a * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_a, "avg_ms": ms_a, "launches_per_step": 2,
+                     "note": "bytes of THIS form (the draw written, read back, the sample written); the path's own algorithmic "
+                             "bytes are the 4 B per sample of in_kernel_noise"},
+        "in_kernel_noise": {"ms_per_step": ms_b, "ms_per_step_events": ev_b, "value": B * world * T * a.steps / el_b,
+                            "peak_bytes_per_call": peak_b, "same_kernel_fed_the_written_out_draw": same,
+                            "draw_moments": {"mean": moments[0], "var": moments[1]},
+                            "roofline": {"kernel": "k_sinegen<9,true>", "bound": "hbm", "achieved": alg_b / (ms_b * 1e-3) / 1e9,
+                                         "peak": 8000.0, "unit": "GB/s", "frac": alg_b / (ms_b * 1e-3) / 1e9 / 8000.0,
+                                         "algorithmic_bytes_per_launch": alg_b,
+                                         "note": "not HBM-bound any more: 3 Philox4x32-10 + 5 Box-Muller pairs + 9 sines per sample"}},
+        "kernel_only": {"ms_per_step": ms_k, "note": "k_sinegen<9,false> on a resident draw (the draw untimed: round 4's line)"}}))
 
 
 def bench_rssloss(a, rank, world, device):

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ddsp_hip_stft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ddsp_hip_sine_source": (c_int, [P, c_int, c_int, c_int, c_double, P, P, P, P, c_int, c_float, c_float, c_float,
                                      P, P, P]),
+    "ddsp_hip_sine_source_drawn": (c_int, [P, c_int, c_int, c_int, c_double, P, ctypes.c_ulonglong, ctypes.c_ulonglong, P, P, c_int,
+                                           c_float, c_float, c_float, P, P, P]),
+    "ddsp_hip_normal_noise": (c_int, [ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, c_long, c_int, P, P]),
     "ddsp_hip_spectral_loss_scratch_bytes": (c_size_t, [c_int, c_long]),
     "ddsp_hip_spectral_loss": (c_int, [P, P, c_int, c_long, c_float, c_float, c_float, P, c_size_t, P, P, P]),
     "ddsp_hip_spectral_loss_backward": (c_int, [P, P, c_int, c_long, P, c_float, c_float, c_float, P, c_int, P, P]),

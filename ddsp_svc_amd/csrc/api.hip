@@ -917,6 +917,28 @@ int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, cons
   return finish();
 }
 
+int ddsp_hip_sine_source_drawn(const float* f0, int B, int L, int upp, double sr, const float* rand_ini,
+                               unsigned long long noise_seed, unsigned long long noise_offset, const float* weight,
+                               const float* bias, int dim, float sine_amp, float noise_std, float voiced_threshold,
+                               float* rad_acc, float* out, void* stream) {
+  if (B < 0 || L <= 0 || upp <= 0 || dim <= 0 || !(sr > 0)) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!f0 || !rand_ini || !weight || !bias || !rad_acc || !out) return DDSP_HIP_EINVAL;
+  const NoiseGen gen{noise_seed, noise_offset, 1, 0u};
+  if (launch_sine_source(f0, B, L, upp, sr, rand_ini, nullptr, weight, bias, dim, sine_amp, noise_std, voiced_threshold,
+                         rad_acc, out, S(stream), &gen) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_normal_noise(unsigned long long seed, unsigned long long offset, int B, long T, int dim, float* out, void* stream) {
+  if (B < 0 || T <= 0 || dim <= 0) return DDSP_HIP_EINVAL;
+  if (B == 0) return 0;
+  if (!out) return DDSP_HIP_EINVAL;
+  if (launch_normal_noise(seed, offset, B, T, dim, out, S(stream)) != 0) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 size_t ddsp_hip_spectral_loss_scratch_bytes(int B, long bins_per_utterance) {
   if (B < 1 || bins_per_utterance < 1) return 0;
   return sss_scratch_bytes(B, bins_per_utterance);

@@ -111,9 +111,11 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
                const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
                long sm, long sf, hipStream_t st);
 int mel_frames(int T, int n_fft, int hop);
+// gen != null && on: the standard-normal noise is drawn inside the kernel from (seed, offset) (noise may be null)
 int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
                        const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
-                       float voiced_threshold, float* rad_acc, float* out, hipStream_t st);
+                       float voiced_threshold, float* rad_acc, float* out, hipStream_t st, const NoiseGen* gen = nullptr);
+int launch_normal_noise(unsigned long long seed, unsigned long long offset, int B, long T, int dim, float* out, hipStream_t st);
 int sss_chunks(int B, long per_utt);
 size_t sss_scratch_bytes(int B, long per_utt);
 int launch_sss_loss(const float* xt, const float* xp, int B, long per_utt, float inv_wn, float eps, float alpha,

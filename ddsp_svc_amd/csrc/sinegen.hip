@@ -9,6 +9,7 @@
 // shifted by one frame; per harmonic rad * h + rand_ini, sine of the float32 product 2 pi rad.
 #include "ddsp_common.h"
 #include "kernels.h"
+#include "philox.h"
 
 namespace ddsp {
 
@@ -42,13 +43,16 @@ __global__ void __launch_bounds__(256) k_sinegen_scan(const float* __restrict__ 
   }
 }
 
-// per-sample part; DIM harmonics, one thread per sample
-template <int DIM>
+// per-sample part; DIM harmonics, one thread per sample.  DRAW: the standard-normal noise (models.py:168, randn_like of the
+// [B, T, DIM] sine waves) is not read but drawn here (philox.h, keyed by (seed, offset)): the kernel then reads 4 bytes of f0 per
+// frame and writes 4 bytes per sample, where the resident draw costs 4 DIM bytes per sample of HBM traffic in this kernel, the
+// same again in the kernel that wrote it, and [B, T, DIM] floats of memory (1.0 GB at B = 64 x 10 s).
+template <int DIM, bool DRAW>
 __global__ void __launch_bounds__(256) k_sinegen(const float* __restrict__ f0, const float* __restrict__ rad_acc,
                                                  const float* __restrict__ rand_ini, const float* __restrict__ noise,
                                                  const float* __restrict__ weight, const float* __restrict__ bias,
                                                  int L, int upp, float sr, float sine_amp, float noise_std,
-                                                 float voiced_threshold, long total, float* __restrict__ out) {
+                                                 float voiced_threshold, long total, float* __restrict__ out, NoiseGen rng) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const long T = (long)L * upp;
@@ -60,7 +64,19 @@ __global__ void __launch_bounds__(256) k_sinegen(const float* __restrict__ f0, c
   rad = rad + (l > 0 ? rad_acc[b * L + l - 1] : 0.0f);                               // models.py:144
   const bool voiced = f > voiced_threshold;                                          // models.py:163-164
   const float namp = voiced ? noise_std : sine_amp / 3.0f;                           // models.py:165
-  const float* nz = noise + i * DIM;
+  float nz[DIM];
+  if (DRAW) {
+#pragma unroll
+    for (int j = 0; j < (DIM + 3) / 4; ++j) {
+      const Normal4 q = philox_normal4(rng, (unsigned)b, (unsigned)t, (unsigned)j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * j + e < DIM) nz[4 * j + e] = q.z[e];
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < DIM; ++h) nz[h] = noise[i * DIM + h];
+  }
   float acc = bias[0];
 #pragma unroll
   for (int h = 0; h < DIM; ++h) {
@@ -72,20 +88,48 @@ __global__ void __launch_bounds__(256) k_sinegen(const float* __restrict__ f0, c
   out[i] = tanhf(acc);                                                               // models.py:203 (Tanh)
 }
 
+// the draw of k_sinegen<DIM, true> written out: z[B, T, dim] (tests; callers that need the numbers themselves)
+__global__ void __launch_bounds__(256) k_normal_noise(NoiseGen rng, long T, int dim, long total, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;           // one thread per (sample, group of four harmonics)
+  const int groups = (dim + 3) / 4;
+  if (i >= total * groups) return;
+  const long s = i / groups;
+  const int j = (int)(i - s * groups);
+  const long b = s / T;
+  const Normal4 q = philox_normal4(rng, (unsigned)b, (unsigned)(s - b * T), (unsigned)j);
+  for (int e = 0; e < 4; ++e)
+    if (4 * j + e < dim) out[s * dim + 4 * j + e] = q.z[e];
+}
+
+int launch_normal_noise(unsigned long long seed, unsigned long long offset, int B, long T, int dim, float* out, hipStream_t st) {
+  if (T >= (1L << 32) || dim < 1 || (offset >> 62) != 0) return -1;     // the counter holds t in 32 bits, 4 * offset_hi + j in 32
+  const long total = (long)B * T, threads = total * ((dim + 3) / 4);
+  const long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffL) return -1;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_normal_noise, dim3((unsigned)blocks), dim3(256), 0, st, NoiseGen{seed, offset, 1, 0u}, T, dim, total, out);
+  return 0;
+}
+
 int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
                        const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
-                       float voiced_threshold, float* rad_acc, float* out, hipStream_t st) {
+                       float voiced_threshold, float* rad_acc, float* out, hipStream_t st, const NoiseGen* gen) {
   if (dim != 9 && dim != 1) return -1;
   const long total = (long)B * L * upp;
   const long blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffL) return -1;
+  const bool draw = gen && gen->on;
+  if (draw && ((long)L * upp >= (1L << 32) || (gen->offset >> 62) != 0)) return -1;
+  if (!draw && !noise) return -1;
+  NoiseGen rng{0ull, 0ull, 0, 0u};
+  if (draw) rng = *gen;
   hipLaunchKernelGGL(k_sinegen_scan, dim3((unsigned)B), dim3(256), 0, st, f0, L, upp, (float)sr, rad_acc);
-  if (dim == 9)
-    hipLaunchKernelGGL(k_sinegen<9>, dim3((unsigned)blocks), dim3(256), 0, st, f0, rad_acc, rand_ini, noise, weight, bias, L,
-                       upp, (float)sr, sine_amp, noise_std, voiced_threshold, total, out);
-  else
-    hipLaunchKernelGGL(k_sinegen<1>, dim3((unsigned)blocks), dim3(256), 0, st, f0, rad_acc, rand_ini, noise, weight, bias, L,
-                       upp, (float)sr, sine_amp, noise_std, voiced_threshold, total, out);
+#define DDSP_SINEGEN(D, R)                                                                                                     \
+  hipLaunchKernelGGL((k_sinegen<D, R>), dim3((unsigned)blocks), dim3(256), 0, st, f0, rad_acc, rand_ini, noise, weight, bias, L, \
+                     upp, (float)sr, sine_amp, noise_std, voiced_threshold, total, out, rng)
+  if (dim == 9) { if (draw) DDSP_SINEGEN(9, true); else DDSP_SINEGEN(9, false); }
+  else { if (draw) DDSP_SINEGEN(1, true); else DDSP_SINEGEN(1, false); }
+#undef DDSP_SINEGEN
   return 0;
 }
 

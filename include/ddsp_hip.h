@@ -293,6 +293,17 @@ int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, cons
                          const float* noise, const float* weight, const float* bias, int dim, float sine_amp,
                          float noise_std, float voiced_threshold, float* rad_acc, float* out, void* stream);
 
+/* The same with the standard-normal noise of models.py:168 (torch.randn_like(sine_waves): [B, L*upp, dim] values, 0.5 GB at
+ * B = 32 x 10 s, 1.0 GB at B = 64) DRAWN INSIDE the kernel instead of read: opt-in, a Philox4x32-10 / Box-Muller stream of its
+ * own keyed by (noise_seed, noise_offset) -- reproducible, independent of launch geometry, not torch.randn's numbers for a
+ * seed.  noise_offset < 2^62, L*upp < 2^32.  ddsp_hip_normal_noise writes the same numbers out as z[B, T, dim]. */
+int ddsp_hip_sine_source_drawn(const float* f0, int B, int L, int upp, double sr, const float* rand_ini,
+                               unsigned long long noise_seed, unsigned long long noise_offset, const float* weight,
+                               const float* bias, int dim, float sine_amp, float noise_std, float voiced_threshold,
+                               float* rad_acc, float* out, void* stream);
+int ddsp_hip_normal_noise(unsigned long long seed, unsigned long long offset, int B, long T, int dim, float* out,
+                          void* stream);
+
 /* ---- spectral loss of the training loop (ddsp/loss.py:9-54) ---- */
 
 /* SSSLoss.forward behind the STFT (loss.py:22-31).  spec_true / spec_pred: the complex STFTs of the two signals

@@ -379,6 +379,29 @@ def uniform_noise(B: int, T: int, seed: int, offset: int) -> np.ndarray:
     return ((sel >> np.uint32(8)).astype(np.float32) * F32(2.0 ** -24)).astype(F32)
 
 
+def normal_noise(B: int, T: int, dim: int, seed: int, offset: int) -> np.ndarray:
+    """``z [B,T,dim]`` float64, the opt-in in-kernel standard-normal draw of the NSF harmonic source (csrc/philox.h,
+    ``ddsp_hip_normal_noise``; it stands where nsf_hifigan/models.py:168 draws ``torch.randn_like``): counter = (t, b, offset lo,
+    4 * offset hi + j), key = (seed lo, hi); words (x0, x1), (x2, x3) -> Box-Muller pairs with u1 = ((x >> 8) + 1) 2^-24,
+    u2 = (x' >> 8) 2^-24; harmonic h takes normal h % 4 of call j = h // 4."""
+    groups = (dim + 3) // 4
+    ctr = np.zeros((B, T, groups, 4), dtype=np.uint64)
+    ctr[..., 0] = np.arange(T, dtype=np.uint64)[None, :, None]
+    ctr[..., 1] = np.arange(B, dtype=np.uint64)[:, None, None]
+    ctr[..., 2] = np.uint64(offset & 0xFFFFFFFF)
+    ctr[..., 3] = (np.uint64(4 * ((offset >> 32) & 0x3FFFFFFF)) + np.arange(groups, dtype=np.uint64))[None, None, :]
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    x = philox4x32_10(ctr, np.broadcast_to(key, ctr.shape[:-1] + (2,))).astype(np.uint64)
+    z = np.empty((B, T, groups, 4), dtype=np.float64)
+    for p in range(2):
+        u1 = ((x[..., 2 * p] >> np.uint64(8)) + np.uint64(1)).astype(np.float64) * 2.0 ** -24
+        u2 = (x[..., 2 * p + 1] >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+        r = np.sqrt(-2.0 * np.log(u1))
+        z[..., 2 * p] = r * np.cos(2.0 * np.pi * u2)
+        z[..., 2 * p + 1] = r * np.sin(2.0 * np.pi * u2)
+    return z.reshape(B, T, groups * 4)[..., :dim]
+
+
 # --------------------------------------------------------------------------------------
 # 8-f #1  CombSubFast / CombSubSuperFast: short-time spectral filtering     vocoder.py:613-786
 # --------------------------------------------------------------------------------------

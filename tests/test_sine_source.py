@@ -115,3 +115,82 @@ def test_against_reference_source_module(dev):
     assert got.shape == want.shape
     print("SourceModuleHnNSF on %s against the reference's CPU path: max abs error %.2e" % (dev, float((got - want).abs().max())))
     assert (got - want).abs().max() <= 2e-6
+
+
+# ---- the opt-in in-kernel standard-normal draw (models.py:168's randn_like: [B, L*upp, dim] floats that need not exist) -----------
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,T,dim,seed,offset", [(1, 512, 9, 1, 0), (3, 700, 9, 0x1234567890ABCDEF, 7), (2, 40, 1, 5, (1 << 40) + 3)])
+def test_normal_noise_matches_oracle(dev, B, T, dim, seed, offset):
+    """the written-out draw against the float64 restatement (Philox4x32-10 is pinned to its known answers in test_noise_rng.py):
+    the hardware log2 / sine / cosine are within 2e-6 of it on values up to 5.77"""
+    from ddsp_svc_amd import nsf_source as S
+    z = S.normal_noise(B, T, dim, seed, offset, dev).cpu().numpy()
+    ref = O.normal_noise(B, T, dim, seed, offset)
+    assert z.shape == (B, T, dim) and z.dtype == np.float32
+    assert np.abs(z - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_normal_noise_statistics():
+    z = O.normal_noise(3, 1 << 15, 9, 20260923, 0)
+    n = z.size
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1.0) < 6 * np.sqrt(2.0 / n)
+    assert abs(float((z ** 3).mean())) < 6 * np.sqrt(15.0 / n) and abs(float((z ** 4).mean()) - 3.0) < 6 * np.sqrt(96.0 / n)
+    assert np.abs(z).max() <= 5.78                                  # u1 >= 2^-24
+    # a 32-bin chi-square against the normal cdf
+    from math import erf, sqrt
+    edges = np.linspace(-3.2, 3.2, 31)
+    cdf = np.array([0.5 * (1 + erf(e / sqrt(2))) for e in edges])
+    p = np.diff(np.concatenate([[0.0], cdf, [1.0]]))
+    counts = np.histogram(z, bins=np.concatenate([[-np.inf], edges, [np.inf]]))[0]
+    chi2 = float(((counts - n * p) ** 2 / (n * p)).sum())
+    assert chi2 < 31 + 5 * np.sqrt(2 * 31), chi2
+    # independence: between the harmonics of a sample (incl. the two members of a Box-Muller pair and the two pairs of a
+    # counter), between neighbouring samples, utterances and offsets
+    zz = z.reshape(-1, 9)
+    c = np.corrcoef(zz.T)
+    assert np.abs(c - np.eye(9)).max() < 5 / np.sqrt(zz.shape[0])
+    for lag in (1, 2, 512):
+        r = float((z[:, lag:, 0] * z[:, :-lag, 0]).mean())
+        assert abs(r) < 5 / np.sqrt(z.shape[0] * z.shape[1]), (lag, r)
+    assert abs(float((z[0] * z[1]).mean())) < 5 / np.sqrt(z[0].size)
+    v = O.normal_noise(1, 1 << 15, 9, 20260923, 1)
+    assert abs(float((z[0] * v[0]).mean())) < 5 / np.sqrt(v.size)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("dim", [9, 1])
+def test_sine_source_with_in_kernel_noise(dev, dim):
+    """``noise=None`` is the same kernel with its noise generated instead of loaded: the output equals the call fed the
+    written-out draw (bit for bit), is the reference's formula on those numbers, and the module opt-in advances the stream"""
+    from ddsp_svc_amd import nsf_source as S
+    B, L = 3, 11
+    rng = np.random.default_rng(dim)
+    f0 = O.synth_f0(B, L, SR, UPP, seed=4)[..., 0]
+    f0[rng.random((B, L)) < 0.3] = 0.0
+    w = rng.standard_normal(dim).astype(np.float32) * 0.3
+    b = rng.standard_normal(1).astype(np.float32) * 0.1
+    ri = rng.random(dim).astype(np.float32)
+    ri[0] = 0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    drawn = S.sine_source(t(f0), UPP, SR, t(w), t(b), t(ri), None, noise_seed=99, noise_offset=3)
+    z = S.normal_noise(B, L * UPP, dim, 99, 3, dev)
+    fed = S.sine_source(t(f0), UPP, SR, t(w), t(b), t(ri), z)
+    assert torch.equal(drawn, fed)
+    ref = O.sine_source(f0, UPP, SR, w, b, ri, z.cpu().numpy())
+    assert np.abs(drawn.cpu().numpy() - ref).max() <= 2e-6
+    with pytest.raises(ValueError):
+        S.sine_source(t(f0), UPP, SR, t(w), t(b), t(ri), None)
+    if dim == 9:
+        m = S.SourceModuleHnNSF(SR, harmonic_num=8).to(dev)
+        m.in_kernel_noise_seed = 7
+        torch.manual_seed(0)
+        a = m(t(f0), UPP)
+        torch.manual_seed(0)                                      # the same rand_ini draw; the noise stream has advanced
+        c = m(t(f0), UPP)
+        assert a.shape == (B, L * UPP, 1) and not torch.equal(a, c) and m._noise_calls == 2
+        # training the merge layer: the per-harmonic recovery uses ONE draw for all nine passes
+        for p in m.l_linear.parameters():
+            p.requires_grad_(True)
+        y = m(t(f0), UPP)
+        y.sum().backward()
+        assert m.l_linear.weight.grad is not None and m._noise_calls == 3

@@ -84,6 +84,30 @@ print("also", {k: round(v["ms_per_step"], 4) for k, v in d.get("also", {}).items
 print("gpu chain", (d.get("cpu_baseline_aten_chain") or {}).get("same_chain_on_gpu"))
 PY
   ;;
+suite)
+  # the whole GPU suite + smoke, the lanes probe (split against unsplit at full size, per output and utterance), the cfg-4
+  # line with and without the allocator's cache released first, the NSF source line (both draw forms)
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee "$O/${V}_pytest_gpu.log"
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee "$O/${V}_smoke.log"
+  timeout 300 python tools/lanes_probe.py 14336 2>&1 | grep -v Warning | tee "$O/${V}_lanes_probe.txt"
+  for t in "fresh:" "keep:--cfg4-keep-cache" "fresh20:--cfg4-round-steps 20"; do
+    name=${t%%:*}; args=${t#*:}
+    timeout 600 python bench.py --no-cpu-baseline --no-module-mode --no-live-traffic --no-also --cfg4 $args 2>/dev/null | tail -1 > "$O/${V}_bench_cfg4_$name.json"
+    python - "$O/${V}_bench_cfg4_$name.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read()); c = d["cfg4"]
+print(sys.argv[1].split("/")[-1], "headline", round(d["ms_per_step"], 4), "cfg4", round(c["ms_per_step"], 4), "with gather", round(c.get("ms_per_step_with_gather", 0), 4),
+      "rounds", c["rounds_ms"], c.get("rounds_ms_with_gather"))
+PY
+  done
+  timeout 300 python bench.py --model sinesrc 2>/dev/null | tail -1 > "$O/${V}_bench_sinesrc.json"
+  python - <<'PY'
+import json, os
+d = json.loads(open("gpurun_out/%s_bench_sinesrc.json" % os.environ["V"]).read())
+print("sinesrc randn+kernel ms", round(d["ms_per_step"], 4), "peak MB", d["peak_bytes_per_call"] / 1e6, "| in-kernel ms", round(d["in_kernel_noise"]["ms_per_step"], 4),
+      "peak MB", d["in_kernel_noise"]["peak_bytes_per_call"] / 1e6, "| kernel only", round(d["kernel_only"]["ms_per_step"], 4), d["in_kernel_noise"]["draw_moments"])
+PY
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
