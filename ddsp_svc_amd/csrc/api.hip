@@ -16,7 +16,7 @@ thread_local int t_geometry_batch = 0;
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -454,8 +454,11 @@ int ddsp_hip_fft_convolve_backward(const float* audio, int x_is_u01, const float
   if (B < 0 || F <= 0 || hop <= 0 || N < 2 || (N & 1)) return DDSP_HIP_EINVAL;
   if (B == 0) return 0;
   if (!audio || !taps || !grad_out || !d_taps) return DDSP_HIP_EINVAL;
-  // hop 512, N <= 512: the hop-block form; every other shape: direct correlations (fir_bwd_direct.hip)
+  // hop 512, N <= 512: the hop-block form; hop 512, N <= 1022: the per-frame 2048-point form (fir_fft_bwd.hip; knob
+  // FIR_BWD_DIRECT = 1: off, for same-box A/Bs); every other shape: direct correlations (fir_bwd_direct.hip)
   if (launch_fir_blk_bwd(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0 &&
+      (knob(KNOB_FIR_BWD_DIRECT) == 1 ||
+       launch_fir_fft_bwd(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0) &&
       launch_fir_bwd_direct(audio, x_is_u01, taps, grad_out, d_audio, d_taps, B, F, hop, N, S(stream)) != 0)
     return DDSP_HIP_ESHAPE;
   return finish();

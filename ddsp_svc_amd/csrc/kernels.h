@@ -91,6 +91,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
                    const FirSecond* second = nullptr);
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st);
+// hop 512, even N <= 1022 (fir_fft_bwd.hip): the per-frame 2048-point form, what N = 514 .. 1022 take; d_x may be null
+int launch_fir_fft_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
+                       int B, int F, int hop, int N, hipStream_t st);
 // every hop / tap count (fir_bwd_direct.hip): direct correlations, behind launch_fir_blk_bwd as k_fir_simple is behind the forward forms
 int launch_fir_bwd_direct(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                           int B, int F, int hop, int N, hipStream_t st);

@@ -67,6 +67,10 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t width, size_t height, hipStream_t) {
+  for (size_t r = 0; r < height; ++r) memset(static_cast<char*>(p) + r * pitch, v, width);
+  return hipSuccess;
+}
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 

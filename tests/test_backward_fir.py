@@ -393,3 +393,30 @@ def test_sins_trains_at_hop_256(dev):
     for got, want, name in zip(ctrls, ref_c, ("amplitudes", "group_delay", "noise_magnitude")):
         e, w = rms(got.grad.cpu().numpy() - want.grad.numpy()), rms(want.grad.numpy())
         assert e <= 3e-5 * w, (name, e, w)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F,N,run", [(2, 5, 1022, 0), (1, 8, 1022, 1), (1, 7, 514, 2), (2, 1, 1022, 0), (1, 2, 600, 1), (1, 12, 766, 3),
+                                       (1, 9, 1000, 1)])
+def test_fft_convolve_backward_long_taps_fft_form(dev, B, F, N, run, knobs):
+    """514 .. 1022 taps at hop 512 (the classic CombSub harmonic filter, n_mag 512): the per-frame 2048-point adjoint
+    (csrc/fir_fft_bwd.hip) against the oracle's float64 adjoint -- odd / even frame counts (the padded last pair, the held last
+    row fed by frames F-1 and F through two atomic adds), a single frame, runs of one pair (every carry rebuilt by a warm-up frame)
+    -- and against the direct-correlation form it replaces there (knob FIR_BWD_DIRECT = 1): the same gradients, other bits"""
+    from ddsp_svc_amd import core
+    if run:
+        knobs("FFT_RUN", run)
+    x, ir, R = _case(B, F, N, 1000 * F + N)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    dx, dh = core.fft_convolve_backward(t(R), t(x), t(ir))
+    rx, rh = O.ltv_fir_backward(R, x, ir)
+    assert rms(dx.cpu().numpy() - rx) <= 5e-6 * rms(rx), rms(dx.cpu().numpy() - rx) / rms(rx)
+    assert rms(dh.cpu().numpy() - rh) <= 5e-6 * rms(rh), rms(dh.cpu().numpy() - rh) / rms(rh)
+    none, dh2 = core.fft_convolve_backward(t(R), t(x), t(ir), need_audio_grad=False)
+    assert none is None and torch.equal(dh2, dh)
+    dx3, dh3 = core.fft_convolve_backward(t(R), t(x), t(ir))
+    assert torch.equal(dx3, dx) and torch.equal(dh3, dh)                      # the atomics on the last row add two addends: same bits
+    knobs("FIR_BWD_DIRECT", 1)
+    dxd, dhd = core.fft_convolve_backward(t(R), t(x), t(ir))
+    assert rms((dxd - dx).cpu().numpy()) <= 5e-6 * rms(rx) and rms((dhd - dh).cpu().numpy()) <= 5e-6 * rms(rh)
+    assert not torch.equal(dhd, dh)                                           # (it IS another kernel)

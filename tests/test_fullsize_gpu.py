@@ -116,7 +116,10 @@ def test_fir_linearity_and_frame_locality(cuda, batch, impl):
         assert float(diff[:lo].max()) == 0.0 and float(diff[hi + 1:].max()) == 0.0
     else:              # FFT form: the frame shares its transforms with its pair partner -> rounding-level leakage
         assert float(diff[:lo].max()) <= 2e-5 and float(diff[hi + 1:].max()) <= 2e-5      # inside the pair, exact zero beyond
-        assert float(diff[:lo - 2 * HOP].max()) == 0.0 and float(diff[hi + 1 + 2 * HOP:].max()) == 0.0
+        # (the per-frame form is ONE kernel since round 5, the four-taps-per-thread variant with its 4096-sample ring: a pair's
+        # window reaches two hops further than the hop-block form's)
+        reach = (4 if impl == 4 else 2) * HOP
+        assert float(diff[:lo - reach].max()) == 0.0 and float(diff[hi + 1 + reach:].max()) == 0.0
     assert float(diff[lo:hi].max()) > 0.1
 
 

@@ -108,6 +108,22 @@ print("sinesrc randn+kernel ms", round(d["ms_per_step"], 4), "peak MB", d["peak_
       "peak MB", d["in_kernel_noise"]["peak_bytes_per_call"] / 1e6, "| kernel only", round(d["kernel_only"]["ms_per_step"], 4), d["in_kernel_noise"]["draw_moments"])
 PY
   ;;
+probe3)
+  # the GPU suite; why a process with an RCCL communicator runs the B = 32 step 10 % slower (tools/pg_probe.py); the long-tap
+  # adjoints, FFT form against the direct correlations (knob FIR_BWD_DIRECT), and a training step at 256 / 512 / 256 bins
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee "$O/${V}_pytest_gpu.log"
+  : > "$O/${V}_pg_probe.txt"
+  for m in none nccl nccl_nomon gloo nccl_destroyed none; do
+    timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | tee -a "$O/${V}_pg_probe.txt"
+  done
+  for m in none nccl; do timeout 200 python tools/pg_probe.py $m graph 2>&1 | grep "ms/step" | tee -a "$O/${V}_pg_probe.txt"; done
+  for m in none nccl; do PROBE_B=16 timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | tee -a "$O/${V}_pg_probe.txt"; done
+  for k in 0 1; do
+    echo "FIR_BWD_DIRECT=$k" | tee -a "$O/${V}_fir_bwd_long.txt"
+    NBINS=512 DDSP_HIP_FIR_BWD_DIRECT=$k timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"
+    NBINS=300 DDSP_HIP_FIR_BWD_DIRECT=$k timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"
+  done
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
