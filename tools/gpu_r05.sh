@@ -124,6 +124,28 @@ probe3)
     NBINS=300 DDSP_HIP_FIR_BWD_DIRECT=$k timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"
   done
   ;;
+pg)
+  # the RCCL communicator's 32 us per step: which part of it?  (one configuration per process, tools/pg_probe.py)
+  : > "$O/${V}_pg_probe.txt"
+  run() { echo "-- $*" | tee -a "$O/${V}_pg_probe.txt"; env "$@" 2>&1 | grep "ms/step" | tee -a "$O/${V}_pg_probe.txt"; }
+  run X=1 timeout 200 python tools/pg_probe.py none
+  run X=1 timeout 200 python tools/pg_probe.py nccl
+  run DDSP_HIP_ONE_STREAM=1 timeout 200 python tools/pg_probe.py none
+  run DDSP_HIP_ONE_STREAM=1 timeout 200 python tools/pg_probe.py nccl
+  run X=1 timeout 200 python tools/pg_probe.py streams8
+  run X=1 timeout 200 python tools/pg_probe.py streams32
+  run X=1 timeout 200 python tools/pg_probe.py pinned
+  run GPU_MAX_HW_QUEUES=8 timeout 200 python tools/pg_probe.py nccl
+  run GPU_MAX_HW_QUEUES=2 timeout 200 python tools/pg_probe.py nccl
+  run GPU_MAX_HW_QUEUES=2 timeout 200 python tools/pg_probe.py none
+  run NCCL_MAX_NCHANNELS=1 NCCL_MIN_NCHANNELS=1 timeout 200 python tools/pg_probe.py nccl
+  run HSA_ENABLE_SDMA=0 timeout 200 python tools/pg_probe.py nccl
+  run RCCL_MSCCL_ENABLE=0 RCCL_MSCCLPP_ENABLE=0 timeout 200 python tools/pg_probe.py nccl
+  run NCCL_LAUNCH_MODE=GROUP timeout 200 python tools/pg_probe.py nccl
+  run HIP_FORCE_DEV_KERNARG=1 timeout 200 python tools/pg_probe.py nccl
+  run NCCL_DEBUG=INFO timeout 200 python tools/pg_probe.py nccl
+  NCCL_DEBUG=INFO timeout 200 python tools/pg_probe.py nccl 2>&1 | grep -i "NCCL INFO" | head -60 > "$O/${V}_nccl_info.txt"
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"

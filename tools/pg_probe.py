@@ -20,7 +20,20 @@ if mode == "nccl_nomon":
     os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-if mode != "none":
+_keep = []
+if mode.startswith("streams"):                       # idle streams (and events) of other priorities, no communicator: is it their mere existence?
+    n = int(mode[7:] or 8)
+    for i in range(n):
+        st_ = torch.cuda.Stream(priority=-1 if i % 2 else 0)
+        ev_ = torch.cuda.Event()
+        with torch.cuda.stream(st_):
+            torch.zeros(1, device=dev)
+            ev_.record()
+        _keep.append((st_, ev_))
+    torch.cuda.synchronize()
+elif mode == "pinned":                               # a pinned host allocation + a mapped one, as a communicator holds
+    _keep.append(torch.empty(64 << 20, dtype=torch.uint8).pin_memory())
+elif mode != "none":
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
@@ -69,6 +82,6 @@ host = (time.perf_counter() - t0) / 20 * 1e3
 torch.cuda.synchronize()
 print("%-16s graph=%d B=%d  ms/step wall %s  events %s  host enqueue %.4f ms/step  threads %d"
       % (mode, graph, B, ["%.4f" % r[0] for r in res], ["%.4f" % r[1] for r in res], host, len(os.listdir("/proc/self/task"))))
-if mode not in ("none", "nccl_destroyed"):
+if mode in ("nccl", "nccl_nomon", "gloo"):
     import torch.distributed as dist
     dist.destroy_process_group()
