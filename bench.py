@@ -40,6 +40,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BEFORE the HIP runtime is loaded (import torch): eight hardware queues instead of the runtime's default four.  HIP maps
+# streams onto its hardware queues round robin; a process that holds an RCCL communicator (every rank of --gpus N, the cfg-4
+# line) has created ~7 streams before the synthesiser makes its second one, which then lands on the SAME hardware queue as the
+# caller's stream: the two-stream layout runs in one queue and the B = 32 step takes 0.359 ms instead of 0.325 (same box,
+# profiles/r05_v5_pg_fix.txt; with eight queues 0.326 with and without the communicator; every 1-rank "gather" line of rounds
+# 2 - 4 carried this +10 %).  A user's setting wins.  INTEGRATION.md, "processes that hold an RCCL communicator".
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -1564,6 +1572,7 @@ def main(argv=None):
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_s": a.prewarm_seconds,
             "ms_per_step": ms, "ms_per_step_events": events_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "config": {"workload": "%s B=%d/GPU x %.0f s utterances (F=%d, T=%d), n_mag %d/%d/%d, sr 44100, hop 512, "
                                    "DSP path (HOT-1 + HOT-2) from resident f0 / raw controls ~N(0,1) / uniform noise, "
                                    "signal only" % (a.model, B, a.seconds, F, T, n, n, n),

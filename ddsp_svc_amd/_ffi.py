@@ -142,6 +142,10 @@ def _env_flag(name):
 
 
 _ONE_STREAM = _env_flag("DDSP_HIP_ONE_STREAM")                 # read ONCE, at import: never hand the tails a second stream
+try:                                                            # priority of the second stream (A/B switch; see aux_torch_stream)
+    _AUX_PRIORITY = int(os.environ.get("DDSP_HIP_AUX_PRIORITY", "0"))
+except ValueError:
+    _AUX_PRIORITY = 0
 
 
 def set_tuning(name, value):
@@ -161,7 +165,7 @@ def aux_torch_stream(t, rows):
     with _LOCK:
         s = _AUX.get(key)
         if s is None:
-            s = _AUX[key] = torch.cuda.Stream(device=t.device)
+            s = _AUX[key] = torch.cuda.Stream(device=t.device, priority=_AUX_PRIORITY)
             while len(_AUX) > _AUX_MAX:                    # least recently used first; a dropped stream is destroyed by torch
                 _AUX.popitem(last=False)                   # once the work already enqueued on it has finished
         else:

@@ -146,6 +146,23 @@ pg)
   run NCCL_DEBUG=INFO timeout 200 python tools/pg_probe.py nccl
   NCCL_DEBUG=INFO timeout 200 python tools/pg_probe.py nccl 2>&1 | grep -i "NCCL INFO" | head -60 > "$O/${V}_nccl_info.txt"
   ;;
+pg2)
+  # the fix: the second stream on a hardware queue of its own -- by priority class (DDSP_HIP_AUX_PRIORITY=-1) or by more queues
+  : > "$O/${V}_pg_fix.txt"
+  run() { echo "-- $*" | tee -a "$O/${V}_pg_fix.txt"; env "$@" 2>&1 | grep "ms/step" | tee -a "$O/${V}_pg_fix.txt"; }
+  for rep in 1 2; do
+    run X=1 timeout 200 python tools/pg_probe.py none
+    run DDSP_HIP_AUX_PRIORITY=-1 timeout 200 python tools/pg_probe.py none
+    run X=1 timeout 200 python tools/pg_probe.py nccl
+    run DDSP_HIP_AUX_PRIORITY=-1 timeout 200 python tools/pg_probe.py nccl
+    run GPU_MAX_HW_QUEUES=8 timeout 200 python tools/pg_probe.py none
+    run GPU_MAX_HW_QUEUES=8 timeout 200 python tools/pg_probe.py nccl
+  done
+  run GPU_MAX_HW_QUEUES=16 timeout 200 python tools/pg_probe.py nccl
+  run GPU_MAX_HW_QUEUES=8 PROBE_B=16 timeout 200 python tools/pg_probe.py nccl
+  run DDSP_HIP_AUX_PRIORITY=-1 PROBE_B=16 timeout 200 python tools/pg_probe.py nccl
+  run X=1 PROBE_B=16 timeout 200 python tools/pg_probe.py none
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
