@@ -28,6 +28,9 @@ namespace ddsp {
 using fft::cmulc;
 
 constexpr int FFB_HOP = 512;
+#ifndef DDSP_FFB_WGS
+#define DDSP_FFB_WGS 2                    // resident workgroups per CU the register budget is set for (tools/build_variant.sh: 3)
+#endif
 
 struct FirFftBwdGeom {
   int F, N, T;            // frames, taps, samples per utterance
@@ -37,7 +40,7 @@ struct FirFftBwdGeom {
 };
 
 template <bool WITH_DX>
-__global__ void __launch_bounds__(fft::THREADS, 2) k_fir_fft_bwd(const float* __restrict__ x, int x_is_u01,
+__global__ void __launch_bounds__(fft::THREADS, DDSP_FFB_WGS) k_fir_fft_bwd(const float* __restrict__ x, int x_is_u01,
                                                                 const float* __restrict__ taps,
                                                                 const float* __restrict__ grad_out, float* __restrict__ d_x,
                                                                 float* __restrict__ d_taps, FirFftBwdGeom g) {
@@ -205,7 +208,7 @@ int launch_fir_fft_bwd(const float* x, int x_is_u01, const float* taps, const fl
   g.pairs = (F + 2) / 2;
   // run length: one round of resident workgroups (two per CU at this kernel's register budget), equal work; every run but an
   // utterance's first pays two of a pair's five transforms for its carry
-  const long slots = 2 * 256;
+  const long slots = DDSP_FFB_WGS * 256;
   const int Bg = t_geometry_batch > 0 ? t_geometry_batch : B;
   long per_utt = slots / (Bg > 0 ? Bg : 1);
   if (per_utt < 1) per_utt = 1;

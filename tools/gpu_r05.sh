@@ -163,6 +163,25 @@ pg2)
   run DDSP_HIP_AUX_PRIORITY=-1 PROBE_B=16 timeout 200 python tools/pg_probe.py nccl
   run X=1 PROBE_B=16 timeout 200 python tools/pg_probe.py none
   ;;
+final)
+  # the round's final evidence on one box (run under tools/with_reference.sh): round 4's refresh (suite + smoke, the driver's
+  # command with the reference as CPU baseline, the other bench rows, traces, counters, training steps, latencies) plus round 5's
+  # rows: the B sweep, the NSF source with both draw forms, the classic configuration's training step with the FFT-form
+  # long-tap adjoint and with the direct correlations, the communicator check
+  V=$V bash tools/gpu_r04.sh refresh
+  echo "== B sweep"; for B in 16 32 64 128 256; do
+    f="$O/${V}_sweep_B${B}.json"; timeout 300 $BENCH --batch-per-gpu $B --steps 60 2>&1 | tail -1 > "$f"; line "$f"; done
+  timeout 300 python bench.py --model sinesrc 2>/dev/null | tail -1 > "$O/${V}_bench_sinesrc.json"
+  echo "== training at 256 / 512 / 256 bins" | tee -a "$O/${V}_train_ms.txt"
+  for k in 0 1; do echo "FIR_BWD_DIRECT=$k" | tee -a "$O/${V}_train_ms.txt"
+    DDSP_HIP_FIR_BWD_DIRECT=$k timeout 200 python tools/train_step_probe.py combsub512 2>&1 | tail -1 | tee -a "$O/${V}_train_ms.txt"; done
+  for k in 0 1; do echo "FIR_BWD_DIRECT=$k" | tee -a "$O/${V}_fir_bwd_long.txt"
+    NBINS=512 DDSP_HIP_FIR_BWD_DIRECT=$k timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"; done
+  if [ -f tools/ab/libddsp_hip_ffb3.so ]; then echo "three workgroups per CU (tools/ab/libddsp_hip_ffb3.so)" | tee -a "$O/${V}_fir_bwd_long.txt"
+    NBINS=512 DDSP_HIP_LIB=$R/tools/ab/libddsp_hip_ffb3.so timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"; fi
+  echo "== communicator" | tee "$O/${V}_pg_check.txt"
+  for q in 4 8; do for m in none nccl; do GPU_MAX_HW_QUEUES=$q timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | sed "s/^/queues=$q /" | tee -a "$O/${V}_pg_check.txt"; done; done
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"

@@ -27,6 +27,8 @@ if kind == "combsubsuperfast":
 elif kind == "combsubfast":
     f0, ctrls, noise = bench.make_inputs(kind, B, F, bench.model_sizes(kind, n), dev, 1234)
     w = torch.sqrt(torch.hann_window(1024, device=dev))
+elif kind == "combsub512":                                # the classic configuration: n_mag 256 / 512 / 256 (harmonic filter N = 1022)
+    f0, ctrls, noise = bench.make_inputs("combsub", B, F, (256, 512, 256), dev, 1234)
 else:
     f0, ctrls, noise = bench.make_inputs(kind, B, F, (n, n, n), dev, 1234)
 c = [x.clone().requires_grad_(True) for x in ctrls]
