@@ -29,7 +29,8 @@ using fft::cmulc;
 
 constexpr int FFB_HOP = 512;
 #ifndef DDSP_FFB_WGS
-#define DDSP_FFB_WGS 2                    // resident workgroups per CU the register budget is set for (tools/build_variant.sh: 3)
+#define DDSP_FFB_WGS 3                    // resident workgroups per CU the register budget is set for: 168 registers with 10 spilled
+                                          // dwords beat 180 without at two (0.320 against 0.341 ms, same box, r05_v6_fir_bwd_long.txt)
 #endif
 
 struct FirFftBwdGeom {
@@ -63,14 +64,14 @@ __global__ void __launch_bounds__(fft::THREADS, DDSP_FFB_WGS) k_fir_fft_bwd(cons
   fft::Twiddles tw;
   tw.init(tid);
 
-  // one frame's operands: chunk (4 slots), taps (4 slots), cotangent window (8 slots)
-  struct Frame { float cv[4], hv[4], gv[S]; };
-  auto load_frame = [&](int j) -> Frame {
-    Frame f;
+  // one frame's operands: chunk and taps (4 slots each), cotangent window (8 slots).  Each array is fetched for the NEXT pair right
+  // after this pair's transform has consumed it, into the registers it just left: one copy of everything is live, not two
+  struct ChunkTaps { float cv[4], hv[4]; };
+  struct Window { float gv[S]; };
+  auto load_ct = [&](int j) -> ChunkTaps {
+    ChunkTaps f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) { f.cv[m] = 0.f; f.hv[m] = 0.f; }
-#pragma unroll
-    for (int m = 0; m < S; ++m) f.gv[m] = 0.f;
     if (j <= g.F) {                                           // j == F + 1 only pads an odd frame count
       const int s0 = (j - 1) * FFB_HOP;
       const int row = j < g.F ? j : g.F - 1;                  // core.py:167
@@ -87,32 +88,38 @@ __global__ void __launch_bounds__(fft::THREADS, DDSP_FFB_WGS) k_fir_fft_bwd(cons
           f.cv[m] = (n < FFB_HOP ? lam : 1.0f - lam) * xv;    // periodic Bartlett (core.py:161)
         }
       }
-      const int a0 = s0 - D;                                  // gs_j[u] = grad_out[a_j + u]
+    }
+    return f;
+  };
+  auto load_win = [&](int j) -> Window {
+    Window w;
+#pragma unroll
+    for (int m = 0; m < S; ++m) w.gv[m] = 0.f;
+    if (j <= g.F) {
+      const int a0 = (j - 1) * FFB_HOP - D;                   // gs_j[u] = grad_out[a_j + u]
 #pragma unroll
       for (int m = 0; m < S; ++m) {
         const int t = a0 + 256 * m + tid;
-        if (t >= 0 && t < g.T) f.gv[m] = gb[t];
+        if (t >= 0 && t < g.T) w.gv[m] = gb[t];
       }
     }
-    return f;
+    return w;
   };
 
   float carry[2] = {0.f, 0.f};                                // falling half of the previous frame's chunk gradient (block 2 pr - 1)
   const int pr0 = (WITH_DX && p_first > 0) ? p_first - 1 : p_first;    // the pair before the run: only its second frame, for the carry
-  Frame n0 = load_frame(2 * pr0), n1 = load_frame(2 * pr0 + 1);
+  Window w0 = load_win(2 * pr0), w1 = load_win(2 * pr0 + 1);
+  ChunkTaps ct[2] = {load_ct(2 * pr0), load_ct(2 * pr0 + 1)};
   for (int pr = pr0; pr < p_last; ++pr) {
     const bool own = pr >= p_first;
-    const Frame f0 = n0, f1 = n1;
-    if (pr + 1 < p_last) {                                    // the next pair's loads land while this one is transformed
-      n0 = load_frame(2 * pr + 2);
-      n1 = load_frame(2 * pr + 3);
-    }
+    const bool more = pr + 1 < p_last;
     // ---- Q = FFT(gs_j0 + i gs_j1) -> GS_j0, GS_j1 ----
     f32x2 GS0[S], GS1[S];
     {
       f32x2 q[S];
 #pragma unroll
-      for (int m = 0; m < S; ++m) q[m] = f32x2{f0.gv[m], f1.gv[m]};
+      for (int m = 0; m < S; ++m) q[m] = f32x2{w0.gv[m], w1.gv[m]};
+      if (more) { w0 = load_win(2 * pr + 2); w1 = load_win(2 * pr + 3); }      // lands while this pair is transformed
       fft::forward(q, tw, exA, exB, tid);
 #pragma unroll
       for (int m = 0; m < S; ++m) exB[256 * m + tid] = q[m];   // natural order (B is free), then the mirrored read
@@ -128,8 +135,11 @@ __global__ void __launch_bounds__(fft::THREADS, DDSP_FFB_WGS) k_fir_fft_bwd(cons
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 0 && !own) continue;                            // the warm-up pair: only its second frame feeds the carry
-      const Frame& cur = h == 0 ? f0 : f1;
+      if (h == 0 && !own) {                                    // the warm-up pair: only its second frame feeds the carry
+        if (more) ct[0] = load_ct(2 * pr + 2);
+        continue;
+      }
+      const ChunkTaps cur = ct[h];
       const int j = 2 * pr + h;
       // energies of the two sequences -> power-of-two balance factor for the taps, as the forward kernel
       float sx = 0.f, sh = 0.f;
@@ -151,6 +161,7 @@ __global__ void __launch_bounds__(fft::THREADS, DDSP_FFB_WGS) k_fir_fft_bwd(cons
       f32x2 z[S];
 #pragma unroll
       for (int m = 0; m < S; ++m) z[m] = f32x2{m < 4 ? cur.cv[m < 4 ? m : 0] : 0.f, m < 4 ? cur.hv[m < 4 ? m : 0] * sc : 0.f};
+      if (more) ct[h] = load_ct(2 * pr + 2 + h);               // this frame's successor, into the registers it leaves
       fft::forward(z, tw, exA, exB, tid);
       // conj(conj(Z) GS) = Z conj(GS); its forward transform R gives IFFT(conj(Z) GS) = conj(R) / 2048
 #pragma unroll
