@@ -182,6 +182,18 @@ final)
   echo "== communicator" | tee "$O/${V}_pg_check.txt"
   for q in 4 8; do for m in none nccl; do GPU_MAX_HW_QUEUES=$q timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | sed "s/^/queues=$q /" | tee -a "$O/${V}_pg_check.txt"; done; done
   ;;
+check)
+  # the final tree once more: GPU suite (with the reference when DDSP_REFERENCE_PATH is set) + smoke, the long-tap adjoint as shipped,
+  # the classic configuration's training step, the training steps
+  timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee "$O/${V}_pytest_gpu.log"
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -5 | tee "$O/${V}_smoke.log"
+  for k in 0 1; do echo "FIR_BWD_DIRECT=$k" | tee -a "$O/${V}_fir_bwd_long.txt"
+    NBINS=512 DDSP_HIP_FIR_BWD_DIRECT=$k timeout 300 python tools/fir_bwd_bench.py 2>&1 | tail -1 | tee -a "$O/${V}_fir_bwd_long.txt"; done
+  for k in combsub sins combsub512; do timeout 200 python tools/train_step_probe.py $k 2>&1 | tail -1; done | tee "$O/${V}_train_ms.txt"
+  ( cd /tmp; rm -rf "$O/tp"; timeout 300 rocprofv3 --kernel-trace --stats -d "$O/tp" -o t -- python "$R/tools/train_step_probe.py" combsub512 > /dev/null 2>&1
+    python "$R/tools/rocpd_stats.py" $(find "$O/tp" -name "*.db" | head -1) 2>&1 | head -16 > "$O/${V}_train_combsub512_kernel_stats.csv"; rm -rf "$O/tp" )
+  cat "$O/${V}_train_combsub512_kernel_stats.csv"
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
