@@ -47,6 +47,9 @@ elif mode != "none":
         if mode == "nccl_destroyed":
             dist.destroy_process_group()
 F = 862
+if os.environ.get("PROBE_MAIN_PRIORITY"):            # the CALLER's stream in another priority class (the second stream stays normal)
+    _main = torch.cuda.Stream(priority=int(os.environ["PROBE_MAIN_PRIORITY"]))
+    torch.cuda.set_stream(_main)
 step, _ = bench.build_step("combsub", B, F, 256, dev, seed=1)
 bench.prewarm(step, 0.5)
 if graph:
