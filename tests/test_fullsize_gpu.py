@@ -250,3 +250,44 @@ def test_phase_checksum_and_restart(cuda, batch):
     dx = (st2.x - st.x[:, h * HOP:]).double()
     dx = dx - dx.round()
     assert float(dx.abs().max()) <= 2e-6          # float32 hand-over of the phase: ~1e-7 cycles per step of 2*pi rounding
+
+
+@pytest.mark.parametrize("n_taps", [510, 1022, 600])
+def test_fir_adjoints_full_size(cuda, batch, n_taps):
+    """The filter's adjoint kernels at the BASELINE batch through a size-independent property.  y = fir(x, taps) is linear in x
+    and in taps, so for any cotangent g:  <g, fir(x, taps)> = <d_x, x> = <d_taps, taps>  (inner products in float64).  N = 510:
+    the hop-block adjoint; N = 1022 / 600: the per-frame 2048-point adjoint (k_fir_fft_bwd, round 5), which must also agree with
+    the direct correlations it replaces there, repeat bit for bit (its held last row takes atomic adds), and be frame-local"""
+    from ddsp_svc_amd import _ffi, core
+    _, _, x = batch
+    g_ = torch.Generator().manual_seed(n_taps)
+    taps = (torch.randn(B, F, n_taps, generator=g_) / n_taps ** 0.5).to(cuda)
+    g = torch.randn(B, T, generator=g_).to(cuda)
+    y = core.fft_convolve(x, taps)
+    dx, dt = core.fft_convolve_backward(g, x, taps)
+    lhs = float((g.double() * y.double()).sum())
+    scale = float(g.double().pow(2).sum().sqrt() * y.double().pow(2).sum().sqrt())
+    assert abs(lhs - float((dx.double() * x.double()).sum())) <= 2e-6 * scale
+    assert abs(lhs - float((dt.double() * taps.double()).sum())) <= 2e-6 * scale
+    dx2, dt2 = core.fft_convolve_backward(g, x, taps)
+    assert torch.equal(dx, dx2) and torch.equal(dt, dt2)
+    none, dt3 = core.fft_convolve_backward(g, x, taps, need_audio_grad=False)
+    assert none is None and torch.equal(dt3, dt)
+    # a cotangent that lives in one hop block reaches only the tap rows and input samples within its filter's reach
+    g1 = torch.zeros_like(g)
+    g1[:, 400 * HOP:401 * HOP] = g[:, 400 * HOP:401 * HOP]
+    dx1, dt1 = core.fft_convolve_backward(g1, x, taps)
+    rows = dt1.abs().amax(dim=(0, 2))
+    reach = n_taps // 2 // HOP + 2
+    assert float(rows[:400 - reach].max()) <= 1e-5 * float(rows.max()) and float(rows[401 + reach:].max()) <= 1e-5 * float(rows.max())
+    assert float(rows[400].max()) > 0
+    cols = dx1.abs().amax(dim=0)
+    lo, hi = 400 * HOP - n_taps // 2 - 2 * HOP, 401 * HOP + n_taps // 2 + 2 * HOP
+    assert float(cols[:lo].max()) <= 1e-5 * float(cols.max()) and float(cols[hi:].max()) <= 1e-5 * float(cols.max())
+    if n_taps > 512:
+        _ffi.set_tuning("FIR_BWD_DIRECT", 1)
+        try:
+            dxd, dtd = core.fft_convolve_backward(g, x, taps)
+        finally:
+            _ffi.set_tuning("FIR_BWD_DIRECT", 0)
+        assert rms(dxd - dx) <= 5e-6 * rms(dxd) and rms(dtd - dt) <= 5e-6 * rms(dtd)
