@@ -110,3 +110,62 @@ def test_random_scale_loss(dev, seed, knobs):
         gwant = np.mean([O.sss_loss_backward(at, bt, n, 1.0, overlap, eps=1e-5) for n in sizes], axis=0)
         assert abs(float(value.detach()) - want) <= 2e-5 * want, (B, T, sizes, strided, overlap)
         assert _rms(grad.cpu().numpy() - gwant) <= 2e-4 * _rms(gwant), (B, T, sizes, strided, overlap)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("seed", range(6))
+def test_random_split_calls_and_adjoints(dev, seed, knobs):
+    """round 5's paths under random shapes: a call split into sub-batches (random LANE_ROWS, one or two lanes, in-kernel or
+    supplied noise) against the unsplit call bit for bit; the filter's adjoint at random tap counts up to 1022 and random run
+    lengths (hop-block form, per-frame 2048-point form) and the sinusoid bank's at random hops against the oracle's float64"""
+    from ddsp_svc_amd import core, synth
+    rng = np.random.default_rng(3000 + seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # ---- split against unsplit
+    B, F = int(rng.integers(2, 7)), int(rng.integers(2, 30))
+    kind = rng.choice(["combsub", "sins"])
+    n = int(rng.choice([256, 129, 65]))
+    H = int(rng.choice([64, 17])) if kind == "sins" else n
+    f0 = t(O.synth_f0(B, F, SR, HOP, seed=int(rng.integers(1 << 30))))
+    c = [t(rng.standard_normal((B, F, s)).astype(np.float32) * 0.7) for s in (H, n, n)]
+    u = t(rng.random((B, F * HOP)).astype(np.float32))
+    in_kernel = bool(rng.integers(2)) and n <= 257
+    fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+
+    def call():
+        st = synth.phase(f0, SR, HOP)
+        if in_kernel:
+            return fn(f0, st, c[0], c[1], c[2], None, SR, HOP, noise_seed=seed + 1, noise_offset=3)
+        return fn(f0, st, c[0], c[1], c[2], u, SR, HOP, noise_is_u01=True)
+    knobs("LANE_ROWS", 1)
+    whole = call()
+    knobs("LANE_ROWS", int(rng.integers(2, B * F)))
+    knobs("LANES", int(rng.choice([0, 1])))
+    split = call()
+    for a, b in zip(whole, split):
+        assert torch.equal(a, b), (kind, B, F, n, H, in_kernel)
+    knobs("LANE_ROWS", 0)
+    knobs("LANES", 0)
+    # ---- the filter's adjoints
+    B, F = int(rng.integers(1, 3)), int(rng.integers(1, 14))
+    N = 2 * int(rng.integers(1, 512))
+    knobs("BLK_RUN", int(rng.choice([0, 1, 2, 3])))
+    knobs("FFT_RUN", int(rng.choice([0, 1, 2, 3])))
+    x = (rng.random((B, F * HOP)) * 2 - 1).astype(np.float32)
+    ir = (rng.standard_normal((B, F, N)) / np.sqrt(N)).astype(np.float32)
+    R = rng.standard_normal((B, F * HOP)).astype(np.float32)
+    dx, dh = core.fft_convolve_backward(t(R), t(x), t(ir))
+    rx, rh = O.ltv_fir_backward(R, x, ir)
+    assert _rms(dx.cpu().numpy() - rx) <= 5e-6 * _rms(rx) and _rms(dh.cpu().numpy() - rh) <= 5e-6 * _rms(rh), (B, F, N)
+    # ---- the sinusoid bank's adjoint at another hop
+    hop = int(rng.choice([64, 128, 256, 300, 1024]))
+    B, F, H = 1, int(rng.integers(1, 6)), int(rng.integers(1, 50))
+    f0 = O.synth_f0(B, F, SR, hop, seed=int(rng.integers(1 << 30)))
+    (ca,) = O.synth_controls(B, F, [H], seed=int(rng.integers(1 << 30)))
+    R = rng.standard_normal((B, F * hop)).astype(np.float32)
+    st = synth.phase(t(f0), SR, hop)
+    cc = t(ca).requires_grad_(True)
+    (synth.SinusoidBankFunction.apply(t(f0), st, cc, SR, hop) * t(R)).sum().backward()
+    xw, _ = O.wrapped_phase(f0, SR, hop)
+    want = O.sinusoid_bank_backward(R, xw, f0, ca, SR, hop)
+    assert _rms(cc.grad.cpu().numpy() - want) <= 1e-5 * _rms(want), (hop, F, H)
