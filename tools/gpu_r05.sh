@@ -194,6 +194,12 @@ check)
     python "$R/tools/rocpd_stats.py" $(find "$O/tp" -name "*.db" | head -1) 2>&1 | head -16 > "$O/${V}_train_combsub512_kernel_stats.csv"; rm -rf "$O/tp" )
   cat "$O/${V}_train_combsub512_kernel_stats.csv"
   ;;
+layouts)
+  # stream layouts 5 - 7 (the harmonic taps synthesised early on the branch stream, a third tap buffer) against the default 4;
+  # needs profiles/r05_v9_stream_layouts_5_7.patch applied to csrc/api.hip (measured, lost, not in the tree: EXPERIMENTS 5.9)
+  echo "== B = 32"; ab 32 "L4:X=1" "L5:DDSP_HIP_STREAM_LAYOUT=5" "L6:DDSP_HIP_STREAM_LAYOUT=6" "L7:DDSP_HIP_STREAM_LAYOUT=7"
+  echo "== B = 64"; ab 64 "L4:X=1" "L5:DDSP_HIP_STREAM_LAYOUT=5" "L7:DDSP_HIP_STREAM_LAYOUT=7"
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
