@@ -19,7 +19,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                          newest committed profiles/*_hbm_traffic.json (``traffic_source: "committed"``)
   also                   (N = 1) the other single-GPU BASELINE configs attested by the same command: the Sins cfg-3 step with its
                          dominant kernel's roofline, and the as-shipped CombSubSuperFast model (informative)
-  cfg4                   (N = 8, or --cfg4) BASELINE cfg 4: 64 utterances per GPU, samples/s without and with the RCCL gather
+  cfg4                   (the default N = 1 command, N = 8, or --cfg4) BASELINE cfg 4's per-GPU shape: 64 utterances per GPU,
+                         samples/s without and with the RCCL gather, interleaved rounds (a 1-rank communicator at N = 1)
+  parity_vs_oracle       the gate every line is printed behind: two utterances of the TIMED output against the oracle
+                         (<= 1e-4 RMS abs, <= 1e-5 rel) -- a miss is SystemExit, not a field
+  hip_hw_queues          GPU_MAX_HW_QUEUES of the process (set to 8 here before the HIP runtime loads: see below)
   ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
   cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
                          on this host's cores over a bounded sample of the same workload (N=1 only); kind "reference" -- the
