@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 150          /* 0.1.5.0: + the spectral loss from the waveforms (ddsp_hip_stft_loss*), chirp-z tap synthesis */
+#define DDSP_HIP_VERSION 160          /* 0.1.6.0: + ddsp_hip_sine_source_drawn / ddsp_hip_normal_noise, adjoints at 514..1022 taps and every hop, knobs LANE_ROWS / LANES */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
