@@ -200,6 +200,22 @@ layouts)
   echo "== B = 32"; ab 32 "L4:X=1" "L5:DDSP_HIP_STREAM_LAYOUT=5" "L6:DDSP_HIP_STREAM_LAYOUT=6" "L7:DDSP_HIP_STREAM_LAYOUT=7"
   echo "== B = 64"; ab 64 "L4:X=1" "L5:DDSP_HIP_STREAM_LAYOUT=5" "L7:DDSP_HIP_STREAM_LAYOUT=7"
   ;;
+bwdpmc)
+  # the long-tap adjoint's own evidence: kernel trace, HBM bytes (FETCH_SIZE / WRITE_SIZE in separate passes, kernel-trace only;
+  # FETCH_SIZE doubled per the gfx950 correction), SQ counters
+  ( cd /tmp
+    rm -rf "$O/bp"; NBINS=512 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/bp" -o t -- python "$R/tools/fir_bwd_bench.py" > /dev/null 2>&1
+    python "$R/tools/rocpd_stats.py" $(find "$O/bp" -name "*.db" | head -1) 2>&1 | head -6 | tee "$O/${V}_fir_fft_bwd_kernel_stats.csv"; rm -rf "$O/bp"
+    : > "$O/${V}_fir_fft_bwd_pmc.txt"
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+      rm -rf "$O/bp"; NBINS=512 timeout 300 rocprofv3 --pmc $set --kernel-trace -d "$O/bp" -o p -- python "$R/tools/fir_bwd_bench.py" > /dev/null 2>&1
+      f=$(find "$O/bp" -name "*.db" | head -1)
+      [ -n "$f" ] && python "$R/tools/rocpd_pmc.py" "$f" 2>/dev/null | grep "k_fir_fft_bwd" >> "$O/${V}_fir_fft_bwd_pmc.txt"
+      rm -rf "$O/bp"
+    done )
+  cat "$O/${V}_fir_fft_bwd_pmc.txt"
+  ;;
 sweep) sweep ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
