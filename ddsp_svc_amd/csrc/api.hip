@@ -249,6 +249,12 @@ void synth_allpass_taps(const float* c_gd, long ld_gd, const float* table, long 
   launch_ir_gemm(re, n, im, n, DDSP_HIP_ACT_NONE, 1.0f, table, DDSP_HIP_MODE_ROLL, nullptr, rows, n, taps, st);
 }
 
+// knob STREAM_LAYOUT = 1 / 4: batch shapes keep the two-stream layouts of rounds 2 - 5 (A/B runs); default: the fused layout
+bool fused_off() {
+  const long v = knob(KNOB_STREAM_LAYOUT);
+  return v == 1 || v == 4;
+}
+
 size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_max - 1);
   w.buf0 = c.take<float>(BT);
@@ -267,7 +273,9 @@ size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
   }
   w.taps_nz = c.take<float>(R * N);
   w.nzbuf = c.take<float>(BT);
-  w.taps3 = (long)R < kSmallRows ? c.take<float>(R * N) : nullptr;
+  // a third tap buffer: all tap syntheses of a step are then ONE launch (the fused layout of ddsp_hip_combsub_synth: 256-bin models
+  // at hop 512; knob STREAM_LAYOUT 1 / 4 = the two-stream layouts of rounds 2 - 5, which do not need it)
+  w.taps3 = ((long)R < kSmallRows || (n_max == 256 && hop == 512 && !fused_off())) ? c.take<float>(R * N) : nullptr;
   return align_up(c.used, 256);
 }
 
@@ -580,8 +588,28 @@ int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, i
 int sins_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
   const int B = a.B, F = a.F, hop = a.hop, H = a.n0, n_ap = a.n1, n_nz = a.n2;
   const long R = (long)B * F;
-  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
   float* nz = a.noise_out ? a.noise_out : w.nzbuf;
+  // The fused layout (as combsub_rows below; round 6: at every shape): both tap syntheses in one launch -- four dependent
+  // launches on the caller's stream: sinusoid bank | taps (grid.y) | noise filter | all-pass filter + noise.  Same kernels, same
+  // arguments, same bits as the two-stream layout below.  [MI355X] B = 32 x 10 s, same box: 0.3367 -> 0.3212 ms (r06_v10s_*).
+  if ((R < kSmallRows || !fused_off()) && n_ap == 256 && n_nz == 256 && !t_taps_gemm && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
+    const int r = launch_sins_bank(a.f0_frames, a.initial_phase, a.c0, a.ld0, B, F, hop, H, a.sr, a.infer, a.phase0, w.buf0, st);
+    if (r == -1) return DDSP_HIP_EHOP;
+    if (r == -2) return DDSP_HIP_ESHAPE;
+    TapsJobs jobs;
+    jobs.n = 0;
+    int ok = launch_taps_pfa510(a.c2, a.ld2, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R,
+                                n_nz, w.taps_nz, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(a.c1, a.ld1, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, a.t1, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                             w.taps, st, 0.f, &jobs);
+    if (ok != 0 || launch_taps_pfa510_batch(jobs, st) != 0) return DDSP_HIP_ESHAPE;
+    if (launch_fir(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), a.fir_impl, st, &a.gen) < 0)
+      return DDSP_HIP_ESHAPE;
+    if (launch_fir(w.buf0, 0, w.taps, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_ap - 1), a.fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return 0;
+  }
+  // noise = Hann-windowed zero-phase filter exp(c)/128 on uniform noise (vocoder.py:603-607), on the second stream
   Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
   // With the all-pass at 256 bins (prime-factor kernel: no response scratch in the exciter buffer) its taps go to the
   // second stream too, ahead of the noise branch, and the sinusoid bank starts at once (knob STREAM_LAYOUT 1: round-1 order)
@@ -609,6 +637,42 @@ int combsub_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream
   const long R = (long)B * F;
   const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
   float* nz = a.noise_out ? a.noise_out : w.nzbuf;
+  // THE layout of a 256-bin step (round 6): THREE launches on the caller's stream instead of seven on two streams -- exciter and
+  // the three tap syntheses (k_front_small, grid.y) | all-pass filter beside the noise filter (grid.y, runs twice as long: half the
+  // warm-up passes) | harmonic filter + noise.  Round 4 built it for streaming shapes (B = 1, a fraction of a second per call,
+  // gui.py:118-133: the chain of DEPENDENT launches, ~9 us each, is the latency there).  At batch shapes rounds 2 - 5 kept seven
+  // launches on two streams "for the overlap" -- but at the clocks' steady state these kernels gain nothing from running beside
+  // each other (a filter's three waves per SIMD leave no registers for a fourth wave of anything; one-stream order 0.322 ms,
+  // two streams 0.319: what the overlap wins, three cross-stream hand-overs of ~7 us lose), while every separate launch pays its
+  // own ramp and drain: the four front kernels 107.6 us one after the other, 81 as one launch; the two independent filters 145 /
+  // 125.  [MI355X] same box, B = 32 x 10 s: 0.3194 -> 0.3015 ms (profiles/r06_v8_*, r06_v9_*).  The second stream, its events and
+  // the hardware-queue question of round 5 (GPU_MAX_HW_QUEUES) are gone from this path.
+  // Same kernels, same arguments as the layouts below (same bits below 4096 frames: tests/test_small_shapes.py; above, the paired
+  // filters' run split differs: rounding-level); knob SMALL_PATH = 1: never; knob STREAM_LAYOUT = 1 / 4: not at batch shapes.
+  if ((R < kSmallRows || !fused_off()) && all256 && hop == 512 && !a.gen.on && (a.fir_impl == 0 || a.fir_impl == 5) && w.taps3 &&
+      knob(KNOB_SMALL_PATH) != 1
+#ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: the same
+      && (knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0        //  predicate as launch_fir_blk's)
+#endif
+      ) {
+    ExciterJob exc;
+    if (make_exciter_job(a.f0_frames, a.initial_phase, B, F, hop, a.sr, a.infer, a.phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
+    TapsJobs jobs;
+    jobs.n = 0;
+    int ok = launch_taps_pfa510(a.c2, a.ld2, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R,
+                                n_nz, w.taps_nz, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(a.c0, a.ld0, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, a.t0, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
+                             w.taps, st, 0.f, &jobs);
+    ok |= launch_taps_pfa510(a.c1, a.ld1, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f, a.t1, DDSP_HIP_MODE_DYNAMIC, a.f0_frames, R,
+                             n_harm, w.taps3, st, (float)a.sr, &jobs);
+    if (ok != 0 || launch_taps_pfa510_batch(jobs, st, &exc) != 0) return DDSP_HIP_ESHAPE;   // exciter + the three tap syntheses
+    const FirSecond second{a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr};
+    if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, nullptr, &second) < 0)
+      return DDSP_HIP_ESHAPE;
+    if (launch_fir(w.buf1, 0, w.taps3, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_harm - 1), a.fir_impl, st) < 0)
+      return DDSP_HIP_ESHAPE;
+    return 0;
+  }
   Branch br(st, aux_stream);           // without a second stream br.aux is the caller's stream: the same launches, in line
   // Stream layout (knob STREAM_LAYOUT).  1: the noise branch -- its taps and its filter -- on the second stream beside the
   // harmonic chain, joined into the last filter as its addend.  4 (default where every filter has 256 bins; otherwise the
@@ -686,7 +750,6 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   if (gen.on && !(hop == 512 && n_nz <= 257 && (fir_impl == 0 || fir_impl == 5))) return DDSP_HIP_ESHAPE;
   const int n_max = n_ap > n_nz ? n_ap : n_nz;
   hipStream_t st = S(stream);
-  const long R = (long)B * F;
   const TapsFormScope form;
   const TailCall call{f0_frames, initial_phase, phase0, c_amp, ld_amp, c_gd, ld_gd, c_nz, ld_nz, noise, noise_is_u01,
                       B, F, hop, sr, infer, H, n_ap, n_nz, nullptr, table_ap, table_nz, signal, harmonic_or_null,
@@ -700,26 +763,6 @@ int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, cons
   SynthWs w;
   carve_synth(c, B, F, hop, n_max, w);
   if (!c.ok) return DDSP_HIP_EWS;
-  // Streaming shapes (as ddsp_hip_combsub_synth below): both tap syntheses in one launch -- four dependent launches instead of
-  // five: sinusoid bank | taps (grid.y) | noise filter | all-pass filter + noise.  Same kernels, same arguments, same bits.
-  if (R < kSmallRows && n_ap == 256 && n_nz == 256 && !t_taps_gemm && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    const int r = launch_sins_bank(f0_frames, initial_phase, c_amp, ld_amp, B, F, hop, H, sr, infer, phase0, w.buf0, st);
-    if (r == -1) return DDSP_HIP_EHOP;
-    if (r == -2) return DDSP_HIP_ESHAPE;
-    TapsJobs jobs;
-    jobs.n = 0;
-    int ok = launch_taps_pfa510(c_nz, ld_nz, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                                n_nz, w.taps_nz, st, 0.f, &jobs);
-    ok |= launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                             w.taps, st, 0.f, &jobs);
-    if (ok != 0 || launch_taps_pfa510_batch(jobs, st) != 0) return DDSP_HIP_ESHAPE;
-    if (launch_fir(noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), fir_impl, st, &gen) < 0)
-      return DDSP_HIP_ESHAPE;
-    if (launch_fir(w.buf0, 0, w.taps, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_ap - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
-  }
   const int rc = sins_rows(call, w, st, aux_stream);
   return rc != 0 ? rc : finish();
 }
@@ -742,7 +785,6 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   int n_max = n_ap > n_nz ? n_ap : n_nz;
   if (n_harm > n_max) n_max = n_harm;
   hipStream_t st = S(stream);
-  const long R = (long)B * F;
   const TapsFormScope form;
   const TailCall call{f0_frames, initial_phase, phase0, c_gd, ld_gd, c_harm, ld_harm, c_nz, ld_nz, noise, noise_is_u01,
                       B, F, hop, sr, infer, n_ap, n_harm, n_nz, table_ap, table_harm, table_nz, signal, harmonic_or_null,
@@ -756,37 +798,6 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
   SynthWs w;
   carve_synth(c, B, F, hop, n_max, w);
   if (!c.ok) return DDSP_HIP_EWS;
-  const bool all256 = n_ap == 256 && n_harm == 256 && n_nz == 256 && !t_taps_gemm;
-  // Streaming shapes (B = 1, a fraction of a second per call: gui.py:118-133): the step's latency is its chain of DEPENDENT
-  // launches (~9 us each on the GPU whatever the length), so the same kernels are issued as THREE launches instead of seven:
-  // exciter and the three tap syntheses (k_front_small, grid.y) | all-pass filter beside the noise filter (grid.y) | harmonic
-  // filter + noise.
-  // Same kernels, same arguments, same bits as the batch layout below (tests/test_small_shapes.py); knob SMALL_PATH = 1: off.
-  if (R < kSmallRows && all256 && hop == 512 && !gen.on && (fir_impl == 0 || fir_impl == 5) && w.taps3 &&
-      knob(KNOB_SMALL_PATH) != 1
-#ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: the same
-      && (knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0        //  predicate as launch_fir_blk's)
-#endif
-      ) {
-    float* nz = noise_out_or_null ? noise_out_or_null : w.nzbuf;
-    ExciterJob exc;
-    if (make_exciter_job(f0_frames, initial_phase, B, F, hop, sr, infer, phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
-    TapsJobs jobs;
-    jobs.n = 0;
-    int ok = launch_taps_pfa510(c_nz, ld_nz, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, table_nz, DDSP_HIP_MODE_HANN, nullptr, R,
-                                n_nz, w.taps_nz, st, 0.f, &jobs);
-    ok |= launch_taps_pfa510(c_gd, ld_gd, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, table_ap, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
-                             w.taps, st, 0.f, &jobs);
-    ok |= launch_taps_pfa510(c_harm, ld_harm, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f, table_harm, DDSP_HIP_MODE_DYNAMIC, f0_frames, R,
-                             n_harm, w.taps3, st, (float)sr, &jobs);
-    if (ok != 0 || launch_taps_pfa510_batch(jobs, st, &exc) != 0) return DDSP_HIP_ESHAPE;   // exciter + the three tap syntheses
-    const FirSecond second{noise, noise_is_u01, w.taps_nz, nullptr, nz, nullptr};
-    if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, nullptr, &second) < 0)
-      return DDSP_HIP_ESHAPE;
-    if (launch_fir(w.buf1, 0, w.taps3, nz, signal, harmonic_or_null, B, F, hop, 2 * (n_harm - 1), fir_impl, st) < 0)
-      return DDSP_HIP_ESHAPE;
-    return finish();
-  }
   const int rc = combsub_rows(call, w, st, aux_stream);
   return rc != 0 ? rc : finish();
 }

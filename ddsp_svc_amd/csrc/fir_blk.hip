@@ -690,6 +690,9 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   const long slots = (long)wps * 2 * 256;
   const int Bg = t_geometry_batch > 0 ? t_geometry_batch : B;          // kernels.h: a sub-batch keeps the whole call's split
   long per_utt = slots / (Bg > 0 ? Bg : 1);
+  // two jobs share the one round of resident workgroups: runs twice as long, half the warm-up passes (at streaming shapes every
+  // workgroup is resident anyway and the split stays what the one-job launches of the same shape use: same bits)
+  if (second && (long)Bg * F >= kSmallRows) per_utt = slots / (2 * (Bg > 0 ? Bg : 1));
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   // at least three pairs per workgroup (each pays a warm-up block and its twiddles) -- except at streaming shapes, where every

@@ -171,8 +171,103 @@ __device__ __forceinline__ float div_by_row(float a, float b, float rb) {
 // by the 16 rows' window half widths and their reciprocals (MODE_DYNAMIC)
 constexpr int W_WORDS = TR * 17 * WSTRIDE + (TR * 17 + 15) / 16;          // complex words
 constexpr int U_FLOATS = 2 * ROWS * NB;                                   // 8192 floats
-constexpr int HW_AT = ROWS * NT;                                          // 8160: hw[16], then 1/hw[16]
+// the batch's window rows (MODE_DYNAMIC) live in the 32 floats the output staging O[16][510] leaves of the union region -- the
+// stage that reads them reads nothing else there -- and one flag word behind it.  (Round 6 first put a larger table BEHIND the
+// region: LDS reads at offsets >= 32 KiB of a workgroup's allocation turned out to be pathologically slow for the workgroups of
+// a launch's first round -- stage C 10 - 15 us instead of 2.6 for half of them, tools/pfa_tail_probe.py, profiles/r06_v3_* -- so
+// nothing a loop reads may live there; the flag is read once per thread.)
+constexpr int HW_AT = ROWS * NT;                                          // 8160: float2 {RN(1 / hw), thr / 2} x ROWS  (or {hw, RN(1 / hw)}: below)
+constexpr int HW_FLAG = U_FLOATS;                                         // != 0: some row of the batch needs the per-tap form
+constexpr int LDS_FLOATS = U_FLOATS + 4;
 static_assert(U_FLOATS >= 2 * W_WORDS && U_FLOATS >= HW_AT + 2 * ROWS, "union region too small");
+
+// ---- the dynamic window of core.py:240-251, w(d) = (1 + cos(pi u)) / 2 with u = d / hw and ONLY u > 1 clamped (to u = 0, i.e.
+// w = 1; core.py:245), d = j - N/2 -- per ROW: the reciprocal of hw and the clamp as a threshold on d.  u = RN(d / hw) is
+// monotonic in d, so "u > 1" is "d >= thr" with thr = the smallest integer offset whose float32 quotient exceeds 1: floor(hw) + 1
+// unless that quotient rounds to exactly 1 (hw one ulp below an integer), then one more -- decided with ONE true division per row,
+// so the clamp is the reference's bit for bit whatever the cosine's argument rounds to.
+// A row is `nice` when hw >= 0.5 and finite (every f0 below 132 kHz): only then are u / 2 revolutions inside the hardware
+// cosine's range and the threshold form valid; any other row sends its whole batch to the per-tap form of rounds 2 - 5, and the
+// batch's rows then hold {hw, RN(1 / hw)} instead.
+__device__ __forceinline__ bool window_row_nice(float hw) { return hw >= 0.5f && hw < 3.0e38f; }
+__device__ __forceinline__ float2 stage_window_row(float hw) {
+  const float dc = floorf(hw) + 1.0f;
+  float thr = (dc / hw > 1.0f) ? dc : dc + 1.0f;
+  thr = thr < 1024.0f ? thr : 1024.0f;
+  return make_float2(1.0f / hw, 0.5f * thr);
+}
+
+// two taps of one row: dh = d / 2 of both.  cos(pi u) = cos(2 pi (u / 2)), and the hardware cosine takes revolutions: u / 2 =
+// dh * RN(1 / hw) -- two roundings (1.2e-7 of the angle) where the reference's float32 chain u = RN(d / hw), RN(pi u) has two of
+// its own: the two windows differ by <= 2.4e-7 of the angle, i.e. <= 1.2e-6 (typically 2e-7) of the window at the ~10 rad a
+// 256-bin filter reaches at f0 = 800 Hz, and NOT AT ALL in which taps are clamped.  6 packed + 2 transcendental + 4 instructions
+// per pair; rounds 2 - 5 spent ~50 on a division with an exact fallback and a reduced cosine per tap.
+__device__ __forceinline__ f32x2 window_pair(f32x2 dh, float2 row) {
+  const f32x2 q = dh * f32x2{row.x, row.x};
+  const f32x2 c = {__builtin_amdgcn_cosf(q.x), __builtin_amdgcn_cosf(q.y)};
+  f32x2 w = __builtin_elementwise_fma(f32x2{0.5f, 0.5f}, c, f32x2{0.5f, 0.5f});      // (1 + cos) / 2, core.py:246
+  w.x = dh.x >= row.y ? 1.0f : w.x;                        // core.py:245
+  w.y = dh.y >= row.y ? 1.0f : w.y;
+  return w;
+}
+
+// the window factors of a group of four consecutive positions j .. j+3 of row r (taps 0, 1 of row r + 1 at j = 508): both kernels
+__device__ __forceinline__ void window_group(const float* U, int j, int r, float (&w)[4]) {
+  const float2* HW2 = reinterpret_cast<const float2*>(U + HW_AT);
+  const bool wrap = j + 3 >= NT;
+  const float2 ha = HW2[r];
+  const float2 hx = HW2[r + 1 < ROWS ? r + 1 : r];          // (a straddling group never reaches row 16: it would start past the batch)
+  const float2 hb = wrap ? hx : ha;
+  const float dh = 0.5f * (float)(j - HALF);
+  const float dh2 = wrap ? -0.5f * (float)HALF : dh + 1.0f;
+  const f32x2 wa = window_pair(f32x2{dh, dh + 0.5f}, ha);
+  const f32x2 wb = window_pair(f32x2{dh2, dh2 + 0.5f}, hb);
+  w[0] = wa.x; w[1] = wa.y; w[2] = wb.x; w[3] = wb.y;
+}
+// the same in the per-tap form (rows hold {hw, RN(1 / hw)})
+__device__ __forceinline__ void window_group_per_tap(const float* U, int j, int r, float (&w)[4]) {
+  const float2* HW2 = reinterpret_cast<const float2*>(U + HW_AT);
+  const bool wrap = j + 3 >= NT;
+  const float2 ha = HW2[r], hb = HW2[wrap && r + 1 < ROWS ? r + 1 : r];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool nx = wrap && e >= 2;
+    const int je = nx ? e - 2 : j + e;
+    float u = div_by_row((float)(je - HALF), nx ? hb.x : ha.x, nx ? hb.y : ha.y);     // core.py:244
+    if (u > 1.0f) u = 0.0f;                                          // core.py:245 -- only the upper side is clamped
+    w[e] = (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                    // core.py:246
+  }
+}
+// wave 0 of a workgroup stages the batch's rows from their half widths (lane = row; lanes >= ROWS pass hw = 1)
+__device__ __forceinline__ void stage_window_rows(float* U, int lane, float hw) {
+  const unsigned long long bad = __ballot(lane < ROWS && !window_row_nice(hw));
+  const float2 row = bad ? make_float2(hw, 1.0f / hw) : stage_window_row(hw);
+  if (lane < ROWS) *reinterpret_cast<float2*>(U + HW_AT + 2 * lane) = row;
+  if (lane == 0) U[HW_FLAG] = bad ? 1.0f : 0.0f;
+}
+
+// tanh(x) for the all-pass group delay pi tanh(c) (vocoder.py:581 / :834): 1 - 2 / (exp(2 |x|) + 1) on the hardware exponential
+// and reciprocal (1 ulp each), the sign copied back.  Absolute error <= 1.5e-7 (rms 4e-8; ocml's tanhf: 6e-8 / 2e-8 at ~6 x the
+// instructions and two divergent branches) -- what counts for a phase that is a SUM of these: 256 bins later 2e-6 rad rms, a
+// fifth of what the reference's own float32 rounding of that sum (ulp(100 rad) / 2 = 4e-6) does to it.
+__device__ __forceinline__ float tanh_hw(float x) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.88539008f);        // exp(2 |x|); inf beyond 44: the quotient is 0
+  const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+  return copysignf(t, x);
+}
+
+// inclusive prefix sum of a 32-bit integer over the 64 lanes of a wave (the DPP steps of wave_incl_scan, ddsp_common.h)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, BOUND); }
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  v += dpp_u32<0x111, 0xF, true>(v);
+  v += dpp_u32<0x112, 0xF, true>(v);
+  v += dpp_u32<0x114, 0xF, true>(v);
+  v += dpp_u32<0x118, 0xF, true>(v);
+  v += dpp_u32<0x142, 0xA, false>(v);
+  v += dpp_u32<0x143, 0xC, false>(v);
+  return v;
+}
 
 }  // namespace pfa
 
@@ -225,11 +320,16 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   // ---- stage 0: rows -> LDS, activated and scaled by 1/N.  irfft drops Im(DC) and Im(Nyquist) (core.py:259) ----
   if (KIND == KIND_ALLPASS) {
     // exp(1j * cumsum(pi * tanh(c))) (vocoder.py:581,599 / :834,845): wave w takes rows 4w..4w+3, a lane owns 4 consecutive
-    // bins; float64 scan reduced to revolutions before the float cosine / sine, as k_allpass_response (ir.hip)
+    // bins.  Only the phase's fraction of a revolution matters, so the running sum is kept in REVOLUTIONS as a 32-bit fixed-point
+    // number that wraps where the cosine does: g = fl32(pi tanh c) as the reference forms it, g / 2 pi * 2^32 rounded to an integer
+    // in float64 (exact to 2^-33 of a revolution; the low word of the sum with 1.5 * 2^52 is that integer mod 2^32), and from there
+    // integer additions -- exact and associative: the wave scan is six one-word DPP additions instead of the float64 scan of rounds
+    // 2 - 5, and the sum of 256 bins is off by < 2^-25 of a revolution (2e-7 rad) whatever its size.  (The reference's float64
+    // accumulation rounded to float32, vocoder.py:599 on the CPU, is off by ulp(sum) / 2: 1e-6 rad at 30 rad, 4e-6 at 100.)
     const int wave = tid >> 6, lane = tid & 63;
-    const double inv_2pi = 0.15915494309189533577;
-    // a ROLLED loop over the wave's four rows (the body holds 4 tanhf, a float64 wave scan and 8 sine / cosine: unrolled
-    // it was a quarter of the kernel's code), the next row's load in flight while a row is activated
+    const double rev_fx = 683565275.57643158978229477;      // 2^32 / (2 pi)
+    const double magic = 6755399441055744.0;                // 1.5 * 2^52
+    // a ROLLED loop over the wave's four rows, the next row's load in flight while a row is activated
     auto load_row = [&](int q) -> float4 {
       const long gr = row0 + wave * 4 + q;
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -247,15 +347,19 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       const int r = wave * 4 + q;
       if (r >= ROWS) break;                                // wave-uniform (batches of fewer than 16 rows)
       const bool live = row0 + r < rows;
-      const float g[4] = {kPiF * tanhf(cv.x), kPiF * tanhf(cv.y), kPiF * tanhf(cv.z), kPiF * tanhf(cv.w)};
-      const double local = (((double)g[0] + (double)g[1]) + (double)g[2]) + (double)g[3];
-      double run = wave_excl_scan(local, lane);
+      const float g[4] = {kPiF * tanh_hw(cv.x), kPiF * tanh_hw(cv.y), kPiF * tanh_hw(cv.z), kPiF * tanh_hw(cv.w)};
+      unsigned s[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double m = fma((double)g[e], rev_fx, magic);
+        const unsigned fx = (unsigned)__builtin_bit_cast(unsigned long long, m);
+        s[e] = e ? s[e - 1] + fx : fx;
+      }
+      const unsigned before = wave_incl_scan_u32(s[3]) - s[3];
       float co[4], si[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        run += (double)g[e];
-        const double rev = run * inv_2pi;
-        const float fr = (float)(rev - rint(rev));
+        const float fr = (float)(int)(before + s[e]) * 2.3283064365386963e-10f;     // 2^-32: revolutions in [-0.5, 0.5]
         co[e] = live ? __builtin_amdgcn_cosf(fr) * inv_n : 0.f;
         si[e] = live ? __builtin_amdgcn_sinf(fr) * inv_n : 0.f;
       }
@@ -369,11 +473,10 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       if (gr < rows) hw_row = half_width[gr];
     }
     __syncthreads();                                       // W is in registers: the region becomes the output staging
-    if (MODE == MODE_DYNAMIC && tid < ROWS) {
+    if (MODE == MODE_DYNAMIC && tid < 64) {                // wave 0: the rows' window constants (behind the output staging)
       float x = hw_row;
       if (hw_sr > 0.f) x = (1.5f * hw_sr) / (x + 1e-3f);   // vocoder.py:851, same float32 operations
-      U[HW_AT + tid] = x;
-      U[HW_AT + ROWS + tid] = 1.0f / x;
+      stage_window_rows(U, tid, x);
     }
     if (act) {
       dft30(v);
@@ -443,29 +546,32 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       put(it, ov);
     }
   } else if (MODE == MODE_DYNAMIC) {
-    // rolled: the body (four divisions by the row's half width with their exact fallback, four cosines) is the bulk of this
-    // mode's code, everything it reads is in LDS
+    // (everything the loops read is in LDS)
     int j = j0, r = r0;
-#pragma unroll 1
-    for (int it = 0; it < GROUPS; ++it) {
-      float ov[4];
-      if (!fetch(it, ov)) break;
-      const bool wrap = j + 3 >= NT;
-      const int r1 = wrap ? r + 1 : r;                      // (a straddling group never reaches row 16: it would start past the batch)
-      const float hv[2] = {U[HW_AT + r], U[HW_AT + r1]};
-      const float rb[2] = {U[HW_AT + ROWS + r], U[HW_AT + ROWS + r1]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool nx = wrap && e >= 2;
-        const int je = nx ? e - 2 : j + e;
-        float u = div_by_row((float)(je - HALF), nx ? hv[1] : hv[0], nx ? rb[1] : rb[0]);     // core.py:244
-        if (u > 1.0f) u = 0.0f;                                          // core.py:245 -- only the upper side is clamped
-        ov[e] *= (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                  // core.py:246
+    if (U[HW_FLAG] == 0.0f) {                               // workgroup-uniform
+#pragma unroll 2
+      for (int it = 0; it < GROUPS; ++it) {
+        float ov[4], w[4];
+        if (!fetch(it, ov)) break;
+        window_group(U, j, r, w);
+        ov[0] *= w[0]; ov[1] *= w[1]; ov[2] *= w[2]; ov[3] *= w[3];
+        put(it, ov);
+        j += 4;                                             // the next group: 1024 floats on = two rows and four taps
+        r += 2;
+        if (j >= NT) { j -= NT; r += 1; }
       }
-      put(it, ov);
-      j += 4;                                               // the next group: 1024 floats on = two rows and four taps
-      r += 2;
-      if (j >= NT) { j -= NT; r += 1; }
+    } else {                                                // half widths below 0.5, negative, infinite, NaN
+#pragma unroll 1
+      for (int it = 0; it < GROUPS; ++it) {
+        float ov[4], w[4];
+        if (!fetch(it, ov)) break;
+        window_group_per_tap(U, j, r, w);
+        ov[0] *= w[0]; ov[1] *= w[1]; ov[2] *= w[2]; ov[3] *= w[3];
+        put(it, ov);
+        j += 4;
+        r += 2;
+        if (j >= NT) { j -= NT; r += 1; }
+      }
     }
   } else {
 #pragma unroll 1
@@ -479,12 +585,12 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
 }
 
 __global__ void __launch_bounds__(256, DDSP_PFA_WGS) k_taps_pfa510(TapsJobs jobs) {
-  __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
+  __shared__ __attribute__((aligned(16))) float U[pfa::LDS_FLOATS];
   taps_pfa510_body<false>(jobs, ExciterJob{}, U);
 }
 
 __global__ void __launch_bounds__(256, DDSP_PFA_WGS) k_front_small(TapsJobs jobs, ExciterJob exc) {
-  __shared__ __attribute__((aligned(16))) float U[pfa::U_FLOATS];
+  __shared__ __attribute__((aligned(16))) float U[pfa::LDS_FLOATS];
   taps_pfa510_body<true>(jobs, exc, U);
 }
 
@@ -503,23 +609,21 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(int ACT, int HAS_IM,
                                                          const float* __restrict__ hann, const float* __restrict__ half_width,
                                                          long rows, float* __restrict__ d_re, float* __restrict__ d_im) {
   using namespace pfa;
-  __shared__ __attribute__((aligned(16))) float U[U_FLOATS + 2 * ROWS];
+  __shared__ __attribute__((aligned(16))) float U[LDS_FLOATS];
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * ROWS;
   float* Zf = U;                                            // stage 0 -> A: Z[t][m] complex, (row 2t, -row 2t+1)
   f32x2* W = reinterpret_cast<f32x2*>(U);                  // A -> B
   f32x2* Out = reinterpret_cast<f32x2*>(U);                // B -> C: Out[t][k] complex
-  float* HW = U + U_FLOATS;                                 // the batch's half widths and their reciprocals
-  if (MODE == MODE_DYNAMIC && tid < ROWS) {
+  if (MODE == MODE_DYNAMIC && tid < 64) {                  // the batch's window rows (stage_window_rows), as the forward kernel's
     const long gr = row0 + tid;
-    const float x = gr < rows ? half_width[gr] : 1.0f;
-    HW[tid] = x;
-    HW[ROWS + tid] = 1.0f / x;
+    stage_window_rows(U, tid, (tid < ROWS && gr < rows) ? half_width[gr] : 1.0f);
   }
   if (MODE == MODE_DYNAMIC) __syncthreads();
+  const bool fast_window = MODE == MODE_DYNAMIC && U[HW_FLAG] == 0.0f;      // workgroup-uniform
 
   // ---- stage 0: windowed tap gradients -> Z, un-rolled: m = (j + 255) mod 510.  The batch's 16 x 510 gradients are one
-  // contiguous, 16-byte aligned stretch; a thread's groups of four are 1024 floats apart ----
+  // contiguous, 16-byte aligned stretch; a thread's groups of four are 1024 floats apart.  The window is the forward kernel's ----
   {
     const float* src = d_taps + row0 * NT;
     const long total = rows * (long)NT - row0 * NT;
@@ -537,17 +641,14 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(int ACT, int HAS_IM,
         if (i + 2 < total) gv.z = src[i + 2];
       }
       const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+      float we[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (fast_window) window_group(U, j, r, we);
+      else if (MODE == MODE_DYNAMIC) window_group_per_tap(U, j, r, we);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int je = j + e, re_ = r;
         if (je >= NT) { je -= NT; re_ += 1; }
-        float w = 1.0f;
-        if (MODE == MODE_HANN) w = hann[je];
-        else if (MODE == MODE_DYNAMIC) {
-          float u = div_by_row((float)(je - HALF), HW[re_], HW[ROWS + re_]);      // core.py:244
-          if (u > 1.0f) u = 0.0f;                                                  // core.py:245
-          w = (1.0f + cos_turns_w(kPiF * u)) / 2.0f;                               // core.py:246
-        }
+        const float w = MODE == MODE_HANN ? hann[je] : we[e];
         int m = je + HALF;
         if (m >= NT) m -= NT;
         const float v = w * ge[e];

@@ -6,8 +6,8 @@ Same constructor and ``get_mel`` signature.  ``get_mel`` runs on the HIP kernel 
 configuration the cascades use (``keyshift == 0``, ``speed == 1``, ``center == False``, ``n_fft == win_size == 2048``,
 ``hop_length == 512``).  The augmentation variants (key shift: a transform of ``round(n_fft 2^(k/12))`` points, any length
 from 1024 to 4096; speed change; ``center``) are off the inference path (training-time augmentation, the enhancer's adaptive
-key) and are evaluated on the tensor's own device as the reference's op sequence (nvSTFT.py:83-117: ``torch.stft`` -- rocFFT --
-magnitude, crop / pad and rescale, mel product), pinned to the reference class in tests/test_mel.py.  The mel basis is what the
+key): the stand-alone class raises ``NotImplementedError`` for them, and ``patch_reference_stft()`` leaves them on the
+reference's own code (this package holds no torch-operator restatement of the reference).  The mel basis is what the
 reference builds with ``librosa.filters.mel`` (nvSTFT.py:90): pass it as ``mel_basis`` (any dense
 ``[n_mels, n_fft/2+1]`` tensor), or let the class build the Slaney filterbank itself (librosa's published
 algorithm, ``htk=False``, ``norm='slaney'``).
@@ -117,36 +117,15 @@ class STFT:
 
     def get_mel(self, y, keyshift=0, speed=1, center=False):
         if keyshift != 0 or speed != 1 or center or self.n_fft != self.win_size:
-            return self._get_mel_augmented(y, keyshift, speed, center)
+            # training-time augmentation / the enhancer's adaptive key (nvSTFT.py:83-85,109-114): a transform of
+            # round(n_fft 2^(k/12)) points, a scaled hop, `center`.  No kernel of this package takes them and the package
+            # carries no second, torch-operator implementation of the reference: a patched reference class
+            # (patch_reference_stft) keeps such calls on the reference's own code.
+            raise NotImplementedError("ddsp_svc_amd.mel.STFT.get_mel: keyshift / speed / center / n_fft != win_size are not "
+                                      "taken by the HIP kernel; use nsf_hifigan.nvSTFT.STFT (patch_reference_stft() routes only "
+                                      "the cascade's inference configuration to the kernel and leaves these to the reference)")
         basis, band, window = self._tables(y.device)
         return mel_spectrogram(y, window, basis, band, self.hop_length, self.clip_val)
-
-    def _get_mel_augmented(self, y, keyshift, speed, center):
-        """nvSTFT.py:83-117 for the variants the kernel does not take (key-shifted transform length, scaled hop, ``center``):
-        the reference's operations in the reference's order, on ``y``'s device"""
-        factor = 2 ** (keyshift / 12)                                                 # :83
-        n_fft_new = int(round(self.n_fft * factor))                                   # :84 (np.round: half to even, as round())
-        win_size_new = int(round(self.win_size * factor))
-        hop_length_new = int(round(self.hop_length * speed))
-        basis, _, _ = self._tables(y.device)
-        wkey = str(keyshift) + "_" + str(y.device)                                    # :93-95
-        if wkey not in self.hann_window:
-            self.hann_window[wkey] = torch.hann_window(win_size_new).to(y.device)
-        pad_left = (win_size_new - hop_length_new) // 2                               # :97-103
-        pad_right = max((win_size_new - hop_length_new + 1) // 2, win_size_new - y.size(-1) - pad_left)
-        mode = "reflect" if pad_right < y.size(-1) else "constant"
-        y = torch.nn.functional.pad(y.unsqueeze(1), (pad_left, pad_right), mode=mode).squeeze(1)
-        spec = torch.stft(y, n_fft_new, hop_length=hop_length_new, win_length=win_size_new, window=self.hann_window[wkey],
-                          center=center, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)   # :106
-        spec = torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-9)                 # :108
-        if keyshift != 0:                                                             # :109-114
-            size = self.n_fft // 2 + 1
-            resize = spec.size(1)
-            if resize < size:
-                spec = torch.nn.functional.pad(spec, (0, 0, 0, size - resize))
-            spec = spec[:, :size, :] * self.win_size / win_size_new
-        spec = torch.matmul(basis, spec)                                              # :115
-        return torch.log(torch.clamp(spec, min=self.clip_val))                        # :116, :53-54
 
 
 def patch_reference_stft():

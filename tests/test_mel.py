@@ -115,11 +115,12 @@ def test_get_mel_contract(dev):
     y = torch.zeros(1, 2048, device=dev)
     out = stft.get_mel(y)                                                            # silence: sqrt(1e-9) per bin
     assert torch.isfinite(out).all() and out.shape == (1, 128, 4)
-    # the augmentation variants (nvSTFT.py:83-85,109-114) change the transform length / hop: evaluated as the reference's op
-    # sequence on the same device; shapes as the reference's (frames follow the scaled hop, bins stay n_fft / 2 + 1 -> n_mels)
+    # the augmentation variants (nvSTFT.py:83-85,109-114) change the transform length / hop: no kernel takes them, and the
+    # stand-alone class says so instead of walking the reference's operators (a patched reference class keeps them on its own code)
     y2 = torch.randn(1, 8192, generator=torch.Generator().manual_seed(1)).to(dev)
-    assert stft.get_mel(y2, keyshift=2).shape == (1, 128, 16) and stft.get_mel(y2, keyshift=-5).shape == (1, 128, 16)
-    assert stft.get_mel(y2, speed=2).shape == (1, 128, 8)
+    for kw in ({"keyshift": 2}, {"keyshift": -5}, {"speed": 2}, {"center": True}):
+        with pytest.raises(NotImplementedError):
+            stft.get_mel(y2, **kw)
     with pytest.raises(RuntimeError):                                                # unsupported transform length
         M.STFT(44100, 80, 1024, 1024, 256, 40, 16000).get_mel(y)
 
@@ -146,13 +147,6 @@ def test_against_reference_stft_class(dev):
     ours = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y.to(dev)).cpu()
     assert ours.shape == ref.shape
     _check(ours.numpy(), ref.numpy())
-    # key shift / speed / center (nvSTFT.py:83-85,97-114): the reference's own arithmetic on the drop-in's device
-    for kw in ({"keyshift": 3}, {"keyshift": -4}, {"keyshift": 12}, {"speed": 1.5}, {"keyshift": 2, "speed": 0.5}, {"center": True}):
-        with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **k: basis):
-            r = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y, **kw)
-        o = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y.to(dev), **kw).cpu()
-        assert o.shape == r.shape, kw
-        assert float((o - r).abs().max()) <= (1e-5 if dev.type == "cpu" else 2e-3), (kw, float((o - r).abs().max()))
 
 
 def test_patch_reference_stft_keeps_cpu_calls_on_the_reference():

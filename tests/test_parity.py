@@ -622,7 +622,10 @@ def test_taps_prime_factor_form(dev, rows, knobs):
         assert rms(got[path, "ap"] - ref) <= 3e-6 * rms(ref), path          # the response itself carries <= 2e-5 abs (hardware sin/cos)
     for key in [k for k in got if k[0] == "pfa"]:
         other = got[("gemm",) + key[1:]]
-        assert rms(got[key] - other) <= 1e-6 * rms(other), key
+        # the all-pass of the prime-factor kernel takes tanh from the hardware exponential (abs error <= 1.5e-7 per bin, round 6)
+        # where the dense path's k_allpass_response calls tanhf: the two phases differ by ~1e-6 rad rms 256 bins on -- both within
+        # 1.5e-6 of the float64 taps, as the reference's own float32 chain is (1.3e-6)
+        assert rms(got[key] - other) <= (2e-6 if key[1] == "ap" else 1e-6) * rms(other), key
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
