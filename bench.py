@@ -249,6 +249,64 @@ def live_traffic(model, extra_args=()):
     return res
 
 
+def in_step_kernel_times(model, extra_args=(), steps=900, stats_out=None):
+    """Average duration of every ddsp:: kernel INSIDE the step at the clocks' steady state: one ``rocprofv3 --kernel-trace`` pass
+    (no counters) over ``bench.py --model M --only-steps --steps 900``, the LAST third of each kernel's launches (a process's first
+    ~100 steps are a transient -- a filter launch goes 77 -> 100 -> 72 us while the clocks settle, profiles/r06_v6_*, r06_v7_* --
+    and every trace of rounds 2 - 5 was 12 - 24 steps long: the "in-step penalty" those rounds chased was that transient).
+    Returns {kernel: {"avg_us", "launches_per_step", "avg_us_all"}} or None.  ``stats_out``: also write the
+    ``rocprofv3 --stats``-style table of the WHOLE trace there (what profiles/*_kernel_stats.csv holds)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    warm = 10
+    d = tempfile.mkdtemp(prefix="ddsp_trace_", dir="/tmp")
+    try:
+        cmd = [rocprof, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--model", model,
+               "--only-steps", "--steps", str(steps), "--warmup", str(warm), *extra_args]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None
+        c = sqlite3.connect(dbs[0])
+        rows = c.execute("select name, start, end from kernels order by start").fetchall()
+        c.close()
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    per = {}
+    for name, s0, e0 in rows:
+        if "ddsp::" not in name:
+            continue
+        per.setdefault(name.split("(")[0].split("ddsp::")[-1].strip(), []).append((e0 - s0) / 1e3)
+    out = {}
+    for k, v in per.items():
+        if k == "k_ir_table" or len(v) < steps:
+            continue
+        tail = v[-(len(v) // 3):]
+        out[k] = {"avg_us": sum(tail) / len(tail), "launches_per_step": round(len(v) / float(steps + warm), 3),
+                  "avg_us_all": sum(v) / len(v), "launches_traced": len(v)}
+    if stats_out:
+        tot = sum(sum(v) for v in per.values()) or 1.0
+        lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent,avg_us_last_third"]
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            t3 = v[-max(1, len(v) // 3):]
+            lines.append('"%s",%d,%.1f,%.2f,%.2f,%.2f,%.2f,%.2f' % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100.0 * sum(v) / tot,
+                                                                  sum(t3) / len(t3)))
+        with open(stats_out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return out or None
+
+
 def traffic_of(kernel, model, live):
     """(per-launch traffic of ``kernel``, whole-step traffic, source) from the live measurement if there is one, else from
     the newest committed summary"""
@@ -341,7 +399,7 @@ def also_lines(a, device, B, F, n, want_traffic):
         "steps": steps, "warmup": warm, "ms_per_step": ms, "ms_per_step_events": ev_ms, "dtype": "f32",
         "config": {"workload": "sins B=%d x %.0f s utterances (F=%d, T=%d), %d harmonics, n_mag %d/%d, DSP path from resident "
                                "f0 / raw controls / uniform noise, signal only (BASELINE cfg 3)" % (B, a.seconds, F, T, n, n, n)},
-        "roofline": {"kernel": "k_sins_bank3", "bound": "hbm", "achieved": bank_bytes / (bank_ms * 1e-3) / 1e9, "peak": 8000.0,
+        "roofline": {"kernel": "k_sins_bank3", "bound": "valu", "achieved": bank_bytes / (bank_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": bank_bytes / (bank_ms * 1e-3) / 1e9 / 8000.0,
                      "traffic": kt["bytes"] if kt else None, "traffic_source": src,
                      "algorithmic_bytes_per_launch": bank_bytes, "avg_ms": bank_ms, "launches_per_step": 1,
@@ -371,6 +429,11 @@ def also_lines(a, device, B, F, n, want_traffic):
                      "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_per_step": 1}}
     del step, inp, y, exc, c
+    # ---- a training step of the DSP (solver.py:93-103 calls the same forward with gradients): forward + backward of the CombSub
+    # tail w.r.t. its three raw controls, cotangent = a fixed random [B, T]; GATED like the headline: utterance 0's three gradients
+    # of the last timed step against the oracle's float64 adjoint (oracle.combsub_dsp_backward, pinned to the reference's own
+    # autograd by tests/test_oracle_golden.py::test_combsub_tail_adjoint) <= 1e-4 relative each, else no line
+    out["train_combsub"] = train_line(a, device, B, F, n, steps, warm)
     # ---- the training loss of the reference (train.py:69): RSSLoss, 4 scales of arbitrary (here: three prime) size
     from ddsp_svc_amd import loss as L
     g = torch.Generator(device="cpu").manual_seed(99)
@@ -399,6 +462,42 @@ def also_lines(a, device, B, F, n, want_traffic):
     return out
 
 
+def train_line(a, device, B, F, n, steps, warm):
+    """``also.train_combsub``: forward + backward of the CombSub DSP (torch.autograd.grad through synth.combsub_synth) at the
+    headline shape, behind a gradient parity gate against the oracle."""
+    from ddsp_svc_amd import synth
+    from oracle import ddsp_oracle as O
+    T = F * HOP
+    f0, ctrls, noise = make_inputs("combsub", B, F, model_sizes("combsub", n), device, seed=777)
+    c = [x.clone().requires_grad_(True) for x in ctrls]
+    g = torch.Generator(device="cpu").manual_seed(778)
+    R = torch.randn(B, T, generator=g).to(device)
+
+    def step():
+        st = synth.phase(f0, SR, HOP)
+        sig = synth.combsub_synth(f0, st, c[0], c[1], c[2], noise, SR, HOP)[0]
+        return torch.autograd.grad((sig * R).sum(), c)
+    prewarm(step, min(a.prewarm_seconds, 0.3))
+    el, ev_ms, grads = time_steps(step, steps, warm, torch.cuda.synchronize)
+    t0 = time.perf_counter()
+    host = lambda t: np.ascontiguousarray(t[0:1].detach().cpu().numpy())
+    want = O.combsub_dsp_backward(host(R), host(f0), host(c[0]), host(c[1]), host(c[2]), host(noise), SR, HOP)
+    errs = {}
+    for gk, k in zip(grads, ("group_delay", "harmonic_magnitude", "noise_magnitude")):
+        got = gk[0:1].detach().cpu().numpy().astype(np.float64)
+        errs[k] = float(np.sqrt(np.mean((got - want[k]) ** 2)) / max(float(np.sqrt(np.mean(want[k] ** 2))), 1e-30))
+    rec = {"rows": [0], "rel_rms": errs, "bar_rel": 1e-4, "seconds": time.perf_counter() - t0,
+           "oracle": "oracle/ddsp_oracle.py combsub_dsp_backward (float64 adjoint, pinned to the reference's autograd fixture)"}
+    if not all(np.isfinite(v) and v <= 1e-4 for v in errs.values()):
+        raise SystemExit("bench.py: the timed training step's gradients are NOT the reference's: %s" % json.dumps(rec))
+    return {"metric": "audio samples/sec, CombSub DSP forward+backward 44.1kHz 256-harm hop512", "value": B * T * steps / el,
+            "unit": "samples/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3, "ms_per_step_events": ev_ms,
+            "dtype": "f32", "parity_vs_oracle": rec,
+            "config": {"workload": "combsub B=%d x %.0f s (F=%d, T=%d), n_mag %d/%d/%d: phase + DSP tail forward, then "
+                                   "torch.autograd.grad of sum(signal * R) w.r.t. the three raw controls (solver.py:93-103's "
+                                   "use of the path, without the network and the loss)" % (B, a.seconds, F, T, n, n, n)}}
+
+
 def cfg4_line(a, rank, world, device, F, n, comm):
     """BASELINE cfg 4 (combsub, 512 utterances sharded over 8 GPUs = 64 per GPU, RCCL gather over xGMI): samples/s of the
     sharded synthesis alone (A) and with the gather of every step's waveforms to rank 0 (B), max over ranks.  Measured as
@@ -419,7 +518,11 @@ def cfg4_line(a, rank, world, device, F, n, comm):
         # costs the gather column, not the line)
         try:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
+            if "MASTER_PORT" not in os.environ:                          # a free port: two benches on one host do not collide
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             RT.init_process_group(rank, world, device)
             probe = torch.ones(1, device=device)
             dist.all_reduce(probe)
@@ -442,17 +545,36 @@ def cfg4_line(a, rank, world, device, F, n, comm):
 
     def step_g():
         return sharding.gather_utterances(step(), B4 * world, dst=0)
+
+    # the gather as a pipelined serving loop could issue it: step k's waveforms travel (async collective on the communicator's
+    # stream) while step k + 1 is synthesised; a step's result is taken one step later; the timed region ends with the last gather
+    # drained.  Measured beside the plain form because at ONE rank it LOSES (the "gather" is a 113 MB device-to-device copy whose
+    # blit competes with the synthesis for the same CUs and HBM: +0.056 ms per step against +0.037 waited for in line, r06_v13);
+    # over xGMI the transfer (7 x 113 MB into rank 0) is several steps long whichever way it is issued.
+    pending = [None]
+
+    def step_async():
+        y = step()
+        fin, _ = sharding.gather_utterances(y, B4 * world, dst=0, async_op=True)
+        prev, pending[0] = pending[0], fin
+        return prev() if prev is not None else y
+
+    def fence_g():
+        if pending[0] is not None:
+            pending[0]()
+            pending[0] = None
+        fence()
     prewarm(step, min(a.prewarm_seconds, 0.3))
-    forms = [("plain", step)] + ([("gather", step_g)] if have_pg else [])
-    wall = {k: [] for k, _ in forms}
-    ev = {k: [] for k, _ in forms}
-    for _, fn in forms:                                                  # warm-up of both forms (allocator, communicator buffers)
+    forms = [("plain", step, fence)] + ([("gather", step_g, fence), ("gather_async", step_async, fence_g)] if have_pg else [])
+    wall = {k: [] for k, _, _ in forms}
+    ev = {k: [] for k, _, _ in forms}
+    for _, fn, fc in forms:                                              # warm-up of every form (allocator, communicator buffers)
         for _ in range(3):
             out = fn()
-    fence()
+        fc()
     for _ in range(rounds):
-        for k, fn in forms:
-            el, ev_ms, out = time_steps(fn, per, 0, fence)
+        for k, fn, fc in forms:
+            el, ev_ms, out = time_steps(fn, per, 0, fc)
             el, ev_ms = reduce_max(el, ev_ms)
             wall[k].append(el / per * 1e3)
             ev[k].append(ev_ms)
@@ -461,7 +583,7 @@ def cfg4_line(a, rank, world, device, F, n, comm):
     res = {"workload": "combsub B=%d/GPU x %.0f s on %d GPU(s): %d utterances, n_mag %d/%d/%d (BASELINE cfg 4)"
                        % (B4, a.seconds, world, B4 * world, n, n, n),
            "batch_per_gpu": B4, "n_gpus": world, "steps": per * rounds, "rounds": rounds, "steps_per_round": per, "warmup": 3,
-           "method": "interleaved rounds (plain, gather, plain, ..) of %d steps after clock ramp-up; medians over rounds" % per,
+           "method": "interleaved rounds (plain, gather, gather_async, plain, ..) of %d steps after clock ramp-up; medians over rounds" % per,
            "ms_per_step": ms, "ms_per_step_events": med(ev["plain"]), "value": B4 * world * T / (ms * 1e-3), "unit": "samples/s",
            "rounds_ms": [round(v, 4) for v in wall["plain"]], "rccl_ranks": comm.get("rccl_ranks")}
     if have_pg:
@@ -482,10 +604,14 @@ def cfg4_line(a, rank, world, device, F, n, comm):
                     "rounds_ms_with_gather": [round(v, 4) for v in wall["gather"]],
                     "gather_ms": g_alone,
                     "gather_overhead_ms": med([g - p for g, p in zip(wall["gather"], wall["plain"])]),
+                    "ms_per_step_with_gather_async": med(wall["gather_async"]),
+                    "gather_async_overhead_ms": med([g - p for g, p in zip(wall["gather_async"], wall["plain"])]),
                     "gather_bytes_per_rank": 4.0 * B4 * T,
                     "gather": "torch.distributed.gather (%s) of every step's [%d, T] waveforms into slices of the "
-                              "result on rank 0; gather_ms = one gather alone between fences (median of 3), "
-                              "gather_overhead_ms = median of the rounds' paired differences (what a step pays for it)"
+                              "result on rank 0, waited for before the next step starts; *_async: step k's gather issued async, "
+                              "running under step k + 1's synthesis and waited for one step later (the last one inside the timed "
+                              "region); gather_ms = one gather alone between fences "
+                              "(median of 3), gather_overhead_ms = median of the rounds' paired differences (what a step pays)"
                               % ("nccl = RCCL" if RT.backend == "nccl" else RT.backend, B4)})
     else:
         res["gather"] = "not timed: no process group (%s)" % comm.get("cfg4_communicator_error", "--no-cfg4-gather")
@@ -1423,6 +1549,10 @@ def main(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the rocprofv3 PMC passes; report the newest committed traffic summary instead")
     ap.add_argument("--no-also", action="store_true", help="skip the Sins (cfg 3) / CombSubSuperFast lines of the N = 1 run")
+    ap.add_argument("--no-in-step-trace", action="store_true",
+                    help="do not run the kernel-trace pass that measures the dominant kernel inside the step (roofline.frac then uses the stand-alone time)")
+    ap.add_argument("--trace-stats-out", default=None,
+                    help="write the per-kernel table of the in-step kernel-trace pass there (what profiles/*_kernel_stats.csv holds)")
     ap.add_argument("--cfg4", action="store_true",
                     help="also run BASELINE cfg 4's per-GPU shape (64 utterances per GPU) -- default at --gpus 8")
     ap.add_argument("--cfg4-batch", type=int, default=64, help="utterances per GPU of the cfg-4 line (BASELINE: 64)")
@@ -1550,9 +1680,20 @@ def main(argv=None):
                                                                                    and not a.no_also))
     cfg4 = cfg4_line(a, rank, world, device, F, n, comm) if want_cfg4 else None
     # parity gate: rank 0's timed output against the oracle BEFORE any number is printed
-    parity = None
+    parity, gate_fail = None, None
     if rank == 0 and not a.no_parity_gate:
-        parity = parity_gate(a.model, f0, ctrls, noise, out)
+        try:
+            parity = parity_gate(a.model, f0, ctrls, noise, out)
+        except SystemExit as e:
+            gate_fail = str(e)
+    if world > 1:                                    # the verdict reaches every rank: nobody is left waiting in a collective
+        flag = torch.tensor([1.0 if gate_fail else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) != 0.0:
+            finish_ranks()
+            raise SystemExit(gate_fail or "bench.py: rank 0's parity gate failed")
+    elif gate_fail:
+        raise SystemExit(gate_fail)
     # arithmetic the FFT forms actually execute (5 N log2 N per complex transform + spectral products): per frame pair
     # three 2048-point transforms (k_fir_fft) or per hop-block pair four 1024-point ones (k_fir_blk)
     if used_impl == 5:
@@ -1570,6 +1711,20 @@ def main(argv=None):
         live = live_traffic(a.model, ("--fir-impl", str(a.fir_impl)) if a.fir_impl else ()) if want_live else None
         traffic, tr, traffic_source = traffic_of(kname, a.model, live) if headline_shape else (None, None, None)
         alg_bytes = (8.0 + 4.0 * (sigma_c + 1) / HOP) * B * T          # out + noise + controls + f0
+        # the dominant kernel INSIDE the step at the clocks' steady state (a kernel-trace pass of this run): what `roofline.frac` is
+        # made of.  SURVEY 8-d bytes of ONE filter: input + output + its n control bins per frame (the tap rows are an intermediate,
+        # not algorithmic bytes); a launch of the fused layout carries one or two filters, so per launch: x filters / launches.
+        want_trace = world == 1 and not a.no_live_traffic and not a.no_in_step_trace
+        instep = in_step_kernel_times(a.model, ("--fir-impl", str(a.fir_impl)) if a.fir_impl else (), stats_out=a.trace_stats_out) \
+            if want_trace else None
+        ks = next((v for k_, v in (instep or {}).items() if k_.startswith(kname.rstrip("<"))), None)
+        filt_bytes = (8.0 + 4.0 * n / HOP) * B * T
+        if ks:
+            per_launch = fir_launches / ks["launches_per_step"]          # filters per launch (1.5 in the fused CombSub step)
+            k_us, k_src = ks["avg_us"], "in-step: rocprofv3 --kernel-trace pass of this run, last third of %d launches" % ks["launches_traced"]
+        else:
+            per_launch, k_us, k_src = 1.0, fir_ms * 1e3, "alone (no in-step trace in this run): HIP events around 20 back-to-back launches"
+        k_bytes, k_flops = filt_bytes * per_launch, fft_flops * per_launch
         res = {
             "metric": "audio samples/sec, CombSub 44.1kHz 256-harm hop512" if a.model == "combsub"
                       else "audio samples/sec, Sins 44.1kHz 256-harm hop512",
@@ -1581,16 +1736,26 @@ def main(argv=None):
                                    "DSP path (HOT-1 + HOT-2) from resident f0 / raw controls ~N(0,1) / uniform noise, "
                                    "signal only" % (a.model, B, a.seconds, F, T, n, n, n),
                        "batch_per_gpu": B, "frames": F, "samples_per_utterance": T, "parallelism": "utterance-shard x%d" % world},
-            "roofline": {"kernel": kname.rstrip("<"), "bound": "hbm", "achieved": fir_bytes / (fir_ms * 1e-3) / 1e9, "peak": 8000.0,
-                         "unit": "GB/s", "frac": fir_bytes / (fir_ms * 1e-3) / 1e9 / 8000.0,
-                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
-                         "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": fir_bytes, "avg_ms": fir_ms, "launches_per_step": fir_launches,
-                         "note": "north-star roofline (algorithmic HBM bytes / time; avg_ms from HIP events around 20 "
-                                 "back-to-back launches of the kernel on resident data; inside a step, after other "
-                                 "kernels, the rocprofv3 trace reads a few per cent more: profiles/*_kernel_stats.csv).  "
-                                 "The kernel is NOT HBM-bound: see roofline_compute for the roof that "
-                                 "binds it (DESIGN.md section 5)"},
+            "roofline": {"kernel": kname.rstrip("<"), "bound": "valu",
+                         "achieved": k_bytes / (k_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": k_bytes / (k_us * 1e-6) / 1e9 / 8000.0,
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": k_bytes, "algorithmic_bytes_per_filter": filt_bytes,
+                         "avg_us": k_us, "avg_source": k_src, "filters_per_step": fir_launches,
+                         "launches_per_step": ks["launches_per_step"] if ks else fir_launches, "filters_per_launch": per_launch,
+                         "valu_frac": k_flops / (k_us * 1e-6) / 1e12 / 157.3, "valu_peak_TFLOPs": 157.3,
+                         "frac_alone": filt_bytes / (fir_ms * 1e-3) / 1e9 / 8000.0, "avg_ms_alone": fir_ms, "avg_ms": fir_ms,
+                         "step_hbm_frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0,
+                         "step_traffic_ratio": (tr["hbm_bytes"] / alg_bytes) if tr else None,
+                         "in_step_kernels": instep,
+                         "note": "frac = SURVEY 8-d algorithmic HBM bytes of what one launch of the dominant kernel processes / its "
+                                 "average duration INSIDE the step (steady state) / 8 TB/s.  `bound` names the roof that binds the kernel: "
+                                 "the vector ALU's issue rate (valu_frac = executed FFT flops / time / 157.3 TFLOP/s; butterflies are "
+                                 "add / sub / mul, no FMA: at most half of that peak is attainable), not HBM -- a fused DSP path is at "
+                                 "0.1 - 0.3 of the HBM roof by construction (SURVEY 8-d).  frac_alone: one filter timed alone (HIP events, "
+                                 "20 back-to-back launches).  step_hbm_frac / step_traffic_ratio: the WHOLE step's algorithmic bytes over "
+                                 "its wall time, and its PMC bytes over its algorithmic bytes -- the path's HBM numbers; frac is one "
+                                 "kernel's."},
             "roofline_compute": (
                 {"kernel": kname.rstrip("<"), "bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
                  "achieved": fft_flops / (fir_ms * 1e-3) / 1e12, "frac": fft_flops / (fir_ms * 1e-3) / 1e12 / 157.3,

@@ -47,7 +47,10 @@ __global__ void __launch_bounds__(256) k_remove_above_fmax(const float* __restri
 // ------------------------------------------------------------------------------------------------
 // level 1+2: per-frame totals of f0[t]/sr.  One wave per frame, lane owns SPL consecutive samples.
 // ------------------------------------------------------------------------------------------------
-constexpr int PH_FRAMES_PER_WAVE = 4;                // consecutive frames a wave walks: amortises the launch of tiny workgroups
+#ifndef DDSP_PH_FPW
+#define DDSP_PH_FPW 4
+#endif
+constexpr int PH_FRAMES_PER_WAVE = DDSP_PH_FPW;      // consecutive frames a wave walks: amortises the launch of tiny workgroups
 
 template <int SPL, bool POW2>
 __global__ void __launch_bounds__(256) k_phase_frame_sums(const float* __restrict__ f0_frames, long n_frames, int F,

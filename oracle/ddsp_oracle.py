@@ -739,6 +739,33 @@ def impulse_response_backward(d_taps, mode: int, half_width=None):
     return d_re, d_im
 
 
+def combsub_dsp_backward(grad_out, f0_frames, c_gd, c_harm, c_noise, noise, sr=44100, hop=512, initial_phase=None, infer=True):
+    """What autograd returns for the three raw controls of ``combsub_dsp`` (the DSP tail of CombSub.forward,
+    vocoder.py:834-862) given ``grad_out = dL/dsignal [B,T]``: the adjoints above chained backwards through the cascade
+    all-pass filter -> dynamic-window filter, and through the noise branch.  float64; returns
+    ``dict(group_delay, harmonic_magnitude, noise_magnitude)``, each ``[B,F,n]``.  Pinned to the reference's own autograd by
+    tests/test_oracle_golden.py (fixture combsub_grad.npz)."""
+    g = np.asarray(grad_out, dtype=F64)
+    x, _ = wrapped_phase(f0_frames, sr, hop, initial_phase, infer)
+    comb = combtooth(x, f0_frames, sr, hop)
+    are, aim = allpass_response(c_gd)
+    taps_ap = impulse_response(are, aim, MODE_ROLL)
+    h1 = ltv_fir_blockfft(comb, taps_ap)
+    src = np.exp(np.asarray(c_harm, dtype=F32).astype(F64))
+    hw = combsub_half_width(f0_frames, sr)
+    taps_h = impulse_response(src, None, MODE_DYNAMIC, hw)
+    nz_mag = np.exp(np.asarray(c_noise, dtype=F32).astype(F64)) / 128.0
+    taps_nz = impulse_response(nz_mag, None, MODE_HANN)
+    d_h1, d_taps_h = ltv_fir_backward(g, h1, taps_h)
+    d_src, _ = impulse_response_backward(d_taps_h, MODE_DYNAMIC, hw)
+    _, d_taps_ap = ltv_fir_backward(d_h1, comb, taps_ap)
+    d_re, d_im = impulse_response_backward(d_taps_ap, MODE_ROLL)
+    _, d_taps_nz = ltv_fir_backward(g, np.asarray(noise, dtype=F64), taps_nz)
+    d_nz, _ = impulse_response_backward(d_taps_nz, MODE_HANN)
+    return dict(group_delay=allpass_backward(c_gd, d_re, d_im), harmonic_magnitude=d_src * src,       # d exp(c) = exp(c)
+                noise_magnitude=d_nz * nz_mag)
+
+
 def allpass_backward(gd_ctrl, d_re, d_im):
     """Adjoint of ``allpass_response``: gradients of (cos theta, sin theta), ``theta = cumsum(pi tanh(c))``, back to
     the raw group-delay control ``c`` (vocoder.py:581,599 / :834,845)."""

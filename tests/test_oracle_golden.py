@@ -87,6 +87,17 @@ def test_combsub_tail(golden_dir, name, infer):
         assert rms(r[k] - g[gk]) <= 5e-6 * rms(g[gk]), (k, rms(r[k] - g[gk]), rms(g[gk]))
 
 
+def test_combsub_tail_adjoint(golden_dir):
+    """the composed adjoint (what bench.py's training row is gated on) against the gradients the REFERENCE's autograd
+    produced through ddsp.vocoder.CombSub's own DSP tail (make_golden.py, combsub_grad.npz)"""
+    g = _load(golden_dir, "combsub_grad.npz")
+    got = O.combsub_dsp_backward(g["cotangent"], g["f0_frames"], g["ctrl_group_delay"], g["ctrl_harmonic_magnitude"],
+                                 g["ctrl_noise_magnitude"], g["noise"])
+    for k in ("group_delay", "harmonic_magnitude", "noise_magnitude"):
+        ref = g["grad_" + k]
+        assert rms(got[k] - ref) <= 2e-5 * rms(ref), (k, rms(got[k] - ref), rms(ref))
+
+
 # ---- SURVEY.md 8-f #1: CombSubFast / CombSubSuperFast -------------------------------------------
 def test_fast_source_gen(golden_dir):
     g = _load(golden_dir, "fastsrc.npz")
