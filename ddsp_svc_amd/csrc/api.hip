@@ -16,7 +16,7 @@ thread_local int t_geometry_batch = 0;
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 void knobs_from_env() {
@@ -253,6 +253,21 @@ void synth_allpass_taps(const float* c_gd, long ld_gd, const float* table, long 
 bool fused_off() {
   const long v = knob(KNOB_STREAM_LAYOUT);
   return v == 1 || v == 4;
+}
+
+// does a CombSub / Sins call of this shape take the fused one-stream layout (combsub_rows / sins_rows)?  One predicate for the
+// launch path and for ddsp_hip_tail_layout, which tells a training caller where the call left its intermediates.
+bool fused_shape_ok(long R, int F, int hop, int n0, int n1, int n2, int fir_impl, bool gen_on, bool combsub) {
+  if (!(R < kSmallRows || !fused_off()) || hop != 512 || t_taps_gemm || knob(KNOB_SMALL_PATH) == 1) return false;
+  if (combsub) {
+    if (n0 != 256 || n1 != 256 || n2 != 256 || gen_on || !(fir_impl == 0 || fir_impl == 5)) return false;
+    if ((long)F * hop > (1L << 24) || R >= (1L << 31) - 64) return false;       // the exciter job's shift form (make_exciter_job)
+#ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: launch_fir_blk's predicate)
+    if (!((knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0)) return false;
+#endif
+    return true;
+  }
+  return n1 == 256 && n2 == 256;                              // Sins: all-pass and noise filter at 256 bins (n0 = harmonics)
 }
 
 size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
@@ -592,7 +607,7 @@ int sins_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
   // The fused layout (as combsub_rows below; round 6: at every shape): both tap syntheses in one launch -- four dependent
   // launches on the caller's stream: sinusoid bank | taps (grid.y) | noise filter | all-pass filter + noise.  Same kernels, same
   // arguments, same bits as the two-stream layout below.  [MI355X] B = 32 x 10 s, same box: 0.3367 -> 0.3212 ms (r06_v10s_*).
-  if ((R < kSmallRows || !fused_off()) && n_ap == 256 && n_nz == 256 && !t_taps_gemm && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
+  if (fused_shape_ok(R, F, hop, H, n_ap, n_nz, a.fir_impl, a.gen.on != 0, false)) {
     const int r = launch_sins_bank(a.f0_frames, a.initial_phase, a.c0, a.ld0, B, F, hop, H, a.sr, a.infer, a.phase0, w.buf0, st);
     if (r == -1) return DDSP_HIP_EHOP;
     if (r == -2) return DDSP_HIP_ESHAPE;
@@ -649,12 +664,7 @@ int combsub_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream
   // the hardware-queue question of round 5 (GPU_MAX_HW_QUEUES) are gone from this path.
   // Same kernels, same arguments as the layouts below (same bits below 4096 frames: tests/test_small_shapes.py; above, the paired
   // filters' run split differs: rounding-level); knob SMALL_PATH = 1: never; knob STREAM_LAYOUT = 1 / 4: not at batch shapes.
-  if ((R < kSmallRows || !fused_off()) && all256 && hop == 512 && !a.gen.on && (a.fir_impl == 0 || a.fir_impl == 5) && w.taps3 &&
-      knob(KNOB_SMALL_PATH) != 1
-#ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: the same
-      && (knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0        //  predicate as launch_fir_blk's)
-#endif
-      ) {
+  if (w.taps3 && fused_shape_ok(R, F, hop, n_ap, n_harm, n_nz, a.fir_impl, a.gen.on != 0, true)) {
     ExciterJob exc;
     if (make_exciter_job(a.f0_frames, a.initial_phase, B, F, hop, a.sr, a.infer, a.phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
     TapsJobs jobs;
@@ -729,6 +739,30 @@ size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max) {
   size_t end = 0;
   for (int l = 0; l < p.slots; ++l) end = carve_synth(c, p.Bs, F, hop, n_max, w);
   return end;
+}
+
+int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int n2, int fir_impl, int in_kernel_noise,
+                         long long offsets[6]) {
+  if (!offsets || B <= 0 || F <= 0 || hop <= 0) return DDSP_HIP_EINVAL;
+  for (int i = 0; i < 6; ++i) offsets[i] = -1;
+  const TapsFormScope form;
+  int n_max = n1 > n2 ? n1 : n2;
+  if (combsub && n0 > n_max) n_max = n0;
+  if (lane_plan(B, F).nsub > 1) return 0;                      // sub-batches on lanes: slots are re-used, nothing survives the call
+  if (!fused_shape_ok((long)B * F, F, hop, n0, n1, n2, fir_impl, in_kernel_noise != 0, combsub != 0)) return 0;
+  constexpr uintptr_t kBase = 4096;                            // a carve over a pretend base: offsets = pointers - base, null = absent
+  Carver c(reinterpret_cast<void*>(kBase), (size_t)1 << 60);
+  SynthWs w;
+  carve_synth(c, B, F, hop, n_max, w);
+  if (combsub && !w.taps3) return 0;
+  auto off = [](const float* p) -> long long { return p ? (long long)(reinterpret_cast<uintptr_t>(p) - kBase) : -1; };
+  offsets[0] = off(w.buf0);                                    // the exciter [B, T]
+  offsets[1] = combsub ? off(w.buf1) : -1;                     // CombSub: the all-pass filter's output [B, T]
+  offsets[2] = off(w.taps);                                    // all-pass taps [B, F, N]
+  offsets[3] = combsub ? off(w.taps3) : -1;                    // CombSub: harmonic (dynamic-window) taps
+  offsets[4] = off(w.taps_nz);                                 // noise taps
+  offsets[5] = off(w.nzbuf);                                   // the filtered noise when no noise output was asked for
+  return 1;
 }
 
 int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,

@@ -137,7 +137,8 @@ struct Plan1024P {
   //     interval 3                                       u: Y -> last column, lane-pair step (done)
   // Y and Q must be free of readers on entry (Q: by the first barrier), X becomes free at the first barrier; on return X and
   // Q are free and Y may still be read by slower waves.
-  template <bool FLIP = false>
+  // U_FULL: u is a full 1024-point input (k_fir_blk_bwd6's cotangent pair) instead of one zero-padded to twice its length
+  template <bool FLIP = false, bool U_FULL = false>
   static __device__ __forceinline__ void transposed_then_forward_s(f32x2 (&v)[8], f32x2 (&u)[8], const Tw& tw, f32x2* Y, f32x2* X,
                                                                    f32x2* Q, const Ix& ix) {
     DDSP_P_MATH({
@@ -151,7 +152,8 @@ struct Plan1024P {
 #pragma unroll
     for (int k = 0; k < 8; ++k) DDSP_P_LD(v[k], Y + ix.r3 + k * C);
     DDSP_P_MATH({
-    dft8_lo4(u);
+    if (U_FULL) dft8(u);
+    else dft8_lo4(u);
     twiddle7x2(v, tw.w2, u, tw.w1);
     dft8(v);
     });

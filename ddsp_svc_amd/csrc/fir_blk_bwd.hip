@@ -22,8 +22,9 @@
 //   starts one pair early to rebuild it (and the tap / cotangent spectra), storing nothing.  No overlap-add, no atomics:
 //   every tap row and every input block is written by exactly one workgroup.  Spectra live in the sign-carrying layout S-
 //   of fft_r.h; products of two of them are plain layout S.
-#include "fft_r.h"
+#include "fft_1024p.h"
 #include "kernels.h"
+#include "tuning.h"
 #include <stdlib.h>
 
 namespace ddsp {
@@ -329,6 +330,185 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
   }
 }
 
+// ---- the tap gradient alone at three waves per SIMD (round 6) -------------------------------------------------------------
+// Two of a training step's three filter adjoints need no input gradient (the noise filter's input is data, the all-pass filter's
+// the exciter): four transforms per block pair, the forward kernel's count -- and k_fir_blk_bwd<false> above, round 3's form (226+
+// registers, four 1024-word exchange buffers: two waves per SIMD), took 116 us where the forward filter takes 72.  This is
+// k_fir_blk6's shape (fir_blk.hip) applied to it: the padded plan of fft_1024p.h, three exchange buffers, the two block transforms
+// one after the other, the pair's inverse and the NEXT pair's cotangent transform staggered on three buffers, and the cotangent
+// spectra S_b0, S_b0+1 NOT kept in registers: the packed transform C = FFT(seg_b0 + i seg_b0+1) stays parked in its buffer and
+// the product sweep splits it bin by bin where it consumes it (own value and mirror image, as the forward kernel's tap
+// transform).  Carried between passes: U of the pair's second block (16 registers, the forward kernel's Hc).  Every load is
+// issued a pass ahead.  Same operator, same geometry rules, rounding-level differences to the two-wave kernel (knob BWD_WPS = 2).
+template <int DUMMY = 0>
+__global__ void __launch_bounds__(128, 3) k_fir_blk_bwd6(const float* __restrict__ x, int x_is_u01, const float* __restrict__ grad_out,
+                                                        float* __restrict__ d_taps, FirBwdGeom g) {
+  using PL = fft::Plan1024P;
+  constexpr int NF = PL::N, P = PL::P, S = 8;
+  __shared__ __attribute__((aligned(16))) f32x2 ex[3][PL::WORDS];
+  f32x2* const bX = ex[0];
+  f32x2* const bY = ex[1];
+  f32x2* const bC = ex[2];
+  const int tid = threadIdx.x;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / g.runs_per_utt);
+  const int run_no = blockIdx.x - b * g.runs_per_utt;
+  const int q_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);          // an utterance's pairs split evenly over its runs
+  const int q_last = (int)(((long)(run_no + 1) * g.pairs) / g.runs_per_utt);
+  const int SH = FBW_HOP / 2 - (g.N >> 1);
+  const float* xb = x + (long)b * g.T;
+  float* dtb = d_taps + (long)b * g.F * g.N;
+  const BufF32 g_buf = BufF32::make(grad_out + (long)b * g.T, g.T);
+  const float sg = (tid & 1) ? -1.0f : 1.0f;
+  const int tid4 = 4 * tid;
+  const float lam0 = (float)tid * (1.0f / (float)FBW_HOP);
+  int tap_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = P * m + tid - SH;
+    tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+  }
+  struct Four { float v[4]; };
+  auto load_blk = [&](int bi, bool live = true) -> Four {
+    Four r;
+    const bool in = live && bi >= 0 && bi < g.F;
+    const BufF32 xr = BufF32::make(xb + (long)(in ? bi : 0) * FBW_HOP, in ? FBW_HOP : 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
+    return r;
+  };
+  struct Seg { float v[12]; };
+  auto load_seg = [&](int qn, bool live = true) -> Seg {       // L[i] = grad_out[(2 qn - 1/2) hop + 128 i + tid], i = 0..11
+    Seg r;
+    const int t0 = 2 * qn * FBW_HOP - FBW_HOP / 2;
+    const BufF32 gb = live ? g_buf : BufF32::make(grad_out, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int t = t0 + P * i;
+      r.v[i] = gb.ld(t >= 0 ? 4 * (t + tid) : BufF32::kOutOfRange);
+    }
+    return r;
+  };
+  auto pack_seg = [&](const Seg& s, f32x2 (&z)[S]) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) z[m] = f32x2{s.v[m], s.v[m + 4]};
+  };
+  auto pack_blk = [&](const Four& cx, bool live, f32x2 (&z)[S]) {
+    const bool u01 = x_is_u01 && live;                          // noise = rand * 2 - 1 (vocoder.py:603,854)
+    const float ua = u01 ? 2.0f : 1.0f, ub = u01 ? -1.0f : 0.0f;
+    float l0 = lam0;
+    asm volatile("" : "+v"(l0));                                // not a loop invariant (k_fir_blk6)
+    const f32x2 lp = {-l0, l0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float xv = fmaf(ua, cx.v[m], ub);
+      const f32x2 w = f32x2{1.0f - 0.25f * (float)m, 0.25f * (float)m} + lp;   // (1 - lambda, lambda)
+      z[m] = w * f32x2{xv, xv};
+    }
+#pragma unroll
+    for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
+  };
+  const int kS0 = PL::s_index(tid, 0);
+  const int kP0 = PL::parked(kS0);
+  const int mb = PL::mirror_base(tid);
+  auto mirrored = [&](const f32x2* X, int m) -> f32x2 { return PL::rd_parked(X + mb - 64 * m); };
+  const bool own_mirror = tid < 2;
+  auto park = [&](const f32x2 (&z)[S], f32x2* X) {
+#pragma unroll
+    for (int m = 0; m < S; ++m) X[kP0 + 64 * m] = z[m];
+  };
+  const float cs = 0.5f / (float)NF;                           // the 1/2 of the Hermitian combination N + conj M and the 1/N of the inverse
+  const f32x2 kHa = {0.5f * cs, 0.5f * cs};
+  const f32x2 kMi = {0.5f * cs, -0.5f * cs};
+
+  typename PL::Tw tw;
+  typename PL::Ix ix;
+  // the warm-up pass q_first - 1 rebuilds the carried U of block 2 q_first - 1; its cotangent pair is transformed here
+  Seg sgm = load_seg(q_first - 1);
+  Four x0 = load_blk(2 * q_first - 2), x1 = load_blk(2 * q_first - 1);
+  tw.init(tid);
+  ix.init(tid);
+  {
+    f32x2 zc[S];
+    pack_seg(sgm, zc);
+    PL::template forward_s<false, true>(zc, tw, bX, bY, ix);
+    park(zc, bC);
+  }
+  sgm = load_seg(q_first);
+  __syncthreads();
+  f32x2 Uc[S];
+#pragma unroll
+  for (int m = 0; m < S; ++m) Uc[m] = f32x2{0.f, 0.f};
+  for (int q = q_first - 1; q < q_last; ++q) {
+    const bool warm = q < q_first;                              // workgroup-uniform
+    const bool next_pass = q + 1 < q_last, pass_after = q + 2 < q_last;
+    const int b0 = 2 * q;
+    f32x2 z0[S], z1[S];
+    pack_blk(x0, b0 >= 0 && b0 < g.F, z0);
+    x0 = load_blk(b0 + 2, next_pass);
+    PL::template forward_s<true, true>(z0, tw, bX, bY, ix);
+    pack_blk(x1, b0 + 1 >= 0 && b0 + 1 < g.F, z1);
+    x1 = load_blk(b0 + 3, next_pass);
+    PL::template forward_s<true, true>(z1, tw, bX, bY, ix);
+    // one sweep over the bins: split the parked cotangent transform (own value o, mirror image tn: S_b0 = c FFT(seg_b0) =
+    // (o - conj tn) c/2, S_b0+1 = -i (o + conj tn) c/2), U_b = conj(Z_b) S_b, and the two Hermitian combinations of
+    // k_fir_blk_bwd: N stays in z0, M is parked for the mirrored read
+    const bool last0 = b0 == g.F - 1, last1 = b0 + 1 == g.F - 1;      // the held last row (core.py:167) also takes its own block's second term
+    f32x2 M0;
+#pragma unroll
+    for (int m = 0; m < S; m += 2) {
+      const f32x2 o0 = PL::rd_parked(bC + kP0 + 64 * m), o1 = PL::rd_parked(bC + kP0 + 64 * (m + 1));
+      f32x2 tn0 = mirrored(bC, m);
+      const f32x2 tn1 = mirrored(bC, m + 1);
+      if (m == 0) tn0 = own_mirror ? -o0 : tn0;
+      const f32x2 p0 = fft::sub_conj(o0, tn0), p1 = fft::sub_conj(o1, tn1);
+      const f32x2 d0 = fft::add_conj(o0, tn0), d1 = fft::add_conj(o1, tn1);
+      const f32x2 sa0 = p0 * kHa, sa1 = p1 * kHa;
+      const f32x2 sb0 = fft::swap_scale(d0, kMi), sb1 = fft::swap_scale(d1, kMi);
+      const f32x2 l0 = fft::cmul_lo(z0[m], sa0), l1 = fft::cmul_lo(z1[m], sb0);
+      const f32x2 l2 = fft::cmul_lo(z0[m + 1], sa1), l3 = fft::cmul_lo(z1[m + 1], sb1);
+      const f32x2 u00 = fft::cmulc_hi(z0[m], sa0, l0), u10 = fft::cmulc_hi(z1[m], sb0, l1);
+      const f32x2 u01 = fft::cmulc_hi(z0[m + 1], sa1, l2), u11 = fft::cmulc_hi(z1[m + 1], sb1, l3);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x2 U0 = e ? u01 : u00, U1 = e ? u11 : u10;
+        const f32x2 Bj = last0 ? Uc[m + e] + U0 : Uc[m + e];
+        const f32x2 Bj1 = last1 ? U0 + U1 : U0;
+        const f32x2 Pp = Bj + U1, Qq = Bj - U1;
+        const f32x2 T1 = U0 - Bj1, T2 = U0 + Bj1;
+        z0[m + e] = fft::sub_mi(T1, Pp);                        // N = (U_j - B_j+1) + i (B_j + U_j+1)   (the 1/2 is in S)
+        const f32x2 Mv = fft::sub_mi(T2, Qq);                   // M = (U_j + B_j+1) + i (B_j - U_j+1), parked
+        if (m + e == 0) M0 = Mv;
+        bX[kP0 + 64 * (m + e)] = Mv;
+        Uc[m + e] = U1;                                         // carried: U of the pair's second block
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      f32x2 mm = mirrored(bX, m);
+      if (m == 0) mm = own_mirror ? M0 : mm;                    // M is plain layout S: the own value as it is
+      z0[m] = fft::add_conj(mm, z0[m]);                         // conj V = M[-k] + conj N[k]: inverse by the forward transform
+    }
+    // the tap rows' inverse, and one exchange behind it the transform of the next pair's cotangent (a full 1024-point input)
+    f32x2 zc[S];
+    pack_seg(sgm, zc);
+    sgm = load_seg(q + 2, pass_after);
+    PL::template transposed_then_forward_s<true, true>(z0, zc, tw, bY, bX, bC, ix);
+    park(zc, bC);                                               // read by the next pass's sweep, behind its first stage's barriers
+    // d_taps[j][i] = d h_j[i + SH]: transform index n = 128 m + tid < 512; row b0 = sigma Re, row b0 + 1 = -sigma Im
+    {
+      const bool own0 = !warm && b0 < g.F, own1 = !warm && b0 + 1 < g.F;
+      const BufF32 r0 = BufF32::make(dtb + (long)(own0 ? b0 : 0) * g.N, own0 ? g.N : 0);
+      const BufF32 r1 = BufF32::make(dtb + (long)(own1 ? b0 + 1 : 0) * g.N, own1 ? g.N : 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        r0.st(sg * z0[m].x, tap_off[m]);
+        r1.st(-sg * z0[m].y, tap_off[m]);
+      }
+    }
+  }
+}
+
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st) {
   if (hop != FBW_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance below 2^30 bytes (buffer descriptors)
@@ -344,6 +524,21 @@ int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const fl
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
+  if (!d_x && knob(KNOB_BWD_WPS) != 2) {                         // the tap gradient alone: three waves per SIMD, six workgroups per CU
+    const long slots6 = 6L * 256;
+    long pu = slots6 / (B > 0 ? B : 1);
+    if (pu < 1) pu = 1;
+    int run6 = (int)((g.pairs + pu - 1) / pu);
+    if (run6 < 3) run6 = 3;
+    if (const long v = knob(KNOB_BLK_RUN)) { if (v >= 1) run6 = (int)v; }
+    if (run6 > g.pairs) run6 = g.pairs;
+    g.run = run6;
+    g.runs_per_utt = (g.pairs + run6 - 1) / run6;
+    const long wgs6 = (long)B * g.runs_per_utt;
+    if (wgs6 > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(k_fir_blk_bwd6<0>, dim3((unsigned)wgs6), dim3(128), 0, st, x, x_is_u01, grad_out, d_taps, g);
+    return 0;
+  }
   const long wgs = (long)B * g.runs_per_utt;
   if (wgs > 0x7fffffffL) return -1;
   if (d_x)

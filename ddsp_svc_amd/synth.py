@@ -14,6 +14,8 @@ from .core import _f32c, ir_table
 # same-box A/B switch (tools/train_step_probe.py): 1 = the noise branch of the training composition is joined into the
 # caller's stream as soon as it is launched (the order before round 4) instead of at its first consumer
 _EARLY_JOIN = os.environ.get("DDSP_HIP_TRAIN_EARLY_JOIN", "0") == "1"
+# same-box A/B switch: 1 = training takes the per-operator composition of rounds 2 - 5 even where the fused tail applies
+_TRAIN_COMPOSED = os.environ.get("DDSP_HIP_TRAIN_COMPOSED", "0") == "1"
 
 
 @dataclass
@@ -152,6 +154,16 @@ def sins_synth(f0_frames, state: PhaseState, amplitudes, group_delay, noise_magn
         noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
                                             f0_frames.device), True
     if torch.is_grad_enabled() and any(c.requires_grad for c in (amplitudes, group_delay, noise_magnitude)):
+        f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+        B, F = f0.shape
+        n = group_delay.shape[-1]
+        lay = None
+        if _fused_train_ok(f0_frames, block_size, amplitudes, group_delay, noise_magnitude) and fir_impl == _ffi.FIR_AUTO \
+                and noise_magnitude.shape[-1] == n and not _TRAIN_COMPOSED:
+            lay = _tail_layout(False, B, F, int(block_size), amplitudes.shape[-1], n, n)
+        if lay is not None:
+            return SinsTailFunction.apply(f0, state, amplitudes, group_delay, noise_magnitude, _f32c(noise.reshape(B, -1)),
+                                          noise_is_u01, sampling_rate, int(block_size), lay)
         return _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude, noise, sampling_rate,
                                  block_size, noise_is_u01)
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
@@ -278,6 +290,175 @@ class AllpassTapsFunction(torch.autograd.Function):
         return d_c
 
 
+# ---- training through the FUSED tails (round 6): the forward pass of a training step is the inference call itself -------
+# solver.py:93-103 runs the same forward with gradients.  Rounds 2 - 5 composed it from per-operator autograd Functions
+# (exciter, three tap syntheses, three filters: seven launches on two streams); the fused entry points leave every intermediate
+# the adjoints need in their workspace (ddsp_hip_tail_layout), so the forward of a training step is the three- / four-launch
+# inference call and only the backward pass is a sequence of adjoint kernels.
+
+def _tail_layout(combsub, B, F, hop, n0, n1, n2):
+    """byte offsets of the intermediates a fused tail call of this shape leaves in its workspace, or None (not the fused layout)"""
+    import ctypes
+    off = (ctypes.c_longlong * 6)()
+    rc = _ffi.lib().ddsp_hip_tail_layout(int(combsub), B, F, hop, n0, n1, n2, 0, 0, ctypes.addressof(off))
+    if rc < 0:
+        _ffi.check(rc)
+    return list(off) if rc == 1 else None
+
+
+def _ws_view(ws, offset, shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return ws[offset:offset + 4 * n].view(torch.float32).view(*shape)
+
+
+def _fir_bwd(x, x_is_u01, taps, grad, need_dx):
+    """(d_x | None, d_taps) of fft_convolve for the cotangent ``grad [B,T]`` (ddsp_hip_fft_convolve_backward)"""
+    B, F, N = taps.shape
+    T = x.shape[1]
+    d_taps = torch.empty(B, F, N, dtype=torch.float32, device=x.device)
+    d_x = torch.empty(B, T, dtype=torch.float32, device=x.device) if need_dx else None
+    _ffi.check(_ffi.lib().ddsp_hip_fft_convolve_backward(ptr(x), int(x_is_u01), ptr(taps), ptr(grad), ptr(d_x), ptr(d_taps),
+                                                         B, F, T // F, N, _ffi.stream_of(x)))
+    return d_x, d_taps
+
+
+def _mag_taps_bwd(d_taps, c, ld, scale, mode, hw):
+    B, F, N = d_taps.shape
+    n = N // 2 + 1
+    d_c = torch.empty(B, F, n, dtype=torch.float32, device=d_taps.device)
+    _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(d_taps), ptr(c), ld, _ffi.ACT_EXP, float(scale), int(mode), ptr(hw),
+                                                             B * F, n, ptr(ir_table(n, d_taps.device)), ptr(d_c), None,
+                                                             _ffi.stream_of(d_taps)))
+    return d_c
+
+
+def _allpass_taps_bwd(d_taps, c, ld):
+    B, F, N = d_taps.shape
+    n = N // 2 + 1
+    dev = d_taps.device
+    d_re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
+    d_im = torch.empty_like(d_re)
+    d_c = torch.empty(B, F, n, dtype=torch.float32, device=dev)
+    st = _ffi.stream_of(d_taps)
+    _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(d_taps), None, 0, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
+                                                             B * F, n, ptr(ir_table(n, dev)), ptr(d_re), ptr(d_im), st))
+    _ffi.check(_ffi.lib().ddsp_hip_allpass_backward(ptr(c), ld, B * F, n, ptr(d_re), ptr(d_im), ptr(d_c), st))
+    return d_c
+
+
+def _sum_cot(T_shape, device, *gs):
+    """the cotangent of a branch: the sum of the output cotangents that reach it (None = zero)"""
+    gs = [_f32c(g.reshape(T_shape)) for g in gs if g is not None]
+    if not gs:
+        return None
+    out = gs[0]
+    for g in gs[1:]:
+        out = out + g
+    return out
+
+
+class CombSubTailFunction(torch.autograd.Function):
+    """The CombSub DSP tail (vocoder.py:834-862) as ONE autograd node: forward = ``ddsp_hip_combsub_synth`` (the fused inference
+    call, all three outputs), backward = the adjoint kernels on the intermediates that call left in its workspace."""
+
+    @staticmethod
+    def forward(ctx, f0, state, cg, ch, cn, nz, noise_is_u01, sr, hop, layout):
+        B, F = f0.shape
+        T = F * hop
+        n = cg.shape[-1]
+        g_, ldg = _rows(cg.detach(), n)
+        h_, ldh = _rows(ch.detach(), n)
+        n_, ldn = _rows(cn.detach(), n)
+        dev = f0.device
+        ws, need = _workspace(B, F, hop, n, dev)
+        signal, harm, nzo = _outputs(B, T, dev, True)
+        tab = ir_table(n, dev)
+        _ffi.check(_ffi.lib().ddsp_hip_combsub_synth(
+            ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(g_), ldg, ptr(h_), ldh, ptr(n_), ldn,
+            ptr(nz), int(noise_is_u01), B, F, hop, float(sr), int(state.infer), n, n, n, ptr(tab), ptr(tab), ptr(tab),
+            ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, 0, _ffi.stream_of(f0), None, 0, 0))
+        N = 2 * (n - 1)
+        ctx.save_for_backward(f0, g_, h_, n_, nz, ws)
+        ctx.cfg = (ldg, ldh, ldn, bool(noise_is_u01), float(sr), int(hop), layout, (B, F, T, N))
+        ctx.set_materialize_grads(False)                        # an output nobody differentiates sends None, not a [B, T] of zeros
+        return signal, harm, nzo
+
+    @staticmethod
+    def backward(ctx, g_sig, g_harm, g_nz):
+        f0, cg, ch, cn, nz, ws = ctx.saved_tensors
+        ldg, ldh, ldn, u01, sr, hop, lay, (B, F, T, N) = ctx.cfg
+        comb, h1 = _ws_view(ws, lay[0], (B, T)), _ws_view(ws, lay[1], (B, T))
+        taps_ap, taps_h, taps_nz = (_ws_view(ws, lay[i], (B, F, N)) for i in (2, 3, 4))
+        gh = _sum_cot((B, T), f0.device, g_sig, g_harm)
+        gn = _sum_cot((B, T), f0.device, g_sig, g_nz)
+        d_cg = d_ch = d_cn = None
+        if gh is not None:
+            d_h1, d_taps_h = _fir_bwd(h1, False, taps_h, gh, True)                          # vocoder.py:847-851 backwards
+            hw = (1.5 * sr) / (f0 + 1e-3)                                                    # :851
+            d_ch = _mag_taps_bwd(d_taps_h, ch, ldh, 1.0, _ffi.MODE_DYNAMIC, _f32c(hw.reshape(B * F)))
+            _, d_taps_ap = _fir_bwd(comb, False, taps_ap, d_h1, False)                       # :843-846
+            d_cg = _allpass_taps_bwd(d_taps_ap, cg, ldg)
+        if gn is not None:
+            _, d_taps_nz = _fir_bwd(nz, u01, taps_nz, gn, False)                             # :854-858
+            d_cn = _mag_taps_bwd(d_taps_nz, cn, ldn, 1.0 / 128.0, _ffi.MODE_HANN, None)
+        return None, None, d_cg, d_ch, d_cn, None, None, None, None, None
+
+
+class SinsTailFunction(torch.autograd.Function):
+    """The Sins DSP tail (vocoder.py:580-611) as one autograd node, as CombSubTailFunction."""
+
+    @staticmethod
+    def forward(ctx, f0, state, ca, cg, cn, nz, noise_is_u01, sr, hop, layout):
+        B, F = f0.shape
+        T = F * hop
+        H, n = ca.shape[-1], cg.shape[-1]
+        a_, lda = _rows(ca.detach(), H)
+        g_, ldg = _rows(cg.detach(), n)
+        n_, ldn = _rows(cn.detach(), n)
+        dev = f0.device
+        ws, need = _workspace(B, F, hop, n, dev)
+        signal, harm, nzo = _outputs(B, T, dev, True)
+        tab = ir_table(n, dev)
+        _ffi.check(_ffi.lib().ddsp_hip_sins_synth(
+            ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(a_), lda, ptr(g_), ldg, ptr(n_), ldn,
+            ptr(nz), int(noise_is_u01), B, F, hop, float(sr), int(state.infer), H, n, n, ptr(tab), ptr(tab),
+            ptr(signal), ptr(harm), ptr(nzo), ptr(ws), need, 0, _ffi.stream_of(f0), None, 0, 0))
+        ctx.save_for_backward(f0, a_, g_, n_, nz, ws)
+        ctx.cfg = (lda, ldg, ldn, bool(noise_is_u01), float(sr), int(hop), layout, state, (B, F, T, 2 * (n - 1), H))
+        ctx.set_materialize_grads(False)
+        return signal, harm, nzo
+
+    @staticmethod
+    def backward(ctx, g_sig, g_harm, g_nz):
+        f0, ca, cg, cn, nz, ws = ctx.saved_tensors
+        lda, ldg, ldn, u01, sr, hop, lay, state, (B, F, T, N, H) = ctx.cfg
+        sinus = _ws_view(ws, lay[0], (B, T))
+        taps_ap, taps_nz = _ws_view(ws, lay[2], (B, F, N)), _ws_view(ws, lay[4], (B, F, N))
+        gh = _sum_cot((B, T), f0.device, g_sig, g_harm)
+        gn = _sum_cot((B, T), f0.device, g_sig, g_nz)
+        d_ca = d_cg = d_cn = None
+        lib = _ffi.lib()
+        if gh is not None:
+            d_sin, d_taps_ap = _fir_bwd(sinus, False, taps_ap, gh, True)                     # vocoder.py:597-600 backwards
+            d_cg = _allpass_taps_bwd(d_taps_ap, cg, ldg)
+            scratch = torch.empty(lib.ddsp_hip_sinusoid_bank_backward_scratch_bytes(B, F, H), dtype=torch.uint8, device=f0.device)
+            d_ca = torch.empty(B, F, H, dtype=torch.float32, device=f0.device)
+            _ffi.check(lib.ddsp_hip_sinusoid_bank_backward(ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(ca), lda,
+                                                           ptr(d_sin), B, F, hop, H, sr, int(state.infer), ptr(scratch), ptr(d_ca),
+                                                           _ffi.stream_of(f0)))                # :585-594
+        if gn is not None:
+            _, d_taps_nz = _fir_bwd(nz, u01, taps_nz, gn, False)                             # :603-607
+            d_cn = _mag_taps_bwd(d_taps_nz, cn, ldn, 1.0 / 128.0, _ffi.MODE_HANN, None)
+        return None, None, d_ca, d_cg, d_cn, None, None, None, None, None
+
+
+def _fused_train_ok(f0_frames, hop, *ctrls):
+    """float32 controls on the device, hop 512 -- and what the library's own predicate says (ddsp_hip_tail_layout)"""
+    return int(hop) == 512 and all(c.dtype == torch.float32 and c.dim() == 3 for c in ctrls)
+
+
 def _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, noise_magnitude, noise, sampling_rate,
                          block_size, noise_is_u01):
     """CombSub DSP tail as a composition of differentiable primitives (training, solver.py:93-103): the same kernels as
@@ -338,6 +519,16 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
         noise, noise_is_u01 = uniform_noise(f0_frames.shape[0], f0_frames.shape[1] * int(block_size), noise_seed, noise_offset,
                                             f0_frames.device), True
     if torch.is_grad_enabled() and any(c.requires_grad for c in (group_delay, harmonic_magnitude, noise_magnitude)):
+        f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))
+        B, F = f0.shape
+        n = group_delay.shape[-1]
+        lay = None
+        if _fused_train_ok(f0_frames, block_size, group_delay, harmonic_magnitude, noise_magnitude) and fir_impl == _ffi.FIR_AUTO \
+                and harmonic_magnitude.shape[-1] == n and noise_magnitude.shape[-1] == n and not _TRAIN_COMPOSED:
+            lay = _tail_layout(True, B, F, int(block_size), n, n, n)
+        if lay is not None:
+            return CombSubTailFunction.apply(f0, state, group_delay, harmonic_magnitude, noise_magnitude,
+                                             _f32c(noise.reshape(B, -1)), noise_is_u01, sampling_rate, int(block_size), lay)
         return _combsub_synth_train(f0_frames, state, group_delay, harmonic_magnitude, noise_magnitude, noise,
                                     sampling_rate, block_size, noise_is_u01)
     f0 = _f32c(f0_frames.reshape(f0_frames.shape[0], -1))

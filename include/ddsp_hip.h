@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 160          /* 0.1.6.0: + ddsp_hip_sine_source_drawn / ddsp_hip_normal_noise, adjoints at 514..1022 taps and every hop, knobs LANE_ROWS / LANES */
+#define DDSP_HIP_VERSION 161          /* 0.1.6.1: + ddsp_hip_tail_layout; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -192,6 +192,16 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
  * Streaming shapes (B F < 4096 frames, gui.py:118-133): the workspace holds one tap buffer more, and the tails issue the
  * same kernels as three (CombSub) / four (Sins) dependent launches instead of seven / five -- same results, bit for bit. */
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
+
+/* Where a ddsp_hip_combsub_synth (combsub != 0; n0, n1, n2 = n_ap, n_harm, n_nz) / ddsp_hip_sins_synth (n0 = H, n1 = n_ap,
+ * n2 = n_nz) call of this shape LEAVES ITS INTERMEDIATES in the workspace -- what a training caller keeps for the backward pass
+ * (solver.py:93-103: the same forward with gradients) instead of recomputing or re-running the tail as separate operators:
+ * byte offsets into `ws` of [0] the exciter [B,T], [1] the all-pass filter's output [B,T] (CombSub), [2] the all-pass taps
+ * [B,F,N], [3] the harmonic taps (CombSub), [4] the noise taps, [5] the filtered noise (when no noise output was passed); -1 =
+ * not kept.  Returns 1 when the call takes the fused layout and the offsets are valid until the workspace is written again, 0
+ * when it does not (other bin counts / hops, in-kernel noise, sub-batch lanes: nothing is promised), < 0 on bad arguments. */
+int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int n2, int fir_impl, int in_kernel_noise,
+                         long long offsets[6]);
 
 /* exciters on their own (used by tests and by callers that want the intermediate):
  * combtooth (vocoder.py:839-840) and the sinusoid bank (vocoder.py:585-594), out[B,T] */

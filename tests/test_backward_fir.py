@@ -420,3 +420,43 @@ def test_fft_convolve_backward_long_taps_fft_form(dev, B, F, N, run, knobs):
     dxd, dhd = core.fft_convolve_backward(t(R), t(x), t(ir))
     assert rms((dxd - dx).cpu().numpy()) <= 5e-6 * rms(rx) and rms((dhd - dh).cpu().numpy()) <= 5e-6 * rms(rh)
     assert not torch.equal(dhd, dh)                                           # (it IS another kernel)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("kind", ["combsub", "sins"])
+def test_fused_tail_training_node(dev, kind, monkeypatch):
+    """256-bin models at hop 512 train through ONE autograd node whose forward is the fused inference call (its intermediates stay
+    in the workspace, ddsp_hip_tail_layout) -- against the per-operator composition of rounds 2 - 5 on the same inputs (outputs:
+    the composition's filters use another run split, rounding level; gradients <= 1e-5) and, for CombSub, against the oracle's
+    float64 adjoint (pinned to the reference's autograd by test_oracle_golden.py::test_combsub_tail_adjoint); cotangents on all
+    three outputs, odd frame count, a uniform draw handed over as u in [0, 1)"""
+    from ddsp_svc_amd import synth
+    B, F, n, H = 2, 7, 256, 40
+    f0 = O.synth_f0(B, F, 44100, 512, seed=11)
+    sizes = [n, n, n] if kind == "combsub" else [H, n, n]
+    ctrls = O.synth_controls(B, F, sizes, seed=12)
+    u = np.random.default_rng(13).random((B, F * 512)).astype(np.float32)
+    R = [np.random.default_rng(20 + i).standard_normal((B, F * 512)).astype(np.float32) for i in range(3)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fn = synth.combsub_synth if kind == "combsub" else synth.sins_synth
+
+    def run(composed):
+        monkeypatch.setattr(synth, "_TRAIN_COMPOSED", composed)
+        c = [t(x).requires_grad_(True) for x in ctrls]
+        st = synth.phase(t(f0), 44100, 512)
+        outs = fn(t(f0), st, c[0], c[1], c[2], t(u), 44100, 512, noise_is_u01=True)
+        assert all(o.requires_grad for o in outs)
+        loss = sum((o * t(r)).sum() for o, r in zip(outs, R))
+        return [o.detach().cpu().numpy() for o in outs], [g.cpu().numpy() for g in torch.autograd.grad(loss, c)]
+    out_f, g_f = run(False)
+    out_c, g_c = run(True)
+    for a, b in zip(out_f, out_c):
+        assert rms(a - b) <= 2e-6 * rms(b)
+    for a, b in zip(g_f, g_c):
+        assert rms(a - b) <= 1e-5 * rms(b), (rms(a - b), rms(b))
+    if kind == "combsub":
+        # signal = harmonic + noise: the cotangent of the harmonic branch is R0 + R1, of the noise branch R0 + R2
+        wh = O.combsub_dsp_backward(R[0] + R[1], f0, ctrls[0], ctrls[1], ctrls[2], 2.0 * u - 1.0)
+        wn = O.combsub_dsp_backward(R[0] + R[2], f0, ctrls[0], ctrls[1], ctrls[2], 2.0 * u - 1.0)
+        for got, want in zip(g_f, (wh["group_delay"], wh["harmonic_magnitude"], wn["noise_magnitude"])):
+            assert rms(got - want) <= 2e-5 * rms(want), (rms(got - want), rms(want))

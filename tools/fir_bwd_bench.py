@@ -23,11 +23,11 @@ dx = torch.empty(B, T, device=dev)
 dt = torch.empty(B, F, N, device=dev)
 
 
-def timeit(with_dx, reps=20):
+def timeit(with_dx, reps=int(os.environ.get("REPS", 400))):      # long enough to be past the clocks' transient (~100 launches)
     def once():
         _ffi.check(L.ddsp_hip_fft_convolve_backward(x.data_ptr(), 0, taps.data_ptr(), g.data_ptr(),
                                                     dx.data_ptr() if with_dx else None, dt.data_ptr(), B, F, HOP, N, st))
-    for _ in range(3):
+    for _ in range(max(3, reps // 2)):
         once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -71,6 +71,14 @@ knobs)
     done
   done
   ;;
+train)
+  # forward + backward steps at the clocks' steady state, and the kernels of the CombSub training step (last 100 steps of 400)
+  for k in ${KINDS:-combsub sins combsubsuperfast combsubfast}; do timeout 300 python tools/train_step_probe.py $k 2>&1 | tail -1; done | tee "$O/${V}_train_ms.txt"
+  ( cd /tmp; rm -rf "$O/tp"; TRAIN_WARM=300 TRAIN_STEPS=100 timeout 300 rocprofv3 --kernel-trace -d "$O/tp" -o t -- python "$R/tools/train_step_probe.py" ${TRACE_KIND:-combsub} > /dev/null 2>&1
+    f=$(find "$O/tp" -name "*.db" | head -1)
+    LAST=100 python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums 2>&1 | head -40 > "$O/${V}_train_${TRACE_KIND:-combsub}_launches.txt"; rm -rf "$O/tp" )
+  cat "$O/${V}_train_${TRACE_KIND:-combsub}_launches.txt"
+  ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
   line "$O/${V}_bench_default.json"

@@ -65,11 +65,12 @@ def step():
     return torch.autograd.grad(objective(sig), c)
 
 
-for _ in range(3):
+N_WARM, N_STEPS = int(os.environ.get("TRAIN_WARM", 300)), int(os.environ.get("TRAIN_STEPS", 50))   # the first ~100 steps of a process
+for _ in range(N_WARM):                                                                              # are a clock transient
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(20):
+for _ in range(N_STEPS):
     step()
 torch.cuda.synchronize()
-print(kind, "forward+backward" + (" with RSSLoss" if with_loss else ""), "ms/step", round((time.perf_counter() - t0) / 20 * 1e3, 3))
+print(kind, "forward+backward" + (" with RSSLoss" if with_loss else ""), "ms/step", round((time.perf_counter() - t0) / N_STEPS * 1e3, 3))
