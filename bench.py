@@ -1670,9 +1670,7 @@ def main(argv=None):
     fir_flops = 4.0 * N * B * T                      # direct form: 2N multiply-adds per output sample
     fir_launches = 3 if a.model == "combsub" else 2
     fir_bytes = (8.0 + 4.0 * N / HOP) * B * T        # input + output + one tap row per frame
-    # the hop-block form is k_fir_blk6 (three waves per SIMD) unless knob BLK_WPS = 2 asks for round 3's k_fir_blk
-    blk = "k_fir_blk<" if os.environ.get("DDSP_HIP_BLK_WPS", "").strip() == "2" else "k_fir_blk6"
-    kname = {4: "k_fir_fft", 5: blk}.get(used_impl, "k_fir_mfma")
+    kname = {4: "k_fir_fft", 5: "k_fir_blk6"}.get(used_impl, "k_fir_mfma")      # (the product library ships one generation per kernel)
     # BASELINE cfg 4's per-GPU shape: every rank takes part (collectives inside)
     # (every rank takes part; at N = 1 it is part of the default command, so that the driver's run records the per-GPU shape
     # every multi-GPU point is made of)

@@ -4,7 +4,9 @@
 #include "kernels.h"
 #include "philox.h"
 #include <atomic>
+#include <stdio.h>
 #include <mutex>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -19,12 +21,29 @@ const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", 
                                             "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
+// A knob whose kernel generation is not compiled into this build (the product library ships ONE generation per kernel; the
+// superseded ones exist only under -DDDSP_AB_GENERATIONS, tools/build_variant.sh) does nothing: setting it is an ERROR from
+// ddsp_hip_set_tuning and a warning from the environment, so that an A/B run cannot measure the same kernel twice under two names.
+bool knob_is_inert(int i, long v) {
+#ifdef DDSP_AB_GENERATIONS
+  (void)i; (void)v;
+  return false;
+#else
+  if (v == 0) return false;
+  return i == KNOB_BLK_WPS || i == KNOB_BLK_PADLDS || (i == KNOB_SINS_V1 && v == 2);
+#endif
+}
 void knobs_from_env() {
   for (int i = 0; i < KNOB_COUNT; ++i) {
     char name[64] = "DDSP_HIP_";
     strncat(name, kKnobNames[i], sizeof(name) - strlen(name) - 1);
     const char* e = getenv(name);
-    g_knobs[i].store(e ? atol(e) : 0, std::memory_order_relaxed);
+    long v = e ? atol(e) : 0;
+    if (knob_is_inert(i, v)) {
+      fprintf(stderr, "libddsp_hip: %s=%ld ignored: that kernel generation is not in this build (-DDDSP_AB_GENERATIONS)\n", name, v);
+      v = 0;
+    }
+    g_knobs[i].store(v, std::memory_order_relaxed);
   }
 }
 int knob_index(const char* name) {
@@ -42,7 +61,7 @@ long knob(Knob k) {
 int knob_set(const char* name, long v) {
   std::call_once(g_knobs_once, knobs_from_env);
   const int i = knob_index(name);
-  if (i < 0) return -1;
+  if (i < 0 || knob_is_inert(i, v)) return -1;
   g_knobs[i].store(v, std::memory_order_relaxed);
   return 0;
 }
@@ -91,32 +110,62 @@ struct BranchEvents {
   hipEvent_t fork = nullptr, join = nullptr, mid[2] = {nullptr, nullptr};
 };
 
+// The HIP objects this library creates (fork / join events, the second lane's streams) live in ONE process-wide pool per device:
+// a call checks a set out and hands it back when it returns, so their number is bounded by the calls in flight at once -- not by
+// the host threads that ever called (rounds 2 - 5 kept them in thread_local arrays without destructors: a caller on short-lived
+// threads leaked a set per thread).  A set that goes back while its work is still in flight is safe to re-use: a wait captures
+// the record that precedes it, and streams order whatever the next user enqueues behind it.  Nothing is destroyed at exit.
+template <class T>
+struct DevicePool {
+  std::mutex m;
+  std::vector<T*> idle[64];
+  T* take(int dev) {
+    std::lock_guard<std::mutex> lock(m);
+    if (idle[dev].empty()) return nullptr;
+    T* t = idle[dev].back();
+    idle[dev].pop_back();
+    return t;
+  }
+  void give(int dev, T* t) {
+    std::lock_guard<std::mutex> lock(m);
+    idle[dev].push_back(t);
+  }
+};
+DevicePool<BranchEvents> g_branch_pool;
+
 struct Branch {
   hipStream_t main, aux;
   BranchEvents* ev = nullptr;
+  int dev = -1;
   bool forked = false;
   Branch(hipStream_t m, void* aux_stream) : main(m), aux(m) {
     if (!aux_stream || S(aux_stream) == m) return;
-    static thread_local BranchEvents per_device[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    BranchEvents& e = per_device[dev];
-    if (!e.fork) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return;
+    BranchEvents* e = g_branch_pool.take(d);
+    if (!e) {
       hipEvent_t made[4] = {nullptr, nullptr, nullptr, nullptr};
       for (int i = 0; i < 4; ++i)
         if (hipEventCreateWithFlags(&made[i], hipEventDisableTiming) != hipSuccess) {
           for (int j = 0; j < i; ++j) (void)hipEventDestroy(made[j]);
           return;
         }
-      e.fork = made[0]; e.join = made[1]; e.mid[0] = made[2]; e.mid[1] = made[3];
+      e = new BranchEvents;
+      e->fork = made[0]; e->join = made[1]; e->mid[0] = made[2]; e->mid[1] = made[3];
     }
+    ev = e;
+    dev = d;
     // everything enqueued on the main stream so far (the inputs' producers) precedes the branch
-    if (hipEventRecord(e.fork, m) != hipSuccess) return;
-    if (hipStreamWaitEvent(S(aux_stream), e.fork, 0) != hipSuccess) return;
-    ev = &e;
+    if (hipEventRecord(e->fork, m) != hipSuccess) return;
+    if (hipStreamWaitEvent(S(aux_stream), e->fork, 0) != hipSuccess) return;
     aux = S(aux_stream);
     forked = true;
   }
+  ~Branch() {
+    if (ev) g_branch_pool.give(dev, ev);
+  }
+  Branch(const Branch&) = delete;
+  Branch& operator=(const Branch&) = delete;
   // a point of the branch the main stream waits for while the branch keeps running (i = 0, 1)
   void publish(int i) {
     if (forked) (void)hipEventRecord(ev->mid[i], aux);
@@ -175,12 +224,18 @@ struct LaneSet {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 
-// the second lane's stream pair of this host thread on the current device, or null (then every sub-batch takes lane 0)
-LaneSet* second_lane() {
-  static thread_local LaneSet per_device[64];
+// a second lane's stream pair on the current device, checked out of the pool (give it back with release_lane), or null (then
+// every sub-batch takes lane 0)
+DevicePool<LaneSet> g_lane_pool;
+void release_lane(LaneSet* l, int dev) {
+  if (l) g_lane_pool.give(dev, l);
+}
+LaneSet* second_lane(int* dev_out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  LaneSet& l = per_device[dev];
+  *dev_out = dev;
+  if (LaneSet* have = g_lane_pool.take(dev)) return have;
+  LaneSet& l = *new LaneSet;
   if (!l.join) {
     hipStream_t s0 = nullptr, s1 = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -194,6 +249,7 @@ LaneSet* second_lane() {
       if (e0) (void)hipEventDestroy(e0);
       if (e1) (void)hipEventDestroy(e1);
       (void)hipGetLastError();
+      delete &l;
       return nullptr;
     }
     l.main1 = s0; l.aux1 = s1; l.fork = e0; l.join = e1;
@@ -574,7 +630,9 @@ int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, i
   }
   // a second lane needs a stream pair of its own; without a branch stream (one-stream mode, emulator) the sub-batches run in
   // sequence on the caller's stream, alternating between the slots
-  LaneSet* lane1 = (p.slots == 2 && aux_stream && S(aux_stream) != st) ? second_lane() : nullptr;
+  int lane_dev = 0;
+  LaneSet* lane1 = (p.slots == 2 && aux_stream && S(aux_stream) != st) ? second_lane(&lane_dev) : nullptr;
+  LaneSet* const lane_taken = lane1;                       // goes back to the pool on every path out of this function
   if (lane1) {
     if (hipEventRecord(lane1->fork, st) != hipSuccess || hipStreamWaitEvent(lane1->main1, lane1->fork, 0) != hipSuccess) {
       (void)hipGetLastError();
@@ -596,6 +654,7 @@ int run_lanes(const TailCall& a, const LanePlan& p, void* ws, size_t ws_bytes, i
     (void)hipEventRecord(lane1->join, lane1->main1);
     (void)hipStreamWaitEvent(st, lane1->join, 0);
   }
+  release_lane(lane_taken, lane_dev);
   return rc;
 }
 

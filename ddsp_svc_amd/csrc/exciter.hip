@@ -767,7 +767,9 @@ int launch_sins_bank_bwd(const float* f0_frames, const float* initial_phase, con
   Upsampler up = make_upsampler_pub(F, hop);
   PhaseCfg cfg = make_phase_cfg(sr, infer, initial_phase != nullptr);
   const int HP = (H + 15) & ~15;
-  if (hop != 512) {                                             // every other hop: one wave per frame, direct sines
+  // (hop 512 with F hop > 2^24: make_upsampler has no shift form there, the forward takes the generic k_sins_bank with its
+  //  float-rounded interpolation, and so must its adjoint -- the matrix-pipe kernel hard-codes the shift form)
+  if (hop != 512 || up.shift <= 0) {                            // every other hop: one wave per frame, direct sines
     const dim3 grid((unsigned)((long)B * ((F + 3) / 4))), block(256);
     if (spl == 8)
       hipLaunchKernelGGL(k_sins_bank_bwd_any<8>, grid, block, 0, st, f0_frames, initial_phase, grad_out, F, hop, H, HP, up, cfg, phase0, scratch);

@@ -57,7 +57,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // Standard-normal draw for the harmonic source of NSF-HiFiGAN (nsf_hifigan/models.py:168 draws torch.randn_like(sine_waves):
 // [B, T, dim] values -- THIS IS A DIFFERENT STREAM, as the uniform draw above).  Four normals per counter by Box-Muller:
-// counter = (t, utterance, offset_lo, 4 * offset_hi + j), key = (seed_lo, seed_hi); the words (x0, x1) and (x2, x3) give
+// counter = (t, utterance, offset_lo, 4 * offset_hi + j), key = (seed_lo, seed_hi ^ 'NORM'), j < 4; the words (x0, x1) and (x2, x3) give
 //     u1 = ((x >> 8) + 1) 2^-24 in (0, 1],  u2 = (x' >> 8) 2^-24 in [0, 1),  r = sqrt(-2 ln u1),  z = r cos(2 pi u2), r sin(2 pi u2)
 // and harmonic h of sample t takes normal h % 4 of call j = h / 4 (|z| <= 5.77).  The hardware log2 / sine / cosine (the latter
 // two take revolutions: u2 itself) are within ~1e-6 of the float64 restatement in oracle/ddsp_oracle.py.
@@ -65,8 +65,10 @@ struct Normal4 { float z[4]; };
 
 __device__ __forceinline__ Normal4 philox_normal4(const NoiseGen& g, unsigned utterance, unsigned t, unsigned j) {
   uint32_t x[4];
+  // the key's high word carries a domain tag ("NORM"): with the plain key the words of (seed, offset) were, for offset_hi = 0 and
+  // j = 0, the very words the UNIFORM draw above maps to the noise branch's samples -- two draws a caller may seed alike
   philox4x32_10(t, utterance + g.utt0, (uint32_t)g.offset, 4u * (uint32_t)(g.offset >> 32) + j, (uint32_t)g.seed,
-                (uint32_t)(g.seed >> 32), x);
+                (uint32_t)(g.seed >> 32) ^ 0x4E4F524Du, x);
   Normal4 n;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {

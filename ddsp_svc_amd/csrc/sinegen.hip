@@ -102,7 +102,9 @@ __global__ void __launch_bounds__(256) k_normal_noise(NoiseGen rng, long T, int 
 }
 
 int launch_normal_noise(unsigned long long seed, unsigned long long offset, int B, long T, int dim, float* out, hipStream_t st) {
-  if (T >= (1L << 32) || dim < 1 || (offset >> 62) != 0) return -1;     // the counter holds t in 32 bits, 4 * offset_hi + j in 32
+  // the counter holds t in 32 bits and 4 * offset_hi + j in 32: j = h / 4 must stay below 4 (16 harmonics), or call j of one
+  // offset would be call j - 4 of the next
+  if (T >= (1L << 32) || dim < 1 || dim > 16 || (offset >> 62) != 0) return -1;
   const long total = (long)B * T, threads = total * ((dim + 3) / 4);
   const long blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffL) return -1;

@@ -382,7 +382,7 @@ def uniform_noise(B: int, T: int, seed: int, offset: int) -> np.ndarray:
 def normal_noise(B: int, T: int, dim: int, seed: int, offset: int) -> np.ndarray:
     """``z [B,T,dim]`` float64, the opt-in in-kernel standard-normal draw of the NSF harmonic source (csrc/philox.h,
     ``ddsp_hip_normal_noise``; it stands where nsf_hifigan/models.py:168 draws ``torch.randn_like``): counter = (t, b, offset lo,
-    4 * offset hi + j), key = (seed lo, hi); words (x0, x1), (x2, x3) -> Box-Muller pairs with u1 = ((x >> 8) + 1) 2^-24,
+    4 * offset hi + j), key = (seed lo, hi ^ 'NORM'); words (x0, x1), (x2, x3) -> Box-Muller pairs with u1 = ((x >> 8) + 1) 2^-24,
     u2 = (x' >> 8) 2^-24; harmonic h takes normal h % 4 of call j = h // 4."""
     groups = (dim + 3) // 4
     ctr = np.zeros((B, T, groups, 4), dtype=np.uint64)
@@ -390,7 +390,9 @@ def normal_noise(B: int, T: int, dim: int, seed: int, offset: int) -> np.ndarray
     ctr[..., 1] = np.arange(B, dtype=np.uint64)[:, None, None]
     ctr[..., 2] = np.uint64(offset & 0xFFFFFFFF)
     ctr[..., 3] = (np.uint64(4 * ((offset >> 32) & 0x3FFFFFFF)) + np.arange(groups, dtype=np.uint64))[None, None, :]
-    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    if dim > 16:
+        raise ValueError("dim <= 16: the counter's last word holds four calls per offset")
+    key = np.array([seed & 0xFFFFFFFF, ((seed >> 32) & 0xFFFFFFFF) ^ 0x4E4F524D], dtype=np.uint64)   # domain tag "NORM" (philox.h)
     x = philox4x32_10(ctr, np.broadcast_to(key, ctr.shape[:-1] + (2,))).astype(np.uint64)
     z = np.empty((B, T, groups, 4), dtype=np.float64)
     for p in range(2):

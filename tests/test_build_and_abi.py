@@ -48,6 +48,26 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ddsp_hip_stft_loss_tables(4096, None, None) == -3                              # size the plans do not reach
 
 
+def test_knobs_of_generations_that_are_not_in_the_build_are_refused():
+    """the product library ships one generation per kernel: the knobs that select a superseded one (A/B builds only) are an error,
+    not a silent no-op -- an A/B run must not measure the same kernel twice under two names"""
+    import ctypes as C
+    from ddsp_svc_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.ddsp_hip_set_tuning(b"BLK_WPS", 2) != 0 and lib.ddsp_hip_set_tuning(b"BLK_PADLDS", 4096) != 0
+    assert lib.ddsp_hip_set_tuning(b"SINS_V1", 2) != 0
+    assert lib.ddsp_hip_set_tuning(b"BLK_WPS", 0) == 0 and lib.ddsp_hip_set_tuning(b"SINS_V1", 0) == 0
+    assert lib.ddsp_hip_set_tuning(b"NO_SUCH_KNOB", 1) != 0
+    # where a fused tail call leaves its intermediates: valid offsets for a 256-bin CombSub step, none for other bin counts
+    off = (C.c_longlong * 6)()
+    assert lib.ddsp_hip_tail_layout(1, 2, 8, 512, 256, 256, 256, 0, 0, C.addressof(off)) == 1
+    assert list(off)[0] == 0 and all(o > 0 and o % 256 == 0 for o in list(off)[1:])
+    assert lib.ddsp_hip_tail_layout(1, 2, 8, 512, 256, 512, 256, 0, 0, C.addressof(off)) == 0 and all(o == -1 for o in off)
+    assert lib.ddsp_hip_tail_layout(0, 2, 8, 512, 40, 256, 256, 0, 0, C.addressof(off)) == 1 and off[1] == -1 and off[3] == -1
+    assert lib.ddsp_hip_tail_layout(1, 2, 8, 256, 256, 256, 256, 0, 0, C.addressof(off)) == 0          # another hop
+    assert lib.ddsp_hip_tail_layout(1, 0, 8, 512, 256, 256, 256, 0, 0, C.addressof(off)) < 0
+
+
 def test_host_tensors_are_rejected():
     import torch
     from ddsp_svc_amd import core

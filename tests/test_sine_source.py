@@ -194,3 +194,29 @@ def test_sine_source_with_in_kernel_noise(dev, dim):
         y = m(t(f0), UPP)
         y.sum().backward()
         assert m.l_linear.weight.grad is not None and m._noise_calls == 3
+
+
+def test_normal_and_uniform_draws_of_one_seed_are_different_words():
+    """the normal draw's key carries a domain tag: for (seed, offset) with offset_hi = 0 the raw Philox words behind the first four
+    harmonics of sample t are NOT the words behind the uniform draw's samples 4 t .. (they were)"""
+    seed, T = 12345, 512
+    ctr = np.zeros((T, 4), dtype=np.uint64)
+    ctr[:, 0] = np.arange(T)
+    plain = O.philox4x32_10(ctr, np.broadcast_to(np.array([seed, 0], dtype=np.uint64), (T, 2)))
+    tagged = O.philox4x32_10(ctr, np.broadcast_to(np.array([seed, 0x4E4F524D], dtype=np.uint64), (T, 2)))
+    assert not np.any(plain == tagged)
+    z = O.normal_noise(1, T, 4, seed, 0)[0]                         # built from the tagged words ...
+    u1 = ((tagged[:, 0].astype(np.uint64) >> np.uint64(8)) + np.uint64(1)).astype(np.float64) * 2.0 ** -24
+    u2 = (tagged[:, 1].astype(np.uint64) >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+    assert np.allclose(z[:, 0], np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2), atol=1e-12)
+    u = O.uniform_noise(1, 512, seed, 0)[0]                          # ... the uniform draw from the plain ones
+    assert np.allclose(u[:128], (plain[:128, 0].astype(np.uint64) >> np.uint64(8)).astype(np.float64) * 2.0 ** -24)
+    with pytest.raises(ValueError):
+        O.normal_noise(1, 8, 17, seed, 0)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_normal_noise_rejects_more_than_16_harmonics(dev):
+    from ddsp_svc_amd import nsf_source as S
+    with pytest.raises(RuntimeError):
+        S.normal_noise(1, 8, 17, 1, 0, dev)

@@ -37,8 +37,11 @@ def timeit(impl, reps=20):
 
 res = {"impl3_mfma8_ms": timeit(3), "impl4_fft2048_ms": timeit(4)}
 y4 = y.clone()
-for wps in os.environ.get("WPS", "2 3").split():
-    _ffi.set_tuning("BLK_WPS", int(wps))
+for wps in os.environ.get("WPS", "3").split():            # (2: only in a -DDDSP_AB_GENERATIONS build; the product library refuses the knob)
+    try:
+        _ffi.set_tuning("BLK_WPS", int(wps) if wps != "3" else 0)
+    except RuntimeError:
+        continue
     for run in os.environ.get("RUNS", "0").split():
         if run != "0":
             _ffi.set_tuning("BLK_RUN", int(run))
