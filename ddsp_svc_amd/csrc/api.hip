@@ -985,9 +985,19 @@ int ddsp_hip_combsubsuperfast_synth(const float* f0_frames, const float* rad_acc
   hipStream_t st = S(stream);
   // exciter from the closed-form phase (vocoder.py:643-649); rad_acc was produced before Unit2Control ran
   // (only the per-sample part: the frame-rate scan is the caller's ddsp_hip_fast_source call)
-  if (launch_fast_combtooth(f0_frames, rad_acc, B, F, hop, sr, comb, st) != 0) return DDSP_HIP_ESHAPE;
   // torch.stft / istft: reflect padding unless the signal is not longer than win/2 (vocoder.py:667-670)
   const int reflect = (long)F * hop > win / 2 ? 1 : 0;
+  // Streaming shapes (gui.py:118-133 runs THIS model, configs/combsub.yaml:19: B = 1, a fraction of a second per call): the
+  // exciter is made inside the filter's load path and the tail is ONE launch behind ddsp_hip_fast_source -- a step's latency there
+  // is its chain of dependent launches, and a sample recomputed by each of the four frames that cover it costs nothing on an
+  // almost empty chip.  Same arithmetic, same bits (tests/test_small_shapes.py); knob SMALL_PATH = 1: the two-launch layout.
+  if ((long)B * F < kSmallRows && win == 2048 && hop == 512 && knob(KNOB_SMALL_PATH) != 1) {
+    if (launch_stft_filter(nullptr, noise, 0, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, c_nphase, ld_nphase,
+                           1.0f / 128.0f, window, win, reflect, 1, B, F, hop, signal, st, f0_frames, rad_acc, sr) != 0)
+      return DDSP_HIP_ESHAPE;
+    return finish();
+  }
+  if (launch_fast_combtooth(f0_frames, rad_acc, B, F, hop, sr, comb, st) != 0) return DDSP_HIP_ESHAPE;
   if (launch_stft_filter(comb, noise, 0, c_hmag, ld_hmag, c_hphase, ld_hphase, c_nmag, ld_nmag, c_nphase, ld_nphase,
                          1.0f / 128.0f, window, win, reflect, 1, B, F, hop, signal, st) != 0)
     return DDSP_HIP_ESHAPE;

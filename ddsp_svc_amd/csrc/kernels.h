@@ -104,7 +104,9 @@ int launch_fast_combtooth(const float* f0_frames, const float* rad_acc, int B, i
 int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
                        const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
                        long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize, int B,
-                       int F, int hop, float* out, hipStream_t st);
+                       int F, int hop, float* out, hipStream_t st,
+                       // streaming shapes of CombSubSuperFast: the exciter made in the filter's load path from (f0_frames, rad_acc, sr)
+                       const float* exc_f0 = nullptr, const float* exc_acc = nullptr, double exc_sr = 0.0);
 int launch_stft_filter_bwd(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
                            const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
                            long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize,

@@ -187,10 +187,31 @@ struct StftGeom {
   int noise_u01;          // noise holds a U[0,1) draw: apply 2u - 1 on load (vocoder.py:771)
   float noise_scale;      // 1/128 (vocoder.py:663,760)
   long ld_hm, ld_hp, ld_nm, ld_np;
+  // EXC kernels (streaming shapes): the exciter is not read but made where a frame's samples are fetched -- k_fast_combtooth4<true>'s
+  // arithmetic, sample by sample (vocoder.py:643-649)
+  const float* exc_f0; const float* exc_acc;
+  float exc_sr;
 };
 
+// combtooth sample i of an utterance (hop 512), bit for bit what k_fast_combtooth4<true> stores at i
+__device__ __forceinline__ float fast_combtooth_at(const float* __restrict__ f0_row, const float* __restrict__ acc_row, int F, float sr, int i) {
+  const int f = i >> 9, n = i & (ST_HOP - 1);
+  const float s0 = f0_row[f] / sr;
+  float ds0 = 0.f;
+  if (f < F - 1) ds0 = f0_row[f + 1] / sr - s0;
+  const float acc = f > 0 ? acc_row[f - 1] : 0.0f;
+  const float rhop = 1.0f / (float)ST_HOP;
+  const float nf = (float)n, n1 = (float)(n + 1);
+  const float q = ((0.5f * ds0) * nf) * n1;
+  float rad = s0 * n1 + q * rhop;                                                      // :643
+  const float s0n = s0 + (ds0 * nf) * rhop;                                            // :644
+  rad = rad + acc;                                                                     // :647
+  rad = rad - rintf(rad);                                                              // :648
+  return sinc_f32(div_pos(rad, s0n + 1e-5f));                                          // :649
+}
+
 // WPS = waves per SIMD the kernel is compiled for (HIP's second __launch_bounds__ argument): register budget 512 / WPS
-template <int R, int WPS>
+template <int R, int WPS, bool EXC = false>
 __global__ void __launch_bounds__(64 * R, WPS)
 k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, const float* __restrict__ c_hmag,
               const float* __restrict__ c_hphase, const float* __restrict__ c_nmag,
@@ -216,8 +237,10 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   const int p_first = (int)(((long)run_no * g.pairs) / g.runs_per_utt);
   const int p_last = (int)(((long)(run_no + 1) * g.pairs) / g.runs_per_utt);
   const long ob = (long)b * g.T;
-  const float* eb = exc + ob;
+  const float* eb = EXC ? nullptr : exc + ob;
   const float* nb = noise + ob;
+  const float* xf0 = EXC ? g.exc_f0 + (long)b * g.F : nullptr;
+  const float* xacc = EXC ? g.exc_acc + (long)b * g.F : nullptr;
 
   typename PL::Tw tw;
   tw.init(tid);
@@ -256,11 +279,11 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
   auto fetch_frame = [&](int j) {
     const int s0 = j * ST_HOP - PAD;
     if (s0 >= 0 && s0 + N <= g.T) {                              // interior frame (wave-uniform)
-      const float* ef = eb + s0 + tid;
+      const float* ef = EXC ? nullptr : eb + s0 + tid;
       const float* nf = nb + s0 + tid;
 #pragma unroll
       for (int m = 0; m < S; ++m) {
-        ne[m] = ef[P * m];
+        ne[m] = EXC ? fast_combtooth_at(xf0, xacc, g.F, g.exc_sr, s0 + P * m + tid) : ef[P * m];
         nu[m] = nf[P * m];
       }
     } else {                                                     // clamped (and reflected) addresses; masked where they are used
@@ -272,7 +295,7 @@ k_stft_filter(const float* __restrict__ exc, const float* __restrict__ noise, co
           if (i >= g.T) i = 2 * (g.T - 1) - i;
         }
         i = i < 0 ? 0 : (i >= g.T ? g.T - 1 : i);
-        ne[m] = eb[i];
+        ne[m] = EXC ? fast_combtooth_at(xf0, xacc, g.F, g.exc_sr, i) : eb[i];
         nu[m] = nb[i];
       }
     }
@@ -716,9 +739,11 @@ int launch_fast_source(const float* f0_frames, int B, int F, int hop, double sr,
 int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, const float* c_hmag, long ld_hm,
                        const float* c_hphase, long ld_hp, const float* c_nmag, long ld_nm, const float* c_nphase,
                        long ld_np, float noise_scale, const float* window, int win, int reflect, int normalize, int B,
-                       int F, int hop, float* out, hipStream_t st) {
+                       int F, int hop, float* out, hipStream_t st, const float* exc_f0, const float* exc_acc, double exc_sr) {
   if (hop != ST_HOP || (win != 1024 && win != 2048) || (long)F * hop >= (1L << 30)) return -1;
+  if (exc_f0 && (win != 2048 || !exc_acc)) return -1;          // the inline exciter: the 2048-point kernel only
   StftGeom g;
+  g.exc_f0 = exc_f0; g.exc_acc = exc_acc; g.exc_sr = (float)exc_sr;
   g.F = F; g.T = F * hop;
   g.pairs = (F + 2) / 2;
   g.reflect = reflect; g.normalize = normalize; g.noise_u01 = noise_is_u01; g.noise_scale = noise_scale;
@@ -737,7 +762,11 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
   long per_utt = slots / (B > 0 ? B : 1);
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
-  if (run < 3 * warm) run = 3 * warm;
+  // at least three times the warm-up per workgroup -- except at streaming shapes (gui.py:118-133: B = 1, a fraction of a second),
+  // where every workgroup is resident at once anyway and the launch is as long as its longest workgroup: one pair each (round 6;
+  // six pairs + two of warm-up were 19 us of a 57 us step there).  The overlap-add order per sample does not depend on the
+  // split (a run's warm-up pairs rebuild the ring in frame order): same bits, tests/test_small_shapes.py; knob SMALL_PATH = 1: off
+  if (run < 3 * warm && ((long)B * F >= kSmallRows || knob(KNOB_SMALL_PATH) == 1)) run = 3 * warm;
   if (const long v = knob(KNOB_STFT_RUN)) { if (v >= 1) run = (int)v; }
   if (run > g.pairs) run = g.pairs;
   g.run = run;
@@ -747,6 +776,11 @@ int launch_stft_filter(const float* exc, const float* noise, int noise_is_u01, c
 #define DDSP_STFT_LAUNCH(R_, WPS_)                                                                                  \
   hipLaunchKernelGGL((k_stft_filter<R_, WPS_>), dim3((unsigned)wgs), dim3(64 * R_), 0, st, exc, noise, c_hmag, c_hphase, \
                      c_nmag, c_nphase, window, out, g)
+  if (exc_f0) {
+    hipLaunchKernelGGL((k_stft_filter<4, 2, true>), dim3((unsigned)wgs), dim3(256), 0, st, exc, noise, c_hmag, c_hphase, c_nmag,
+                       c_nphase, window, out, g);
+    return 0;
+  }
   if (win == 2048) {
     if (wps == 4) DDSP_STFT_LAUNCH(4, 4);
     else if (wps == 2) DDSP_STFT_LAUNCH(4, 2);

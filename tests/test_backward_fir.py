@@ -460,3 +460,36 @@ def test_fused_tail_training_node(dev, kind, monkeypatch):
         wn = O.combsub_dsp_backward(R[0] + R[2], f0, ctrls[0], ctrls[1], ctrls[2], 2.0 * u - 1.0)
         for got, want in zip(g_f, (wh["group_delay"], wh["harmonic_magnitude"], wn["noise_magnitude"])):
             assert rms(got - want) <= 2e-5 * rms(want), (rms(got - want), rms(want))
+
+
+@pytest.mark.gpu
+def test_sinusoid_bank_backward_beyond_the_shift_form_gpu():
+    """an utterance of more than 2^24 samples at hop 512: make_upsampler has no shift form there, the forward takes the generic
+    k_sins_bank (ATen's float-rounded interpolation positions) -- and the adjoint must take the matching wave-per-frame kernel, not
+    the matrix-pipe one that hard-codes the shift form.  The bank is LINEAR in A = exp(c) / 128, so the gradient
+    of <R, out> w.r.t. c[f, k] is A[f, k] <R, out(one-hot A at (f, k))>: the adjoint against the FORWARD kernel itself, on the
+    utterance's last frames (where a float-rounded position differs most from the integer one)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ddsp_svc_amd import synth
+    dev = torch.device("cuda:0")
+    B, F, H = 1, 32770, 6                                            # F * 512 = 16 778 240 > 2^24
+    f0 = np.clip(O.synth_f0(B, F, 44100, 512, seed=77), 65, 800).astype(np.float32)
+    (c_amp,) = O.synth_controls(B, F, [H], seed=6)
+    R = np.zeros((B, F * 512), dtype=np.float32)
+    tail = 6 * 512
+    R[:, -tail:] = np.random.default_rng(1).standard_normal((B, tail)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    f0t, Rt = t(f0), t(R)
+    st = synth.phase(f0t, 44100, 512)
+    c = t(c_amp).requires_grad_(True)
+    out = synth.SinusoidBankFunction.apply(f0t, st, c, 44100, 512)
+    (out * Rt).sum().backward()
+    got = c.grad.cpu().numpy()
+    assert float(np.abs(got[:, :-8]).max()) == 0.0 or float(np.abs(got[:, :-8]).max()) <= 1e-6 * float(np.abs(got).max())
+    for f, k in ((F - 1, 0), (F - 1, 5), (F - 2, 2), (F - 3, 1), (F - 6, 4), (F - 7, 3)):
+        hot = torch.full((B, F, H), -1.0e4, device=dev)
+        hot[0, f, k] = float(np.log(128.0))                          # A = 1 there, 0 elsewhere
+        basis = synth.sinusoid_bank(f0t, st, hot, 44100, 512)
+        want = float((basis.double() * Rt.double()).sum()) * float(np.exp(np.float64(c_amp[0, f, k])) / 128.0)
+        assert abs(float(got[0, f, k]) - want) <= 2e-5 * max(abs(want), 1e-3 * float(np.abs(got[:, -8:]).max())), (f, k, got[0, f, k], want)

@@ -153,3 +153,30 @@ def test_from_another_host_thread(dev):
             t.join()
     assert not err, err
     assert len(got) == 6 and all(torch.equal(g, want) for g in got)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F", [(1, 1), (1, 5), (1, 47), (2, 130)])
+def test_superfast_streaming_layout_same_bits(dev, B, F, knobs):
+    """CombSubSuperFast (configs/combsub.yaml as shipped; what gui.py runs) at streaming shapes: one frame pair per workgroup and the
+    exciter made inside the filter's load path -- ONE launch behind fast_source instead of two; the same bits as the batch layout
+    (knob SMALL_PATH = 1), and the oracle's numbers"""
+    from ddsp_svc_amd import synth
+    f0 = O.synth_f0(B, F, SR, HOP, seed=40 + F)
+    f0[0] = np.clip(f0[0] * 1.7, 65, 800)
+    hm, hp, nm, nph = O.synth_controls(B, F, [1025] * 4, seed=F + 1)
+    gz = O.synth_gauss(B, F * HOP, seed=F + 2)
+    w = torch.hann_window(2048)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(a) for a in (f0, hm, hp, nm, nph, gz)]
+
+    def step():
+        fs = synth.fast_source(args[0], SR, HOP)
+        return synth.combsubsuperfast_synth(args[0], fs, args[1], args[2], args[3], args[4], args[5], w.to(dev), SR, HOP)
+    a = step()
+    knobs("SMALL_PATH", 1)
+    b = step()
+    assert torch.equal(a, b)
+    ref = O.combsubsuperfast_dsp(f0, hm, hp, nm, nph, gz, SR, HOP, 2048, w.numpy())["signal"]
+    e = rms(a.cpu().numpy() - ref)
+    assert e <= 1e-5 * rms(ref), (e, rms(ref))
