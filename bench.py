@@ -251,7 +251,7 @@ def live_traffic(model, extra_args=()):
 
 def in_step_kernel_times(model, extra_args=(), steps=900, stats_out=None):
     """Average duration of every ddsp:: kernel INSIDE the step at the clocks' steady state: one ``rocprofv3 --kernel-trace`` pass
-    (no counters) over ``bench.py --model M --only-steps --steps 900``, the LAST third of each kernel's launches (a process's first
+    (no counters) over ``bench.py --model M --only-steps --steps 900``, the last TWO THIRDS of each kernel's launches (a process's first
     ~100 steps are a transient -- a filter launch goes 77 -> 100 -> 72 us while the clocks settle, profiles/r06_v6_*, r06_v7_* --
     and every trace of rounds 2 - 5 was 12 - 24 steps long: the "in-step penalty" those rounds chased was that transient).
     Returns {kernel: {"avg_us", "launches_per_step", "avg_us_all"}} or None.  ``stats_out``: also write the
@@ -288,20 +288,22 @@ def in_step_kernel_times(model, extra_args=(), steps=900, stats_out=None):
         if "ddsp::" not in name:
             continue
         per.setdefault(name.split("(")[0].split("ddsp::")[-1].strip(), []).append((e0 - s0) / 1e3)
-    out = {}
+    out, steady = {}, {}
     for k, v in per.items():
         if k == "k_ir_table" or len(v) < steps:
             continue
-        tail = v[-(len(v) // 3):]
+        tail = v[len(v) // 3:]                                  # past the clocks' transient: the last two thirds of the launches
+        steady[k] = tail
         out[k] = {"avg_us": sum(tail) / len(tail), "launches_per_step": round(len(v) / float(steps + warm), 3),
-                  "avg_us_all": sum(v) / len(v), "launches_traced": len(v)}
+                  "avg_us_all": sum(v) / len(v), "launches_traced": len(v), "launches_averaged": len(tail)}
     if stats_out:
-        tot = sum(sum(v) for v in per.values()) or 1.0
-        lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent,avg_us_last_third"]
-        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            t3 = v[-max(1, len(v) // 3):]
+        tot = sum(sum(v) for v in steady.values()) or 1.0
+        lines = ["# rocprofv3 --kernel-trace of `bench.py --model %s --only-steps --steps %d`: per kernel, the launches past the clocks' "
+                 "transient (the last two thirds); avg_us_whole_trace = all of them" % (model, steps),
+                 "kernel,calls,total_us,avg_us,min_us,max_us,percent,avg_us_whole_trace"]
+        for k, v in sorted(steady.items(), key=lambda kv: -sum(kv[1])):
             lines.append('"%s",%d,%.1f,%.2f,%.2f,%.2f,%.2f,%.2f' % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100.0 * sum(v) / tot,
-                                                                  sum(t3) / len(t3)))
+                                                                  sum(per[k]) / len(per[k])))
         with open(stats_out, "w") as f:
             f.write("\n".join(lines) + "\n")
     return out or None
@@ -1719,7 +1721,7 @@ def main(argv=None):
         filt_bytes = (8.0 + 4.0 * n / HOP) * B * T
         if ks:
             per_launch = fir_launches / ks["launches_per_step"]          # filters per launch (1.5 in the fused CombSub step)
-            k_us, k_src = ks["avg_us"], "in-step: rocprofv3 --kernel-trace pass of this run, last third of %d launches" % ks["launches_traced"]
+            k_us, k_src = ks["avg_us"], "in-step: rocprofv3 --kernel-trace pass of this run, the last %d of %d launches" % (ks["launches_averaged"], ks["launches_traced"])
         else:
             per_launch, k_us, k_src = 1.0, fir_ms * 1e3, "alone (no in-step trace in this run): HIP events around 20 back-to-back launches"
         k_bytes, k_flops = filt_bytes * per_launch, fft_flops * per_launch

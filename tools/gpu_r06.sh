@@ -79,6 +79,58 @@ train)
     LAST=100 python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums 2>&1 | head -40 > "$O/${V}_train_${TRACE_KIND:-combsub}_launches.txt"; rm -rf "$O/tp" )
   cat "$O/${V}_train_${TRACE_KIND:-combsub}_launches.txt"
   ;;
+final)
+  # the round's final evidence on ONE box (run under tools/with_reference.sh): GPU suite + smoke (reference-class tests included),
+  # the driver's command (reference as CPU baseline; in-step trace table saved), the other bench rows, the B sweep, steady-state
+  # traces (the last 150 of 600 steps), SQ counters of the step's kernels, training steps (with and without the reference's loss),
+  # streaming-shape latencies, the step + mel pair, the communicator check, cfg 5 with the reference's networks
+  timeout 2400 python -m pytest tests -m gpu -q -rs 2>&1 | grep -E "passed|failed|error|SKIPPED" | tee "$O/${V}_pytest_gpu.log"
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke | tee "$O/${V}_smoke.log"
+  ( time timeout 1200 python bench.py --trace-stats-out "$O/${V}_bench_in_step_kernel_stats.csv" ) 2>"$O/${V}_bench_combsub.err" | tail -1 > "$O/${V}_bench_combsub.json"; tail -4 "$O/${V}_bench_combsub.err"
+  line "$O/${V}_bench_combsub.json"
+  for m in sins combsubsuperfast combsubfast rssloss mel sinesrc; do
+    timeout 300 python bench.py --model $m --no-also --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > "$O/${V}_bench_$m.json"
+  done
+  echo "== B sweep"; for B in 16 32 64 128 256; do f="$O/${V}_sweep_B${B}.json"; timeout 300 $BENCH --batch-per-gpu $B --steps 60 2>&1 | tail -1 > "$f"; line "$f"; done
+  export LAST=150
+  for m in combsub sins; do MODEL=$m; echo "== steady-state trace, $m"; TRACE_STEPS=600 SERIES_POS=3 trace $m X=1 > /dev/null; cat "$O/${V}_${m}_launches.txt" | head -12; done
+  MODEL=combsub
+  echo "== two-stream layout of rounds 2 - 5 (knob STREAM_LAYOUT = 4), same box"
+  for rep in 1 2; do for t in "fused:X=1" "two_streams:DDSP_HIP_STREAM_LAYOUT=4"; do name=${t%%:*}; f="$O/${V}_bench_${name}_$rep.json"; env ${t#*:} timeout 300 $BENCH 2>&1 | tail -1 > "$f"; line "$f"; done; done
+  MODELS=combsub bash tools/gpu_step_pmc.sh > /dev/null 2>&1; cp "$O/step_pmc_combsub.txt" "$O/${V}_pmc_combsub.txt"; grep -c . "$O/${V}_pmc_combsub.txt"
+  for k in combsub sins combsubsuperfast combsubfast combsub512; do timeout 300 python tools/train_step_probe.py $k 2>&1 | tail -1; done | tee "$O/${V}_train_ms.txt"
+  for k in combsub sins combsubsuperfast; do timeout 300 python tools/train_step_probe.py $k loss 2>&1 | tail -1; done | tee -a "$O/${V}_train_ms.txt"
+  ( cd /tmp; rm -rf "$O/tp"; TRAIN_WARM=300 TRAIN_STEPS=100 timeout 300 rocprofv3 --kernel-trace -d "$O/tp" -o t -- python "$R/tools/train_step_probe.py" combsub > /dev/null 2>&1
+    f=$(find "$O/tp" -name "*.db" | head -1)
+    LAST=100 python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums 2>&1 | head -40 > "$O/${V}_train_combsub_launches.txt"; rm -rf "$O/tp" )
+  timeout 300 python tools/latency_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee "$O/${V}_latency_small_shapes.txt"
+  timeout 300 python tools/mel_pair_probe.py 2>&1 | tail -1 | tee "$O/${V}_mel_pair.txt"
+  echo "== communicator" | tee "$O/${V}_pg_check.txt"
+  for q in 4 8; do for m in none nccl; do GPU_MAX_HW_QUEUES=$q timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | sed "s/^/queues=$q /" | tee -a "$O/${V}_pg_check.txt"; done; done
+  if [ -n "${DDSP_REFERENCE_PATH:-}" ]; then
+    timeout 1200 python bench.py --model cascade_ref --batch-per-gpu 64 2>"$O/${V}_bench_cascade_ref.err" | tail -1 > "$O/${V}_bench_cascade_ref.json"
+    cut -c1-900 "$O/${V}_bench_cascade_ref.json"; tail -2 "$O/${V}_bench_cascade_ref.err"
+  fi
+  python - <<'PY'
+import json, os
+V = os.environ["V"]
+d = json.loads(open("gpurun_out/%s_bench_combsub.json" % V).read())
+print({k: d[k] for k in ("value", "ms_per_step", "ms_per_step_events")})
+print("parity", d.get("parity_vs_oracle"))
+r = d["roofline"]; print("roofline", {k: r[k] for k in r if k not in ("note", "traffic_detail", "in_step_kernels")})
+print("step traffic", (d.get("roofline_step_traffic") or {}).get("ratio"))
+c = d.get("cfg4"); print("cfg4", c and {k: c.get(k) for k in ("ms_per_step", "ms_per_step_with_gather", "ms_per_step_with_gather_async", "value")})
+print("also", {k: round(v["ms_per_step"], 4) for k, v in d.get("also", {}).items()})
+print("cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("kind", "value", "cores", "sample", "gpu_over_cpu")})
+print("module mode", d.get("value_module_mode"))
+for m in ("sins", "combsubsuperfast", "combsubfast", "rssloss", "mel", "sinesrc"):
+    try:
+        e = json.loads(open("gpurun_out/%s_bench_%s.json" % (V, m)).read())
+        print(m, round(e["ms_per_step"], 4), e.get("in_kernel_noise", {}).get("ms_per_step"))
+    except Exception as ex:
+        print(m, "ERR", ex)
+PY
+  ;;
 default)
   ( time timeout 900 python bench.py ) 2>"$O/${V}_bench_default.err" | tail -1 > "$O/${V}_bench_default.json"; tail -4 "$O/${V}_bench_default.err"
   line "$O/${V}_bench_default.json"
