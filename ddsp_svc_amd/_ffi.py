@@ -47,6 +47,9 @@ SIGNATURES = {
     "ddsp_hip_uniform_noise": (c_int, [ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, c_long, P, P]),
     "ddsp_hip_synth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddsp_hip_tail_layout": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "ddsp_hip_combsub_tail_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddsp_hip_combsub_tail_backward": (c_int, [P, P, c_long, P, c_long, P, c_long, P, c_int, P, P, P, c_int, c_int, c_int, c_double,
+                                               c_int, P, P, P, P, P, c_size_t, P]),
     "ddsp_hip_combtooth": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_int, P, P]),
     "ddsp_hip_sinusoid_bank": (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_double, c_int, P, P]),
     "ddsp_hip_sinusoid_bank_backward_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),

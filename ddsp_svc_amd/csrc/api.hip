@@ -824,6 +824,78 @@ int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int
   return 1;
 }
 
+// ---- the backward pass of a fused CombSub tail call (solver.py:93-103: the same forward with gradients) --------------------
+// FOUR launches on the caller's stream, on the intermediates ddsp_hip_combsub_synth left in ITS workspace (ddsp_hip_tail_layout):
+//     k_fir_blk_bwd<true>     harmonic filter: d h1 (input gradient) and d taps_h                  (vocoder.py:847-851 backwards)
+//     k_fir_blk_bwd6          all-pass filter's d taps (from d h1)  +  noise filter's d taps        (two jobs)
+//     k_taps_pfa510_bwd       the three tap-synthesis adjoints (dynamic window from f0, roll, Hann) (three jobs)
+//     k_allpass_backward_256  (d re, d im) -> d group-delay control
+// g_harm / g_noise: the cotangents that reach the harmonic / the noise branch ([B,T]; NULL = none: that branch's gradients are
+// not touched).  ws: ddsp_hip_combsub_tail_backward_ws_bytes.
+size_t ddsp_hip_combsub_tail_backward_ws_bytes(int B, int F, int hop, int n_mag) {
+  if (B <= 0 || F <= 0 || hop <= 0 || n_mag < 2) return 0;
+  Carver c(reinterpret_cast<void*>((uintptr_t)4096), (size_t)1 << 60);
+  const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_mag - 1);
+  c.take<float>(BT);
+  for (int i = 0; i < 3; ++i) c.take<float>(R * N);
+  c.take<float>(R * n_mag);
+  c.take<float>(R * n_mag);
+  return align_up(c.used, 256);
+}
+
+int ddsp_hip_combsub_tail_backward(const float* f0_frames, const float* c_gd, long ld_gd, const float* c_harm, long ld_harm,
+                                   const float* c_nz, long ld_nz, const float* noise, int noise_is_u01, const void* fwd_ws,
+                                   const float* g_harm, const float* g_noise, int B, int F, int hop, double sr, int n_mag,
+                                   const float* table, float* d_gd, float* d_harm, float* d_nz, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (B < 0 || F <= 0 || hop != 512 || n_mag != 256 || !(sr > 0)) return DDSP_HIP_ESHAPE;
+  if (B == 0) return 0;
+  if (!f0_frames || !c_gd || !c_harm || !c_nz || !noise || !fwd_ws || !table || !ws) return DDSP_HIP_EINVAL;
+  if (ld_gd < n_mag || ld_harm < n_mag || ld_nz < n_mag) return DDSP_HIP_EINVAL;
+  if ((g_harm && (!d_gd || !d_harm)) || (g_noise && !d_nz)) return DDSP_HIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0 || (reinterpret_cast<uintptr_t>(fwd_ws) & 15) != 0) return DDSP_HIP_EINVAL;
+  long long off[6];
+  if (ddsp_hip_tail_layout(1, B, F, hop, n_mag, n_mag, n_mag, 0, 0, off) != 1) return DDSP_HIP_ESHAPE;
+  const char* fw = static_cast<const char*>(fwd_ws);
+  const float* comb = reinterpret_cast<const float*>(fw + off[0]);
+  const float* h1 = reinterpret_cast<const float*>(fw + off[1]);
+  const float* taps_ap = reinterpret_cast<const float*>(fw + off[2]);
+  const float* taps_h = reinterpret_cast<const float*>(fw + off[3]);
+  const float* taps_nz = reinterpret_cast<const float*>(fw + off[4]);
+  Carver c(ws, ws_bytes);
+  const size_t BT = (size_t)B * F * hop, R = (size_t)B * F, N = 2 * (size_t)(n_mag - 1);
+  float* d_h1 = c.take<float>(BT);
+  float* dt_h = c.take<float>(R * N);
+  float* dt_ap = c.take<float>(R * N);
+  float* dt_nz = c.take<float>(R * N);
+  float* d_re = c.take<float>(R * n_mag);
+  float* d_im = c.take<float>(R * n_mag);
+  if (!c.ok) return DDSP_HIP_EWS;
+  hipStream_t st = S(stream);
+  const int Ni = (int)N;
+  if (g_harm) {
+    if (launch_fir_blk_bwd(h1, 0, taps_h, g_harm, d_h1, dt_h, B, F, hop, Ni, st) != 0) return DDSP_HIP_ESHAPE;
+    const FirBwdSecond second{noise, noise_is_u01, g_noise, dt_nz};
+    if (launch_fir_blk_bwd(comb, 0, taps_ap, d_h1, nullptr, dt_ap, B, F, hop, Ni, st, g_noise ? &second : nullptr) != 0) {
+      // (knob BWD_WPS = 2: the two-wave kernel takes no second job: one launch each)
+      if (launch_fir_blk_bwd(comb, 0, taps_ap, d_h1, nullptr, dt_ap, B, F, hop, Ni, st) != 0) return DDSP_HIP_ESHAPE;
+      if (g_noise && launch_fir_blk_bwd(noise, noise_is_u01, taps_nz, g_noise, nullptr, dt_nz, B, F, hop, Ni, st) != 0) return DDSP_HIP_ESHAPE;
+    }
+  } else if (g_noise) {
+    if (launch_fir_blk_bwd(noise, noise_is_u01, taps_nz, g_noise, nullptr, dt_nz, B, F, hop, Ni, st) != 0) return DDSP_HIP_ESHAPE;
+  }
+  TapsBwdJobs jobs;
+  jobs.n = 0;
+  if (g_harm) {
+    jobs.j[jobs.n++] = TapsBwdJob{1, 0, DDSP_HIP_MODE_DYNAMIC, dt_h, c_harm, ld_harm, 1.0f, nullptr, f0_frames, (float)sr, d_harm, nullptr};
+    jobs.j[jobs.n++] = TapsBwdJob{0, 1, DDSP_HIP_MODE_ROLL, dt_ap, nullptr, 0, 1.0f, nullptr, nullptr, 0.f, d_re, d_im};
+  }
+  if (g_noise) jobs.j[jobs.n++] = TapsBwdJob{1, 0, DDSP_HIP_MODE_HANN, dt_nz, c_nz, ld_nz, 1.0f / 128.0f, nullptr, nullptr, 0.f, d_nz, nullptr};
+  if (jobs.n && launch_taps_pfa510_bwd_jobs(jobs, table, (long)R, st) != 0) return DDSP_HIP_ESHAPE;
+  if (g_harm) launch_allpass_backward(c_gd, ld_gd, (long)R, n_mag, d_re, d_im, d_gd, st);
+  return finish();
+}
+
 int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,
                         long ld_amp, const float* c_gd, long ld_gd, const float* c_nz, long ld_nz, const float* noise,
                         int noise_is_u01, int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,

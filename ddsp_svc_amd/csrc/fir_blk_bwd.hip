@@ -340,9 +340,18 @@ __global__ void __launch_bounds__(128, 2) k_fir_blk_bwd(const float* __restrict_
 // the product sweep splits it bin by bin where it consumes it (own value and mirror image, as the forward kernel's tap
 // transform).  Carried between passes: U of the pair's second block (16 registers, the forward kernel's Hc).  Every load is
 // issued a pass ahead.  Same operator, same geometry rules, rounding-level differences to the two-wave kernel (knob BWD_WPS = 2).
+// A launch takes one or two JOBS (grid.y): tap gradients of filters of the same shape that do not depend on each other -- the
+// all-pass and the noise filter of a CombSub training step (ddsp_hip_combsub_tail_backward).
+struct FirBwdJob { const float* x; int x_is_u01; const float* grad_out; float* d_taps; };
+struct FirBwdJobs { FirBwdJob j[2]; };
+
 template <int DUMMY = 0>
-__global__ void __launch_bounds__(128, 3) k_fir_blk_bwd6(const float* __restrict__ x, int x_is_u01, const float* __restrict__ grad_out,
-                                                        float* __restrict__ d_taps, FirBwdGeom g) {
+__global__ void __launch_bounds__(128, 3) k_fir_blk_bwd6(FirBwdJobs jobs, FirBwdGeom g) {
+  const FirBwdJob& J = jobs.j[blockIdx.y];
+  const float* __restrict__ x = J.x;
+  const int x_is_u01 = J.x_is_u01;
+  const float* __restrict__ grad_out = J.grad_out;
+  float* __restrict__ d_taps = J.d_taps;
   using PL = fft::Plan1024P;
   constexpr int NF = PL::N, P = PL::P, S = 8;
   __shared__ __attribute__((aligned(16))) f32x2 ex[3][PL::WORDS];
@@ -510,7 +519,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk_bwd6(const float* __restrict
 }
 
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
-                       int B, int F, int hop, int N, hipStream_t st) {
+                       int B, int F, int hop, int N, hipStream_t st, const FirBwdSecond* second) {
   if (hop != FBW_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance below 2^30 bytes (buffer descriptors)
   FirBwdGeom g;
   g.F = F; g.N = N; g.T = F * hop;
@@ -524,9 +533,10 @@ int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const fl
   if (run > g.pairs) run = g.pairs;
   g.run = run;
   g.runs_per_utt = (g.pairs + run - 1) / run;
+  if (second && (d_x || knob(KNOB_BWD_WPS) == 2)) return -1;    // a second job rides in the three-wave tap-gradient kernel only
   if (!d_x && knob(KNOB_BWD_WPS) != 2) {                         // the tap gradient alone: three waves per SIMD, six workgroups per CU
     const long slots6 = 6L * 256;
-    long pu = slots6 / (B > 0 ? B : 1);
+    long pu = slots6 / ((second ? 2L : 1L) * (B > 0 ? B : 1));    // two jobs share the one round: runs twice as long, half the warm-ups
     if (pu < 1) pu = 1;
     int run6 = (int)((g.pairs + pu - 1) / pu);
     if (run6 < 3) run6 = 3;
@@ -536,7 +546,10 @@ int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const fl
     g.runs_per_utt = (g.pairs + run6 - 1) / run6;
     const long wgs6 = (long)B * g.runs_per_utt;
     if (wgs6 > 0x7fffffffL) return -1;
-    hipLaunchKernelGGL(k_fir_blk_bwd6<0>, dim3((unsigned)wgs6), dim3(128), 0, st, x, x_is_u01, grad_out, d_taps, g);
+    FirBwdJobs jobs;
+    jobs.j[0] = FirBwdJob{x, x_is_u01, grad_out, d_taps};
+    jobs.j[1] = second ? FirBwdJob{second->x, second->x_is_u01, second->grad_out, second->d_taps} : jobs.j[0];
+    hipLaunchKernelGGL(k_fir_blk_bwd6<0>, dim3((unsigned)wgs6, second ? 2u : 1u), dim3(128), 0, st, jobs, g);
     return 0;
   }
   const long wgs = (long)B * g.runs_per_utt;

@@ -604,11 +604,18 @@ __global__ void __launch_bounds__(256, DDSP_PFA_WGS) k_front_small(TapsJobs jobs
 // transform as conj(dz_a + i dz_b), Out = IDFT+(that) = conj(D_a + i D_b), and the two spectra are separated with
 // Out[510 - k].  Replaces the dense MFMA contraction k_ir_gemm_bwd at n_mag = 256 (0.10-0.13 ms per launch there).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(int ACT, int HAS_IM, int MODE, const float* __restrict__ d_taps,
-                                                         const float* __restrict__ ctrl, long ld_ctrl, float scale,
-                                                         const float* __restrict__ hann, const float* __restrict__ half_width,
-                                                         long rows, float* __restrict__ d_re, float* __restrict__ d_im) {
+__global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(TapsBwdJobs jobs, long rows) {
   using namespace pfa;
+  const TapsBwdJob& J = jobs.j[blockIdx.y];                 // workgroup-uniform, like everything it selects
+  const int ACT = J.act, HAS_IM = J.has_im, MODE = J.mode;
+  const float* __restrict__ d_taps = J.d_taps;
+  const float* __restrict__ ctrl = J.ctrl;
+  const long ld_ctrl = J.ld_ctrl;
+  const float scale = J.scale, hw_sr = J.hw_sr;
+  const float* __restrict__ hann = J.hann;
+  const float* __restrict__ half_width = J.half_width;
+  float* __restrict__ d_re = J.d_re;
+  float* __restrict__ d_im = J.d_im;
   __shared__ __attribute__((aligned(16))) float U[LDS_FLOATS];
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * ROWS;
@@ -617,7 +624,9 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(int ACT, int HAS_IM,
   f32x2* Out = reinterpret_cast<f32x2*>(U);                // B -> C: Out[t][k] complex
   if (MODE == MODE_DYNAMIC && tid < 64) {                  // the batch's window rows (stage_window_rows), as the forward kernel's
     const long gr = row0 + tid;
-    stage_window_rows(U, tid, (tid < ROWS && gr < rows) ? half_width[gr] : 1.0f);
+    float x = (tid < ROWS && gr < rows) ? half_width[gr] : 1.0f;
+    if (hw_sr > 0.f && tid < ROWS && gr < rows) x = (1.5f * hw_sr) / (x + 1e-3f);   // vocoder.py:851, the forward kernel's operations
+    stage_window_rows(U, tid, x);
   }
   if (MODE == MODE_DYNAMIC) __syncthreads();
   const bool fast_window = MODE == MODE_DYNAMIC && U[HW_FLAG] == 0.0f;      // workgroup-uniform
@@ -760,8 +769,24 @@ int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl,
   const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
   const float* hann = table + 2 * KP * NP;
   const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
-  hipLaunchKernelGGL(k_taps_pfa510_bwd, dim3((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), dim3(256), 0, st, act == 1 ? 1 : 0,
-                     has_im ? 1 : 0, m, d_taps, ctrl, ld_ctrl, scale, hann, half_width, rows, d_re, d_im);
+  TapsBwdJobs jobs;
+  jobs.n = 1;
+  jobs.j[0] = TapsBwdJob{act == 1 ? 1 : 0, has_im ? 1 : 0, m, d_taps, ctrl, ld_ctrl, scale, hann, half_width, 0.f, d_re, d_im};
+  jobs.j[1] = jobs.j[2] = jobs.j[0];
+  hipLaunchKernelGGL(k_taps_pfa510_bwd, dim3((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), dim3(256), 0, st, jobs, rows);
+  return 0;
+}
+
+int launch_taps_pfa510_bwd_jobs(const TapsBwdJobs& in, const float* table, long rows, hipStream_t st) {
+  if (in.n < 1 || in.n > 3 || rows <= 0) return -1;
+  const long KP = ((long)pfa::NB + 15) / 16 * 16, NP = ((long)pfa::NB + 255) / 256 * 256;
+  TapsBwdJobs jobs = in;
+  for (int i = 0; i < jobs.n; ++i) {
+    if ((reinterpret_cast<uintptr_t>(jobs.j[i].d_taps) & 15) != 0) return -1;
+    jobs.j[i].hann = table + 2 * KP * NP;                   // the periodic Hann of the basis table (k_ir_table, ir.hip)
+  }
+  for (int i = jobs.n; i < 3; ++i) jobs.j[i] = jobs.j[0];
+  hipLaunchKernelGGL(k_taps_pfa510_bwd, dim3((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS), (unsigned)jobs.n), dim3(256), 0, st, jobs, rows);
   return 0;
 }
 

@@ -72,6 +72,16 @@ int launch_taps_pfa510_batch(const TapsJobs& jobs, hipStream_t st, const Exciter
 int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl, int act, float scale, const float* table,
                            int mode, const float* half_width, long rows, int n, int has_im, float* d_re, float* d_im,
                            hipStream_t st);
+// up to three tap-synthesis adjoints of the same row count as ONE launch (grid.y): a training step's three (n_mag 256).
+// hw_sr > 0: half_width holds f0 and the half width is 1.5 hw_sr / (f0 + 1e-3) (vocoder.py:851), formed in the kernel
+struct TapsBwdJob {
+  int act, has_im, mode;
+  const float* d_taps; const float* ctrl; long ld_ctrl; float scale;
+  const float* hann; const float* half_width; float hw_sr;
+  float* d_re; float* d_im;
+};
+struct TapsBwdJobs { TapsBwdJob j[3]; int n; };
+int launch_taps_pfa510_bwd_jobs(const TapsBwdJobs& jobs, const float* table, long rows, hipStream_t st);
 void launch_window_taps(const float* in, int mode, const float* half_width, long rows, int N, float* out, hipStream_t st);
 void launch_allpass_backward(const float* c, long ld, long rows, int n, const float* d_re, const float* d_im, float* d_c,
                              hipStream_t st);
@@ -89,8 +99,11 @@ struct FirSecond { const float* x; int x_is_u01; const float* taps; const float*
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr,
                    const FirSecond* second = nullptr);
+// second != null: a second, independent TAP gradient of the same shape rides in the same launch (k_fir_blk_bwd6, grid.y); -1 when
+// this launch cannot take it (an input gradient is wanted, knob BWD_WPS = 2)
+struct FirBwdSecond { const float* x; int x_is_u01; const float* grad_out; float* d_taps; };
 int launch_fir_blk_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
-                       int B, int F, int hop, int N, hipStream_t st);
+                       int B, int F, int hop, int N, hipStream_t st, const FirBwdSecond* second = nullptr);
 // hop 512, even N <= 1022 (fir_fft_bwd.hip): the per-frame 2048-point form, what N = 514 .. 1022 take; d_x may be null
 int launch_fir_fft_bwd(const float* x, int x_is_u01, const float* taps, const float* grad_out, float* d_x, float* d_taps,
                        int B, int F, int hop, int N, hipStream_t st);

@@ -389,20 +389,24 @@ class CombSubTailFunction(torch.autograd.Function):
     def backward(ctx, g_sig, g_harm, g_nz):
         f0, cg, ch, cn, nz, ws = ctx.saved_tensors
         ldg, ldh, ldn, u01, sr, hop, lay, (B, F, T, N) = ctx.cfg
-        comb, h1 = _ws_view(ws, lay[0], (B, T)), _ws_view(ws, lay[1], (B, T))
-        taps_ap, taps_h, taps_nz = (_ws_view(ws, lay[i], (B, F, N)) for i in (2, 3, 4))
-        gh = _sum_cot((B, T), f0.device, g_sig, g_harm)
-        gn = _sum_cot((B, T), f0.device, g_sig, g_nz)
-        d_cg = d_ch = d_cn = None
-        if gh is not None:
-            d_h1, d_taps_h = _fir_bwd(h1, False, taps_h, gh, True)                          # vocoder.py:847-851 backwards
-            hw = (1.5 * sr) / (f0 + 1e-3)                                                    # :851
-            d_ch = _mag_taps_bwd(d_taps_h, ch, ldh, 1.0, _ffi.MODE_DYNAMIC, _f32c(hw.reshape(B * F)))
-            _, d_taps_ap = _fir_bwd(comb, False, taps_ap, d_h1, False)                       # :843-846
-            d_cg = _allpass_taps_bwd(d_taps_ap, cg, ldg)
-        if gn is not None:
-            _, d_taps_nz = _fir_bwd(nz, u01, taps_nz, gn, False)                             # :854-858
-            d_cn = _mag_taps_bwd(d_taps_nz, cn, ldn, 1.0 / 128.0, _ffi.MODE_HANN, None)
+        dev = f0.device
+        gh = _sum_cot((B, T), dev, g_sig, g_harm)
+        gn = _sum_cot((B, T), dev, g_sig, g_nz)
+        if gh is None and gn is None:
+            return (None,) * 10
+        n = N // 2 + 1
+        lib = _ffi.lib()
+        # four launches (csrc/api.hip, ddsp_hip_combsub_tail_backward): harmonic filter's adjoint | all-pass + noise filter tap
+        # gradients (two jobs) | the three tap-synthesis adjoints (three jobs; the dynamic window's half widths from f0 in the kernel) |
+        # all-pass activation
+        need = lib.ddsp_hip_combsub_tail_backward_ws_bytes(B, F, hop, n)
+        bws = torch.empty(need, dtype=torch.uint8, device=dev)
+        d_cg = torch.empty(B, F, n, dtype=torch.float32, device=dev) if gh is not None else None
+        d_ch = torch.empty(B, F, n, dtype=torch.float32, device=dev) if gh is not None else None
+        d_cn = torch.empty(B, F, n, dtype=torch.float32, device=dev) if gn is not None else None
+        _ffi.check(lib.ddsp_hip_combsub_tail_backward(
+            ptr(f0), ptr(cg), ldg, ptr(ch), ldh, ptr(cn), ldn, ptr(nz), int(u01), ptr(ws), ptr(gh), ptr(gn), B, F, hop, sr, n,
+            ptr(ir_table(n, dev)), ptr(d_cg), ptr(d_ch), ptr(d_cn), ptr(bws), need, _ffi.stream_of(f0)))
         return None, None, d_cg, d_ch, d_cn, None, None, None, None, None
 
 

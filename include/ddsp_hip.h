@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 161          /* 0.1.6.1: + ddsp_hip_tail_layout; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
+#define DDSP_HIP_VERSION 162          /* 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -202,6 +202,20 @@ size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
  * when it does not (other bin counts / hops, in-kernel noise, sub-batch lanes: nothing is promised), < 0 on bad arguments. */
 int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int n2, int fir_impl, int in_kernel_noise,
                          long long offsets[6]);
+
+/* The backward pass of a fused ddsp_hip_combsub_synth call (256 / 256 / 256 bins, hop 512: where ddsp_hip_tail_layout returns 1) as
+ * FOUR launches on `stream`: what autograd returns for the three raw controls of vocoder.py:834-862 given the cotangents that
+ * reach the harmonic branch (g_harm [B,T]: d signal + d harmonic) and the noise branch (g_noise [B,T]: d signal + d noise); either
+ * may be NULL (that branch's gradients are not written).  fwd_ws is the forward call's workspace, untouched since; f0 / controls /
+ * noise are that call's; table = the 256-bin basis table.  d_gd, d_harm, d_nz: [B,F,256] contiguous.  ws (16-byte aligned):
+ * ddsp_hip_combsub_tail_backward_ws_bytes(B, F, hop, 256) bytes.  DDSP_HIP_ESHAPE for any other shape (use the per-operator
+ * adjoints: ddsp_hip_fft_convolve_backward, ddsp_hip_impulse_response_backward, ddsp_hip_allpass_backward). */
+size_t ddsp_hip_combsub_tail_backward_ws_bytes(int B, int F, int hop, int n_mag);
+int ddsp_hip_combsub_tail_backward(const float* f0_frames, const float* c_gd, long ld_gd, const float* c_harm, long ld_harm,
+                                   const float* c_nz, long ld_nz, const float* noise, int noise_is_u01, const void* fwd_ws,
+                                   const float* g_harm, const float* g_noise, int B, int F, int hop, double sr, int n_mag,
+                                   const float* table, float* d_gd, float* d_harm, float* d_nz, void* ws, size_t ws_bytes,
+                                   void* stream);
 
 /* exciters on their own (used by tests and by callers that want the intermediate):
  * combtooth (vocoder.py:839-840) and the sinusoid bank (vocoder.py:585-594), out[B,T] */
