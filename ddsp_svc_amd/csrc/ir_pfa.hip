@@ -417,9 +417,20 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   PFA_STAMP(1);
 
   // ---- stage A: DFT-17 over n1 of Z[(30 n1 + 17 n2) mod 510], Z = X_a + i X_b, X[510 - k] = conj X[k] ----
+  // A REAL response (zero-phase magnitude filter) is EVEN after its Hermitian extension, Z[-n] = Z[n], and so is its transform:
+  // column 30 - n2 of this stage is column n2 with k1 reversed, W[k1][30 - n2] = W[17 - k1][n2], so 16 of the 30 columns are
+  // computed (128 threads: two full waves instead of four), and stage B computes rows k1 = 0 .. 8 only -- row 17 - k1 is the same
+  // numbers at the mirrored taps -- reading the missing columns from the mirrored row and writing every result twice.  (Round 2
+  // built this when a launch's length was set by its latencies and it did not pay; in the fused front launch, which runs at the
+  // vector pipe's rate, it does: EXPERIMENTS 6.8.  -DDDSP_PFA_NOSYM: the full form, for A/Bs.)
+#ifdef DDSP_PFA_NOSYM
+  const bool sym = false;
+#else
+  const bool sym = KIND == KIND_REAL;                       // workgroup-uniform
+#endif
   {
-    const bool act = tid < TR * 30;
-    const int t = act ? tid / 30 : 0, n2 = act ? tid - 30 * t : 0;
+    const bool act = sym ? tid < TR * 16 : tid < TR * 30;
+    const int t = !act ? 0 : (sym ? tid >> 4 : tid / 30), n2 = !act ? 0 : (sym ? tid & 15 : tid - 30 * t);
     f32x2 z[17];
     {
       const float* ra = re_s + (2 * t) * NB;
@@ -459,13 +470,19 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
 
   // ---- stage B: DFT-30 over n2; output index m = (120 k1 + 391 k2) mod 510; roll by N/2: tap j = (m + 255) mod 510 ----
   {
-    const bool act = tid < TR * 17;
-    const int t = act ? tid / 17 : 0, k1 = act ? tid - 17 * t : 0;
+    const bool act = sym ? tid < TR * 9 : tid < TR * 17;
+    const int t = !act ? 0 : (sym ? tid / 9 : tid / 17), k1 = !act ? 0 : (sym ? tid - 9 * t : tid - 17 * t);
     f32x2 v[30];
     {
       const f32x2* src = W + w_row(t * 17 + k1);
+      if (sym) {                                            // columns 16 .. 29 live in the mirrored row (row 0 mirrors itself)
+        const f32x2* msrc = W + w_row(t * 17 + (k1 ? 17 - k1 : 0));
 #pragma unroll
-      for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
+        for (int n2 = 0; n2 < 30; ++n2) v[n2] = n2 <= 15 ? src[n2] : msrc[30 - n2];
+      } else {
+#pragma unroll
+        for (int n2 = 0; n2 < 30; ++n2) v[n2] = src[n2];
+      }
     }
     float hw_row = 1.f;
     if (MODE == MODE_DYNAMIC && tid < ROWS) {              // the batch's 16 half widths: in flight across the barrier
@@ -489,6 +506,11 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
         if (j >= NT) j -= NT;
         oa[j] = v[k2].x;
         ob[j] = v[k2].y;
+        if (sym && k1 != 0) {                               // z[-m] = z[m]: tap 510 - j (row k1 = 0 holds both of its own)
+          const int jm = j ? NT - j : 0;
+          oa[jm] = v[k2].x;
+          ob[jm] = v[k2].y;
+        }
       }
     }
   }

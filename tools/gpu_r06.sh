@@ -34,7 +34,7 @@ trace() {  # trace <tag> [env..]: kernel trace of steady-state steps -> timeline
     f=$(find "$O/gp" -name "*.db" | head -1)
     python "$R/tools/rocpd_gaps.py" "$f" 2>&1 > "$O/${V}_gaps_$tag.txt"
     python "$R/tools/rocpd_stats.py" "$f" 2>&1 | head -14 > "$O/${V}_${tag}_kernel_stats.csv"
-    python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums ${SERIES_POS:-4} 2>&1 > "$O/${V}_${tag}_launches.txt"
+    CSV_OUT="$O/${V}_${tag}_steady_kernel_stats.csv" python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums ${SERIES_POS:-4} 2>&1 > "$O/${V}_${tag}_launches.txt"
     rm -rf "$O/gp" )
   head -40 "$O/${V}_gaps_$tag.txt"; head -8 "$O/${V}_${tag}_kernel_stats.csv"; cat "$O/${V}_${tag}_launches.txt"
 }
@@ -95,6 +95,8 @@ final)
   export LAST=150
   for m in combsub sins; do MODEL=$m; echo "== steady-state trace, $m"; TRACE_STEPS=600 SERIES_POS=3 trace $m X=1 > /dev/null; cat "$O/${V}_${m}_launches.txt" | head -12; done
   MODEL=combsub
+  echo "== one launch per kernel (rounds 2 - 5's layout, knob STREAM_LAYOUT = 4, one stream): the kernels' own steady-state times"
+  TRACE_STEPS=600 SERIES_POS=4 trace layout4_one_stream DDSP_HIP_STREAM_LAYOUT=4 DDSP_HIP_ONE_STREAM=1 > /dev/null; head -12 "$O/${V}_layout4_one_stream_launches.txt"; cat "$O/${V}_layout4_one_stream_steady_kernel_stats.csv"
   echo "== two-stream layout of rounds 2 - 5 (knob STREAM_LAYOUT = 4), same box"
   for rep in 1 2; do for t in "fused:X=1" "two_streams:DDSP_HIP_STREAM_LAYOUT=4"; do name=${t%%:*}; f="$O/${V}_bench_${name}_$rep.json"; env ${t#*:} timeout 300 $BENCH 2>&1 | tail -1 > "$f"; line "$f"; done; done
   MODELS=combsub bash tools/gpu_step_pmc.sh > /dev/null 2>&1; cp "$O/step_pmc_combsub.txt" "$O/${V}_pmc_combsub.txt"; grep -c . "$O/${V}_pmc_combsub.txt"

@@ -29,3 +29,14 @@ if len(sys.argv) > 3:                                         # time series of o
     i = int(sys.argv[3])
     print("position #%d over the steps:" % i, " ".join("%.1f" % ((s[i][2] - s[i][1]) / 1e3) for s in steps))
     print("step to step over the steps:", " ".join("%.0f" % ((b[0][1] - a[0][1]) / 1e3) for a, b in zip(steps[:-1], steps[1:])))
+if os.environ.get("CSV_OUT"):                                 # per-kernel table over the SAME steps (steady state when LAST is set)
+    per = {}
+    for st_ in steps:
+        for name, a_, b_ in st_:
+            per.setdefault(name.split("(")[0], []).append((b_ - a_) / 1e3)
+    tot = sum(sum(v) for v in per.values()) or 1.0
+    with open(os.environ["CSV_OUT"], "w") as f:
+        f.write("# the last %d steps of the trace (past the clocks' transient), %d launches per step\n" % (len(steps), n))
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            f.write('"%s",%d,%.1f,%.2f,%.2f,%.2f,%.2f\n' % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100.0 * sum(v) / tot))
