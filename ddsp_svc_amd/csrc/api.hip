@@ -316,7 +316,8 @@ bool fused_off() {
 bool fused_shape_ok(long R, int F, int hop, int n0, int n1, int n2, int fir_impl, bool gen_on, bool combsub) {
   if (!(R < kSmallRows || !fused_off()) || hop != 512 || t_taps_gemm || knob(KNOB_SMALL_PATH) == 1) return false;
   if (combsub) {
-    if (n0 != 256 || n1 != 256 || n2 != 256 || gen_on || !(fir_impl == 0 || fir_impl == 5)) return false;
+    (void)gen_on;                                            // (the in-kernel noise draw rides in the paired filter launch as its second job)
+    if (n0 != 256 || n1 != 256 || n2 != 256 || !(fir_impl == 0 || fir_impl == 5)) return false;
     if ((long)F * hop > (1L << 24) || R >= (1L << 31) - 64) return false;       // the exciter job's shift form (make_exciter_job)
 #ifdef DDSP_AB_GENERATIONS                                   // (the two-wave kernel of the A/B builds takes no second job: launch_fir_blk's predicate)
     if (!((knob(KNOB_BLK_WPS) == 0 || knob(KNOB_BLK_WPS) >= 3) && knob(KNOB_BLK_PADLDS) == 0)) return false;
@@ -736,7 +737,7 @@ int combsub_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream
                              n_harm, w.taps3, st, (float)a.sr, &jobs);
     if (ok != 0 || launch_taps_pfa510_batch(jobs, st, &exc) != 0) return DDSP_HIP_ESHAPE;   // exciter + the three tap syntheses
     const FirSecond second{a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr};
-    if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, nullptr, &second) < 0)
+    if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, a.gen.on ? &a.gen : nullptr, &second) < 0)
       return DDSP_HIP_ESHAPE;
     if (launch_fir(w.buf1, 0, w.taps3, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_harm - 1), a.fir_impl, st) < 0)
       return DDSP_HIP_ESHAPE;

@@ -381,6 +381,7 @@ struct FirJob {
   const float* x; int x_is_u01;
   const float* taps; const float* addend;
   float* out; float* out_plain;
+  int rng;                      // k_fir_blk6<true> only: THIS job's input is drawn in the load path (the other job of a launch may read its)
 };
 struct FirJobs { FirJob j[2]; };
 
@@ -389,6 +390,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
   const FirJob& J = jobs.j[blockIdx.y];
   const float* __restrict__ x = J.x;
   const int x_is_u01 = J.x_is_u01;
+  const bool draw = RNG && J.rng != 0;                      // workgroup-uniform
   const float* __restrict__ taps = J.taps;
   const float* __restrict__ addend = J.addend;
   float* __restrict__ out = J.out;
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
   struct Blk { float v[4]; };
   auto load_blk = [&](int bi, bool live = true) -> Blk {
     Blk r;
-    if (RNG) {
+    if (draw) {
       const Quad q = philox_uniform4(rng, (unsigned)bu, (unsigned)bi, (unsigned)tid);
 #pragma unroll
       for (int m = 0; m < 4; ++m) r.v[m] = bi < g.F ? q.u[m] : 0.f;
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     for (int m = 4; m < S; ++m) z[m] = f32x2{0.f, 0.f};
   };
   auto pack_blk = [&](const Blk& cx, bool live, f32x2 (&z)[S]) {
-    const bool u01 = (RNG || x_is_u01) && live;                 // noise = rand * 2 - 1 (vocoder.py:603,854)
+    const bool u01 = (draw || x_is_u01) && live;                // noise = rand * 2 - 1 (vocoder.py:603,854)
     const float ua = u01 ? 2.0f : 1.0f, ub = u01 ? -1.0f : 0.0f;
     float l0 = lam0;
     asm volatile("" : "+v"(l0));                                // not a loop invariant (see lam0)
@@ -707,12 +709,21 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
   FirJobs jobs;
-  jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain};
+  jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain, 0};
   jobs.j[1] = jobs.j[0];
+  if (noise_gen && noise_gen->on && second) {                   // two jobs, the SECOND one's input drawn in the kernel (its x may be null)
+#ifdef DDSP_AB_GENERATIONS
+    if (wps < 3) return -1;
+#endif
+    rng = *noise_gen;
+    jobs.j[1] = FirJob{second->x, 0, second->taps, second->addend, second->out, second->out_plain, 1};
+    hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs, 2u), dim3(128), 0, st, jobs, g, rng);
+    return 5;
+  }
   if (noise_gen && noise_gen->on) {                             // the input is drawn in the kernel (x may be null)
-    if (second) return -1;
     rng = *noise_gen;
     jobs.j[0].x_is_u01 = 0;
+    jobs.j[0].rng = jobs.j[1].rng = 1;
 #ifdef DDSP_AB_GENERATIONS
     if (wps < 3) {
       hipLaunchKernelGGL((k_fir_blk<2, true>), dim3((unsigned)wgs), dim3(128), 0, st, x, 0, taps, addend, out, out_plain, g, rng);
@@ -723,7 +734,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
     return 5;
   }
   if (second && wps >= 3) {                                     // two independent filters of this shape in one launch
-    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain};
+    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain, 0};
     hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs, 2u), dim3(128), 0, st, jobs, g, rng);
     return 5;
   }
