@@ -13,17 +13,22 @@ data-path collective ("weak" scaling: B per GPU fixed).
 ranks: fewer than N visible devices is an error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline               the dominant kernel (the time-varying FIR, k_fir_blk6) timed alone with events on the launch stream
+  roofline               the dominant kernel (the time-varying FIR, k_fir_blk6) INSIDE the step at the clocks' steady state: a
+                         rocprofv3 --kernel-trace pass of this run (900 steps, the launches past the first third); frac = SURVEY 8-d
+                         bytes of what one launch processes / that duration / 8 TB/s; bound "valu" (valu_frac beside it); frac_alone
+                         = the kernel timed alone with HIP events; step_hbm_frac / step_traffic_ratio = the whole step's
   roofline_step_traffic  PMC HBM bytes of one whole step over its algorithmic bytes: measured IN this run when rocprofv3 is
                          on the box (two --pmc passes over ``bench.py --only-steps``, ``traffic_source: "live"``), otherwise the
                          newest committed profiles/*_hbm_traffic.json (``traffic_source: "committed"``)
   also                   (N = 1) the other single-GPU BASELINE configs attested by the same command: the Sins cfg-3 step with its
-                         dominant kernel's roofline, and the as-shipped CombSubSuperFast model (informative)
+                         dominant kernel's roofline, the as-shipped CombSubSuperFast model (informative), train_combsub = forward +
+                         backward of the CombSub DSP behind a gradient gate against the oracle's adjoint, and the reference's loss
   cfg4                   (the default N = 1 command, N = 8, or --cfg4) BASELINE cfg 4's per-GPU shape: 64 utterances per GPU,
                          samples/s without and with the RCCL gather, interleaved rounds (a 1-rank communicator at N = 1)
   parity_vs_oracle       the gate every line is printed behind: two utterances of the TIMED output against the oracle
                          (<= 1e-4 RMS abs, <= 1e-5 rel) -- a miss is SystemExit, not a field
-  hip_hw_queues          GPU_MAX_HW_QUEUES of the process (set to 8 here before the HIP runtime loads: see below)
+  hip_hw_queues          GPU_MAX_HW_QUEUES of the process (set to 8 here before the HIP runtime loads: see below; since round 6 the
+                         default launch layout has no second stream and does not depend on it)
   ms_per_step_events     the same K timed steps measured with HIP events on the launch stream, beside the wall clock
   cpu_baseline           the numpy oracle (oracle/ddsp_oracle.py, a port of the reference algorithm) timed
                          on this host's cores over a bounded sample of the same workload (N=1 only); kind "reference" -- the
@@ -1797,17 +1802,16 @@ def main(argv=None):
             def step_rng():
                 st = synth.phase(f0, SR, HOP)
                 return fn(f0, st, ctrls[0], ctrls[1], ctrls[2], None, SR, HOP, want_components=False, noise_seed=7)[0]
-            for _ in range(5):
-                step_rng()
+            prewarm(step_rng, min(a.prewarm_seconds, 0.3))         # (the module-mode steps before this were another workload: the clocks settle again)
             torch.cuda.synchronize()
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             r0.record()
-            for _ in range(30):
+            for _ in range(a.steps):
                 o2 = step_rng()
             r1.record()
             torch.cuda.synchronize()
             assert torch.isfinite(o2).all()
-            res["in_kernel_noise"] = {"ms_per_step": r0.elapsed_time(r1) / 30,
+            res["in_kernel_noise"] = {"ms_per_step": r0.elapsed_time(r1) / a.steps,
                                       "algorithmic_bytes_per_step": (4.0 + 4.0 * (sigma_c + 1) / HOP) * B * T,
                                       "note": "opt-in: Philox4x32-10 draw inside the noise filter instead of a resident "
                                               "noise tensor (a stream of its own, not torch.rand's)"}

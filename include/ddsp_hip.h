@@ -179,18 +179,24 @@ int ddsp_hip_combsub_synth(const float* f0_frames, const float* initial_phase, c
                            void* ws, size_t ws_bytes, int fir_impl, void* stream, void* aux_stream,
                            unsigned long long noise_seed, unsigned long long noise_offset);
 
-/* aux_stream (both calls above): NULL, or a second stream of the same device, which must be the calling thread's
- * current device (hipSetDevice) -- the fork / join events are created there.  The noise branch (its taps and its
+/* Launch layout (round 6).  With every filter at 256 bins and hop 512 -- the shipped configurations -- a call is issued on `stream`
+ * ALONE: CombSub as three launches (exciter + the three tap syntheses as jobs of one launch | all-pass filter + noise filter as two
+ * jobs of one launch | harmonic filter + noise), Sins as four; `aux_stream` is not used (independent kernels as jobs of ONE launch save
+ * a ramp and a drain each, where two streams paid three cross-stream hand-overs for an overlap that is worth less: 0.319 -> 0.302 ms
+ * at B = 32 x 10 s).  Tuning knob STREAM_LAYOUT = 1 / 4 restores the two-stream layouts at batch shapes.  Other bin counts / hops:
+ *
+ * aux_stream (both calls above): NULL, or a second stream of the same device, which must be the calling thread's
+ * current device (hipSetDevice) -- the fork / join events are taken from a per-device pool there.  The noise branch (its taps and its
  * filter: independent of the harmonic chain until the final sum) is then enqueued there -- forked after everything
  * already on `stream`, joined back before the last kernel on `stream`, so for the caller the call still behaves as
- * one operation on `stream` -- and fills the machine where the chain's kernels leave it idle (tails, store phases):
- * 3-6 % per step at B = 32 x 10 s.  Results are bit-identical to the one-stream order.  The two events this needs are
- * created once per host thread and device and kept (the only objects the library creates). */
+ * one operation on `stream` -- and fills the machine where the chain's kernels leave it idle (tails, store phases).
+ * Results are bit-identical to the one-stream order.  The events this needs come from a process-wide pool per device, checked
+ * out per call (the only objects the library creates, beside the second lane's streams of knob LANE_ROWS). */
 
 /* workspace the two synth entry points need (bytes); n_max = largest n_mag among the filters.  `ws` must be 16-byte
  * aligned (the tap arrays carved out of it are written 16 bytes at a time); an unaligned pointer is DDSP_HIP_EINVAL.
- * Streaming shapes (B F < 4096 frames, gui.py:118-133): the workspace holds one tap buffer more, and the tails issue the
- * same kernels as three (CombSub) / four (Sins) dependent launches instead of seven / five -- same results, bit for bit. */
+ * 256-bin models at hop 512 (and every model below 4096 frames): the workspace holds one tap buffer more (the fused layout
+ * above: all tap syntheses of a step are one launch). */
 size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
 
 /* Where a ddsp_hip_combsub_synth (combsub != 0; n0, n1, n2 = n_ap, n_harm, n_nz) / ddsp_hip_sins_synth (n0 = H, n1 = n_ap,
