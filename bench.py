@@ -784,11 +784,11 @@ def cpu_baseline_reference(kind, F, n, device, budget_s=25.0):
 
 
 def _cpu_mel_worker(args):
-    seed, T = args
+    seed, T, ks = args
     import numpy as _np
     from oracle import ddsp_oracle as O
     y = O.synth_gauss(1, T, seed=seed) * _np.float32(0.1)
-    return float(O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)).max())
+    return float(O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000), keyshift=ks).max())
 
 
 def step_traffic(model):
@@ -1211,7 +1211,8 @@ def bench_rssloss(a, rank, world, device):
 
 
 def bench_mel(a, rank, world, device):
-    """waveform -> log-mel front-end of the cascade (SURVEY.md 8-f #2): one k_mel launch over B x 10 s of audio"""
+    """waveform -> log-mel front-end of the cascade: one k_mel launch over B x 10 s of audio; with
+    --keyshift k (main_diff.py:359's formant shift): one k_mel_czt launch, a transform of round(2048 2^(k/12)) points"""
     import multiprocessing as mp
     import torch.distributed as dist
     from ddsp_svc_amd import mel as M
@@ -1226,13 +1227,14 @@ def bench_mel(a, rank, world, device):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    prewarm(lambda: stft.get_mel(y), a.prewarm_seconds)
+    ks = a.keyshift
+    prewarm(lambda: stft.get_mel(y, keyshift=ks), a.prewarm_seconds)
     for _ in range(a.warmup):
-        out = stft.get_mel(y)
+        out = stft.get_mel(y, keyshift=ks)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = stft.get_mel(y)
+        out = stft.get_mel(y, keyshift=ks)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -1243,7 +1245,7 @@ def bench_mel(a, rank, world, device):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        stft.get_mel(y)
+        stft.get_mel(y, keyshift=ks)
     e1.record()
     torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / 20
@@ -1251,24 +1253,26 @@ def bench_mel(a, rank, world, device):
         return
     alg = (4.0 + 4.0 * 128 / HOP) * B * T                       # waveform in, [B,F,128] log-mel out
     ms = elapsed / a.steps * 1e3
-    res = {"metric": "audio samples/sec, log-mel front-end 44.1kHz n_fft2048 hop512 128 mels",
+    n_new = M._shifted_sizes(2048, 2048, 512, ks, 1)[0]
+    res = {"metric": "audio samples/sec, log-mel front-end 44.1kHz n_fft2048 hop512 128 mels" +
+                     ("" if ks == 0 else ", keyshift %g (a %d-point transform)" % (ks, n_new)),
            "value": B * world * T * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "prewarm_s": a.prewarm_seconds, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "STFT.get_mel of B=%d/GPU x %.0f s waveforms (T=%d) -> [B,128,%d] log-mel"
                                   % (B, a.seconds, T, F), "batch_per_gpu": B, "samples_per_utterance": T,
                       "parallelism": "utterance-shard x%d" % world},
-           "roofline": {"kernel": "k_mel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+           "roofline": {"kernel": "k_mel" if ks == 0 else "k_mel_czt", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "avg_ms": k_ms, "launches_per_step": 1}}
     if world == 1 and not a.no_cpu_baseline:
         cores = max(1, min(os.cpu_count() or 1, 64))
         with mp.get_context("fork").Pool(cores, initializer=_cpu_worker_init) as pool:
-            pool.map(_cpu_mel_worker, [(i, 4096) for i in range(cores)])
+            pool.map(_cpu_mel_worker, [(i, 4096, ks) for i in range(cores)])
             t1 = time.perf_counter()
             rounds = 0
             while time.perf_counter() - t1 < 8.0 and rounds < 64:
-                pool.map(_cpu_mel_worker, [(rounds * cores + i, T) for i in range(cores)])
+                pool.map(_cpu_mel_worker, [(rounds * cores + i, T, ks) for i in range(cores)])
                 rounds += 1
             wall = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": rounds * cores * T / wall, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -1543,6 +1547,8 @@ def main(argv=None):
                                                          "cascade_seam", "cascade_ref"])
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--keyshift", type=float, default=0.0,
+                    help="--model mel: get_mel's key shift in semitones (the cascade's formant shift, main_diff.py:359)")
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--fir-impl", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

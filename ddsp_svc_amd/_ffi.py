@@ -85,6 +85,11 @@ SIGNATURES = {
     "ddsp_hip_mel_frames": (c_int, [c_int, c_int, c_int]),
     "ddsp_hip_mel_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_float, P,
                                          c_long, c_long, c_long, P]),
+    "ddsp_hip_mel_shifted_table_bytes": (c_size_t, [c_int, c_int]),
+    "ddsp_hip_mel_shifted_tables": (c_int, [c_int, c_int, c_int, P, P]),
+    "ddsp_hip_mel_shifted_frames": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "ddsp_hip_mel_shifted_spectrogram": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_int,
+                                                 c_float, P, c_long, c_long, c_long, P]),
 }
 
 MODE_ROLL, MODE_HANN, MODE_DYNAMIC = 0, 1, 2

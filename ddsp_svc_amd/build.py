@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libddsp_hip.so")
-SOURCES = ["phase.hip", "exciter.hip", "ir.hip", "ir_pfa.hip", "ir_czt.hip", "fir.hip", "fir_fft.hip", "fir_blk.hip", "fir_blk_bwd.hip", "fir_bwd_direct.hip", "fir_fft_bwd.hip", "stft.hip", "mel.hip", "sinegen.hip", "loss.hip", "loss_czt.hip", "api.hip"]
+SOURCES = ["phase.hip", "exciter.hip", "ir.hip", "ir_pfa.hip", "ir_czt.hip", "fir.hip", "fir_fft.hip", "fir_blk.hip", "fir_blk_bwd.hip", "fir_bwd_direct.hip", "fir_fft_bwd.hip", "stft.hip", "mel.hip", "mel_czt.hip", "sinegen.hip", "loss.hip", "loss_czt.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 

@@ -1095,6 +1095,35 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
   return finish();
 }
 
+size_t ddsp_hip_mel_shifted_table_bytes(int n_fft_new, int n_bins) { return mel_czt_table_bytes(n_fft_new, n_bins); }
+
+int ddsp_hip_mel_shifted_tables(int n_fft_new, int win_new, int n_bins, float* tables, void* stream) {
+  if (n_fft_new < 2 || win_new < 1 || win_new > n_fft_new || n_bins < 2) return DDSP_HIP_EINVAL;
+  if (!mel_czt_table_bytes(n_fft_new, n_bins)) return DDSP_HIP_ESHAPE;
+  if (!tables) return DDSP_HIP_EINVAL;
+  if (launch_mel_czt_tables(n_fft_new, win_new, n_bins, tables, S(stream)) != 0) return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
+int ddsp_hip_mel_shifted_frames(int T, int n_fft_new, int win_new, int hop_new, int center) {
+  const int f = mel_czt_frames(T, n_fft_new, win_new, hop_new, center);
+  return f < 1 ? DDSP_HIP_EINVAL : f;
+}
+
+int ddsp_hip_mel_shifted_spectrogram(const float* audio, int B, int T, const float* tables, int n_fft_new, int win_new,
+                                     int hop_new, int center, int n_bins, float mag_scale, const int* band,
+                                     const float* band_weights, int n_mels, float clip_val, float* out, long stride_b,
+                                     long stride_mel, long stride_frame, void* stream) {
+  if (B < 0 || n_mels < 1 || n_bins < 2 || mel_czt_frames(T, n_fft_new, win_new, hop_new, center) < 1) return DDSP_HIP_EINVAL;
+  if (!mel_czt_table_bytes(n_fft_new, n_bins)) return DDSP_HIP_ESHAPE;
+  if (B == 0) return 0;
+  if (!audio || !tables || !band || !band_weights || !out) return DDSP_HIP_EINVAL;
+  if (launch_mel_czt(audio, B, T, tables, n_fft_new, win_new, hop_new, center, n_bins, mag_scale, band, band_weights, n_mels,
+                     clip_val, out, stride_b, stride_mel, stride_frame, S(stream)) != 0)
+    return DDSP_HIP_ESHAPE;
+  return finish();
+}
+
 int ddsp_hip_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
                          const float* weight, const float* bias, int dim, float sine_amp, float noise_std,
                          float voiced_threshold, float* rad_acc, float* out, void* stream) {

@@ -129,6 +129,14 @@ int launch_mel(const float* audio, int B, int T, const float* window, int n_fft,
                const int* band, const float* packed, int packed_len, int n_mels, float clip, float* out, long sb,
                long sm, long sf, hipStream_t st);
 int mel_frames(int T, int n_fft, int hop);
+// the same front-end at any transform length / hop / centring (mel_czt.hip; nvSTFT.py:83-85,109-114)
+int mel_czt_plan(int n_new, int n_bins);
+size_t mel_czt_table_bytes(int n_new, int n_bins);
+int mel_czt_frames(int T, int n_new, int win_new, int hop_new, int center);
+int launch_mel_czt_tables(int n_new, int win_new, int n_bins, float* tab, hipStream_t st);
+int launch_mel_czt(const float* audio, int B, int T, const float* tab, int n_new, int win_new, int hop_new, int center,
+                   int n_bins, float mag_scale, const int* band, const float* packed, int n_mels, float clip, float* out,
+                   long sb, long sm, long sf, hipStream_t st);
 // gen != null && on: the standard-normal noise is drawn inside the kernel from (seed, offset) (noise may be null)
 int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const float* rand_ini, const float* noise,
                        const float* weight, const float* bias, int dim, float sine_amp, float noise_std,

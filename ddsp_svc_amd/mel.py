@@ -2,12 +2,12 @@
 (nsf_hifigan/nvSTFT.py:60-122), the extractor behind ``Vocoder.extract`` (diffusion/vocoder.py:98-111,146-148)
 that turns the DDSP waveform into the conditioning mel of the diffusion / reflow stage.
 
-Same constructor and ``get_mel`` signature.  ``get_mel`` runs on the HIP kernel (csrc/mel.hip) for the
-configuration the cascades use (``keyshift == 0``, ``speed == 1``, ``center == False``, ``n_fft == win_size == 2048``,
-``hop_length == 512``).  The augmentation variants (key shift: a transform of ``round(n_fft 2^(k/12))`` points, any length
-from 1024 to 4096; speed change; ``center``) are off the inference path (training-time augmentation, the enhancer's adaptive
-key): the stand-alone class raises ``NotImplementedError`` for them, and ``patch_reference_stft()`` leaves them on the
-reference's own code (this package holds no torch-operator restatement of the reference).  The mel basis is what the
+Same constructor and ``get_mel`` signature.  ``get_mel`` runs on HIP kernels only: csrc/mel.hip for the configuration the
+cascades use (``keyshift == 0``, ``speed == 1``, ``center == False``, ``n_fft == win_size == 2048``, ``hop_length == 512``:
+a 2048-point FFT, two frames per complex transform), csrc/mel_czt.hip for everything else -- the formant shift of the
+cascade's inference (``main_diff.py:359``: ``keyshift = formant_shift_key``) and the pitch augmentation of
+``preprocess.py:88-92`` (a transform of ``round(n_fft 2^(k/12))`` points: ANY integer length, a chirp-z transform), a speed
+change, ``center=True``, other (n_fft, win, hop) configurations.  There is no torch-operator path.  The mel basis is what the
 reference builds with ``librosa.filters.mel`` (nvSTFT.py:90): pass it as ``mel_basis`` (any dense
 ``[n_mels, n_fft/2+1]`` tensor), or let the class build the Slaney filterbank itself (librosa's published
 algorithm, ``htk=False``, ``norm='slaney'``).
@@ -84,6 +84,47 @@ def mel_spectrogram(audio, window, mel_basis, band, hop_length, clip_val=1e-5):
     return store.transpose(1, 2)
 
 
+def _shifted_sizes(n_fft, win_size, hop_length, keyshift, speed):
+    """nvSTFT.py:82-85 (numpy's rounding, as the reference)."""
+    import numpy as np
+    factor = 2 ** (keyshift / 12)
+    return int(np.round(n_fft * factor)), int(np.round(win_size * factor)), int(np.round(hop_length * speed))
+
+
+def mel_spectrogram_shifted(audio, tables, band, n_fft_new, win_new, hop_new, center, n_bins, mag_scale, n_mels,
+                            clip_val=1e-5):
+    """``get_mel`` at any transform length / hop / centring (nvSTFT.py:83-116) -> ``[B, n_mels, frames]``, frame-major in
+    memory like ``mel_spectrogram``.  ``tables``: ``shifted_tables(...)``."""
+    band, packed = band
+    _ffi.check_device(audio, tables, band, packed)
+    if audio.dim() != 2:
+        raise ValueError("audio must be [B, T]")
+    a = audio if (audio.dtype == torch.float32 and audio.is_contiguous()) else audio.float().contiguous()
+    B, T = a.shape
+    frames = _ffi.lib().ddsp_hip_mel_shifted_frames(T, n_fft_new, win_new, hop_new, int(bool(center))) if T > 0 else -1
+    if frames < 1:
+        raise RuntimeError("get_mel: no frame (transform %d, window %d, hop %d, center %s against %d samples): torch.stft "
+                           "raises here too" % (n_fft_new, win_new, hop_new, bool(center), T))
+    store = torch.empty(B, frames, n_mels, dtype=torch.float32, device=a.device)
+    _ffi.check(_ffi.lib().ddsp_hip_mel_shifted_spectrogram(ptr(a), B, T, ptr(tables), n_fft_new, win_new, hop_new,
+                                                          int(bool(center)), n_bins, float(mag_scale), ptr(band), ptr(packed),
+                                                          n_mels, float(clip_val), ptr(store), frames * n_mels, 1, n_mels,
+                                                          _ffi.stream_of(a)))
+    return store.transpose(1, 2)
+
+
+def shifted_tables(n_fft_new, win_new, n_bins, device):
+    """The chirp tables of one (transform length, window length, basis width) on ``device`` (float32 pairs)."""
+    nbytes = _ffi.lib().ddsp_hip_mel_shifted_table_bytes(n_fft_new, n_bins)
+    if nbytes == 0 or win_new > n_fft_new or win_new < 1:
+        raise RuntimeError("get_mel: transform length %d / window %d with a basis of %d bins is outside the kernel's range "
+                           "(n_fft <= 2048, shifted transform <= 8192 points, window <= transform)"
+                           % (n_fft_new, win_new, n_bins))
+    tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    _ffi.check(_ffi.lib().ddsp_hip_mel_shifted_tables(n_fft_new, win_new, n_bins, ptr(tab), _ffi.stream_of(tab)))
+    return tab
+
+
 class STFT:
     """nsf_hifigan/nvSTFT.py:60-122 on the MI355X."""
 
@@ -100,6 +141,7 @@ class STFT:
         self.mel_basis = {}
         self.hann_window = {}
         self._band = {}
+        self._shifted = {}
         self._given_basis = mel_basis
 
     def _tables(self, device):
@@ -116,23 +158,36 @@ class STFT:
         return self.mel_basis[key], self._band[key], self.hann_window[wkey]
 
     def get_mel(self, y, keyshift=0, speed=1, center=False):
-        if keyshift != 0 or speed != 1 or center or self.n_fft != self.win_size:
-            # training-time augmentation / the enhancer's adaptive key (nvSTFT.py:83-85,109-114): a transform of
-            # round(n_fft 2^(k/12)) points, a scaled hop, `center`.  No kernel of this package takes them and the package
-            # carries no second, torch-operator implementation of the reference: a patched reference class
-            # (patch_reference_stft) keeps such calls on the reference's own code.
-            raise NotImplementedError("ddsp_svc_amd.mel.STFT.get_mel: keyshift / speed / center / n_fft != win_size are not "
-                                      "taken by the HIP kernel; use nsf_hifigan.nvSTFT.STFT (patch_reference_stft() routes only "
-                                      "the cascade's inference configuration to the kernel and leaves these to the reference)")
         basis, band, window = self._tables(y.device)
-        return mel_spectrogram(y, window, basis, band, self.hop_length, self.clip_val)
+        if (keyshift == 0 and speed == 1 and not center and self.n_fft == self.win_size == 2048 and self.hop_length == 512):
+            return mel_spectrogram(y, window, basis, band, self.hop_length, self.clip_val)
+        return _get_mel_shifted(self, y, keyshift, speed, center, band, self._shifted)
+
+
+def _get_mel_shifted(self, y, keyshift, speed, center, band, cache):
+    """nvSTFT.py:82-116 on csrc/mel_czt.hip; ``cache``: chirp tables per (transform, window) length and device (the
+    reference caches its windows per keyshift the same way, :92-94)."""
+    n_new, win_new, hop_new = _shifted_sizes(self.n_fft, self.win_size, self.hop_length, keyshift, speed)
+    n_bins = self.n_fft // 2 + 1
+    key = (n_new, win_new, str(y.device))
+    if key not in cache:
+        cache[key] = shifted_tables(n_new, win_new, n_bins, y.device)
+    scale = self.win_size / win_new if keyshift != 0 else 1.0                       # nvSTFT.py:109-114
+    return mel_spectrogram_shifted(y, cache[key], band, n_new, win_new, hop_new, center, n_bins, scale, self.n_mels,
+                                   self.clip_val)
+
+
+def _shifted_in_range(n_fft, win_size, hop_length, keyshift, speed):
+    n_new, win_new, hop_new = _shifted_sizes(n_fft, win_size, hop_length, keyshift, speed)
+    return (1 <= win_new <= n_new and 1 <= hop_new <= win_new and
+            _ffi.lib().ddsp_hip_mel_shifted_table_bytes(n_new, n_fft // 2 + 1) > 0)
 
 
 def patch_reference_stft():
-    """Route ``nsf_hifigan.nvSTFT.STFT.get_mel`` of an importable reference checkout through the HIP kernel when
-    the call is the cascade's inference configuration on a GPU tensor (keyshift 0, speed 1, center False,
-    n_fft == win == 2048, hop 512); every other call -- CPU tensors, augmentation, other sizes -- keeps the
-    reference code.  The reference's own mel basis (librosa) and Hann window caches are used as they are."""
+    """Route ``nsf_hifigan.nvSTFT.STFT.get_mel`` of an importable reference checkout through the HIP kernels for every
+    call on a ``[B, T]`` GPU tensor the kernels take (the cascade's configuration on csrc/mel.hip; keyshift / speed /
+    center / other sizes on csrc/mel_czt.hip); CPU tensors and sizes outside the kernels' range keep the reference
+    code.  The reference's own mel basis (librosa) is used as it is."""
     import nsf_hifigan.nvSTFT as nv
     if hasattr(nv.STFT, "_reference_get_mel"):
         return nv
@@ -140,8 +195,10 @@ def patch_reference_stft():
     nv.STFT._reference_get_mel = ref_get_mel
 
     def get_mel(self, y, keyshift=0, speed=1, center=False):
-        hip_ok = (getattr(y, "is_cuda", False) and keyshift == 0 and speed == 1 and not center and
-                  self.n_fft == 2048 and self.win_size == 2048 and self.hop_length == 512 and y.dim() == 2)
+        plain = (keyshift == 0 and speed == 1 and not center and self.n_fft == 2048 and self.win_size == 2048 and
+                 self.hop_length == 512)
+        hip_ok = (getattr(y, "is_cuda", False) and y.dim() == 2 and
+                  (plain or _shifted_in_range(self.n_fft, self.win_size, self.hop_length, keyshift, speed)))
         if not hip_ok:
             return ref_get_mel(self, y, keyshift=keyshift, speed=speed, center=center)
         key = str(self.fmax) + "_" + str(y.device)
@@ -155,6 +212,8 @@ def patch_reference_stft():
         bands = self.__dict__.setdefault("_hip_bands", {})
         if key not in bands:
             bands[key] = _bands(self.mel_basis[key])
+        if not plain:
+            return _get_mel_shifted(self, y, keyshift, speed, center, bands[key], self.__dict__.setdefault("_hip_shifted", {}))
         return mel_spectrogram(y, self.hann_window[wkey], self.mel_basis[key].contiguous(), bands[key],
                                self.hop_length, self.clip_val)
 

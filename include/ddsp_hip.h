@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 162          /* 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
+#define DDSP_HIP_VERSION 163          /* 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -312,6 +312,29 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
                              const float* mel_basis, const int* band, const float* band_weights,
                              int n_band_weights, int n_mels, float clip_val,
                              float* out, long stride_b, long stride_mel, long stride_frame, void* stream);
+
+/* STFT.get_mel(y, keyshift, speed, center) in full (nvSTFT.py:73-117; the cascade's formant shift, main_diff.py:359; the
+ * pitch augmentation of preprocess.py:88-92), and any (n_fft, win, hop) configuration:
+ *   n_fft_new = round(n_fft 2^(keyshift/12)), win_new = round(win 2^(keyshift/12)), hop_new = round(hop speed) (:83-85);
+ *   manual padding from (win_new, hop_new) (:97-103); center != 0: torch.stft's reflect padding of n_fft_new/2 on top;
+ *   frames of n_fft_new every hop_new, periodic Hann of win_new centred in them; the first min(n_bins, n_fft_new/2 + 1)
+ *   bins of the n_fft_new-point DFT -- ANY integer length, a chirp-z transform -- sqrt(re^2+im^2+1e-9) (:108), the bins
+ *   above them zero, all times mag_scale (the caller passes win / win_new when keyshift != 0, else 1, :109-114);
+ *   mel basis [n_mels, n_bins] as band / band_weights (see above; always read from band_weights); log(clamp(., clip_val)).
+ * tables: ddsp_hip_mel_shifted_table_bytes(n_fft_new, n_bins) bytes filled once per (n_fft_new, win_new, n_bins) by
+ * ddsp_hip_mel_shifted_tables (the caller caches them per keyshift, as the reference caches its windows, :92-94).
+ * Supported: n_bins <= 1025 (n_fft <= 2048); n_fft_new <= 8192 (<= 4096 when min(n_bins, n_fft_new/2 + 1) <= 513: the
+ * 2048-point convolution plan); win_new <= n_fft_new, hop_new <= win_new; B <= 65535: _table_bytes returns 0 outside.
+ * One convolution of 4096 (2048) points per frame up to n_fft_new = 4096 (2048), two beyond.  _frames: the frame count, or
+ * DDSP_HIP_EINVAL where torch.stft / F.pad raise (transform longer than the padded signal, center's reflection not
+ * shorter than it). */
+size_t ddsp_hip_mel_shifted_table_bytes(int n_fft_new, int n_bins);
+int ddsp_hip_mel_shifted_tables(int n_fft_new, int win_new, int n_bins, float* tables, void* stream);
+int ddsp_hip_mel_shifted_frames(int T, int n_fft_new, int win_new, int hop_new, int center);
+int ddsp_hip_mel_shifted_spectrogram(const float* audio, int B, int T, const float* tables, int n_fft_new, int win_new,
+                                     int hop_new, int center, int n_bins, float mag_scale, const int* band,
+                                     const float* band_weights, int n_mels, float clip_val,
+                                     float* out, long stride_b, long stride_mel, long stride_frame, void* stream);
 
 /* ---- harmonic source of NSF-HiFiGAN (nsf_hifigan/models.py:101-204) ---- */
 

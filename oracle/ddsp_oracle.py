@@ -563,25 +563,47 @@ def mel_filterbank_slaney(sr: float, n_fft: int, n_mels: int, fmin: float, fmax:
 
 
 def get_mel(y: np.ndarray, mel_basis: np.ndarray, n_fft: int = 2048, win_size: int = 2048, hop: int = 512,
-            clip_val: float = 1e-5, window=None) -> np.ndarray:
-    """``STFT.get_mel(y, keyshift=0, speed=1, center=False)`` (nvSTFT.py:73-117): manual padding of
-    ``(win-hop)//2`` left and ``max((win-hop+1)//2, win-len-pad_left)`` right (reflect when the right pad is shorter
-    than the signal, else zeros, :97-103), ``torch.stft(center=False)`` with the periodic Hann window (:106),
-    ``sqrt(re^2 + im^2 + 1e-9)`` (:108), mel matmul (:115), ``log(clamp(., clip_val))`` (:116) -> ``[B, n_mels, frames]``.
-    float64 arithmetic."""
+            clip_val: float = 1e-5, window=None, keyshift: float = 0, speed: float = 1, center: bool = False) -> np.ndarray:
+    """``STFT.get_mel(y, keyshift, speed, center)`` (nvSTFT.py:73-117): transform / window stretched to
+    ``round(n 2^(keyshift/12))`` points and the hop to ``round(hop speed)`` (:82-85); manual padding of ``(win'-hop')//2``
+    left and ``max((win'-hop'+1)//2, win'-len-pad_left)`` right (reflect when the right pad is shorter than the signal, else
+    zeros, :97-103); ``torch.stft`` with the periodic Hann window of ``win'`` points centred in the transform (:106;
+    ``center=True`` adds its own reflect padding of ``n'//2``); ``sqrt(re^2 + im^2 + 1e-9)`` (:108); when ``keyshift != 0``
+    the spectrum is cut / zero-filled to ``n_fft//2 + 1`` bins and scaled by ``win / win'`` (:109-114); mel matmul (:115),
+    ``log(clamp(., clip_val))`` (:116) -> ``[B, n_mels, frames]``.  float64 arithmetic.  ``window``: the float32 Hann
+    window of ``win'`` points (default: built here)."""
     y = np.asarray(y, dtype=F64)
     B, T = y.shape
+    factor = 2 ** (keyshift / 12)
+    n_new = int(np.round(n_fft * factor))
+    win_new = int(np.round(win_size * factor))
+    hop_new = int(np.round(hop * speed))
     if window is None:
-        window = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_size) / win_size)).astype(F32)
+        window = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_new) / win_new)).astype(F32)
     w = np.asarray(window, dtype=F32).astype(F64)
-    pad_left = (win_size - hop) // 2
-    pad_right = max((win_size - hop + 1) // 2, win_size - T - pad_left)
+    if w.shape[0] != win_new or win_new > n_new:
+        raise ValueError("window length")
+    left = (n_new - win_new) // 2                                               # torch.stft centres a short window
+    w = np.pad(w, (left, n_new - win_new - left))
+    pad_left = (win_new - hop_new) // 2
+    pad_right = max((win_new - hop_new + 1) // 2, win_new - T - pad_left)
     mode = "reflect" if pad_right < T else "constant"
     yp = np.pad(y, ((0, 0), (pad_left, pad_right)), mode=mode)
-    nfr = (yp.shape[1] - n_fft) // hop + 1
-    idx = (np.arange(nfr) * hop)[:, None] + np.arange(n_fft)[None, :]
-    spec = np.fft.rfft(yp[:, idx] * w, n_fft)                                  # [B, frames, bins]
+    if center:
+        if n_new // 2 >= yp.shape[1]:
+            raise ValueError("reflection longer than the signal")
+        yp = np.pad(yp, ((0, 0), (n_new // 2, n_new // 2)), mode="reflect")
+    if yp.shape[1] < n_new:
+        raise ValueError("transform longer than the padded signal")
+    nfr = (yp.shape[1] - n_new) // hop_new + 1
+    idx = (np.arange(nfr) * hop_new)[:, None] + np.arange(n_new)[None, :]
+    spec = np.fft.fft(yp[:, idx] * w, axis=-1)[..., :n_new // 2 + 1]            # [B, frames, bins]; any length, odd ones too
     mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
+    if keyshift != 0:
+        size = n_fft // 2 + 1
+        if mag.shape[-1] < size:
+            mag = np.pad(mag, ((0, 0), (0, 0), (0, size - mag.shape[-1])))
+        mag = mag[..., :size] * win_size / win_new
     mel = np.einsum("mk,bfk->bmf", np.asarray(mel_basis, dtype=F32).astype(F64), mag)
     return np.log(np.maximum(mel, clip_val))
 

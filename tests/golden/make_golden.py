@@ -14,6 +14,8 @@ Fixtures (all float32 unless noted):
   csfast_*.npz      CombSubFast.forward, captured controls, injected uniform noise      vocoder.py:735-786
   cssuper_*.npz     CombSubSuperFast.forward, captured controls, injected normal noise  vocoder.py:653-710
   mel_*.npz         nsf_hifigan.nvSTFT.STFT.get_mel with the oracle's Slaney filterbank injected  nvSTFT.py:73-117
+  mel_shifted*.npz  the same with keyshift / speed / center, the 22.05 kHz default configuration, a window shorter than the
+                    transform (--mel-shifted regenerates these alone)                          nvSTFT.py:82-116
   sinesrc.npz       nsf_hifigan.models.SourceModuleHnNSF.forward with its two random draws injected  models.py:140-204
   sssloss.npz       ddsp.loss.SSSLoss / RSSLoss forward + autograd w.r.t. x_pred, with a torch.stft stand-in for the absent
                     torchaudio.transforms.Spectrogram (documented semantics restated)                  loss.py:9-54
@@ -248,10 +250,64 @@ def baseline_shape_fixtures():
             print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+MEL_SHIFTED_CASES = {                    # tag: (keyshift, speed, center, which audio)
+    "ks3p7": (3.7, 1, False, "audio"),          # 2536 points: two chunks of the chirp-z kernel
+    "ksm5": (-5, 1, False, "audio"),            # 1534 points: 768 bins, the rest zero-filled (nvSTFT.py:111-113)
+    "ks2": (2, 1, False, "audio"),              # 2299 points: an odd length
+    "ks12": (12, 1, False, "audio"),            # 4096 points
+    "ksm12": (-12, 1, False, "audio"),          # 1024 points
+    "sp1p25": (0, 1.25, False, "audio"),        # hop 640
+    "center": (0, 1, True, "audio"),
+    "mix": (-3.3, 0.8, True, "audio"),          # 1693 points, hop 410, centred
+    "short": (4, 1, False, "audio_short"),      # signal shorter than the padding: zeros instead of the reflection (:99-102)
+    "short_center": (-2, 1.5, True, "audio_short"),
+}
+
+
+def mel_shifted_fixtures():
+    """mel_shifted*.npz: nsf_hifigan.nvSTFT.STFT.get_mel with keyshift / speed / center (nvSTFT.py:82-116), the oracle's
+    Slaney filterbank injected for the absent librosa; the 44.1 kHz configuration, the class's default 22.05 kHz one
+    (n_fft 1024, hop 256, 80 bands) and a window shorter than the transform."""
+    from oracle import ddsp_oracle as O
+    import_reference()
+    import nsf_hifigan.nvSTFT as nv
+
+    def audio(Tn, seed):
+        g = torch.Generator().manual_seed(seed)
+        t = torch.arange(Tn) / 44100.0
+        y = sum(0.3 / k * torch.sin(2 * np.pi * 220.0 * k * t + k) for k in range(1, 40))
+        return torch.stack([y + 0.05 * torch.randn(Tn, generator=g), 0.2 * torch.randn(Tn, generator=g)])
+
+    ys = {"audio": audio(20 * 512, 77), "audio_short": audio(700, 78)}
+    basis = O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)
+    out = {k: v.numpy() for k, v in ys.items()}
+    with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis):
+        stft = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000)
+        for tag, (ks, sp, ce, which) in MEL_SHIFTED_CASES.items():
+            out["mel_" + tag] = stft.get_mel(ys[which], keyshift=ks, speed=sp, center=ce).numpy()
+        short_win = nv.STFT(44100, 128, 2048, 1024, 512, 40, 16000)               # window centred in the transform
+        out["mel_win1024"] = short_win.get_mel(ys["audio"]).numpy()
+        out["mel_win1024_ks5"] = short_win.get_mel(ys["audio"], keyshift=5).numpy()
+    np.savez_compressed(os.path.join(HERE, "mel_shifted.npz"), **out)
+    basis22 = O.mel_filterbank_slaney(22050, 1024, 80, 20, 11025)
+    out = {"audio": ys["audio"].numpy()[:, :12 * 256], "basis": basis22}
+    y22 = ys["audio"][:, :12 * 256]
+    with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis22):
+        stft = nv.STFT()                                                           # 22050, 80, 1024, 1024, 256, 20, 11025
+        out["mel_plain"] = stft.get_mel(y22).numpy()
+        out["mel_ks5"] = stft.get_mel(y22, keyshift=5).numpy()                     # 1367 points
+        out["mel_ksm4_center"] = stft.get_mel(y22, keyshift=-4, center=True).numpy()
+    np.savez_compressed(os.path.join(HERE, "mel_shifted_22k.npz"), **out)
+    for f in ("mel_shifted.npz", "mel_shifted_22k.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
 def main():
     from oracle import ddsp_oracle as O
     if "--only-loss" in sys.argv:
         return loss_fixture()
+    if "--mel-shifted" in sys.argv:
+        return mel_shifted_fixtures()
     if "--baseline-shapes" in sys.argv:
         return baseline_shape_fixtures()
     core, V = import_reference()
@@ -533,6 +589,7 @@ def main():
 
     loss_fixture()
     baseline_shape_fixtures()
+    mel_shifted_fixtures()
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ddsp_svc_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libddsp_hip_emu.so")
-SOURCES = ["phase.hip", "exciter.hip", "ir.hip", "ir_pfa.hip", "ir_czt.hip", "fir.hip", "fir_fft.hip", "fir_blk.hip", "fir_blk_bwd.hip", "fir_bwd_direct.hip", "fir_fft_bwd.hip", "stft.hip", "mel.hip", "sinegen.hip", "loss.hip", "loss_czt.hip", "api.hip"]
+SOURCES = ["phase.hip", "exciter.hip", "ir.hip", "ir_pfa.hip", "ir_czt.hip", "fir.hip", "fir_fft.hip", "fir_blk.hip", "fir_blk_bwd.hip", "fir_bwd_direct.hip", "fir_fft_bwd.hip", "stft.hip", "mel.hip", "mel_czt.hip", "sinegen.hip", "loss.hip", "loss_czt.hip", "api.hip"]
 
 
 def _clang():

@@ -4,7 +4,9 @@
 Tolerances: the oracle (float64) sits <= 5e-6 (log domain) from the reference's float32 pipeline.  The HIP path is
 held to <= 2e-6 of the frame's largest mel value in the linear domain, and to <= 2e-4 in the log domain on every band
 above 1e-4 of that maximum (bands further down sit on the float32 FFT's noise floor, where the reference's own
-pocketfft and any other float32 transform legitimately differ)."""
+pocketfft and any other float32 transform legitimately differ).  The same bars hold for the chirp-z kernel of the
+keyshift / speed / center variants (csrc/mel_czt.hip), whose oracle form is pinned <= 1e-5 to the reference's
+outputs for ten (keyshift, speed, center) combinations, a short window and the 22.05 kHz configuration."""
 import os
 import sys
 from unittest import mock
@@ -39,6 +41,36 @@ def test_oracle_against_reference_get_mel(golden_dir, tag):
     m = O.get_mel(g["audio"], _basis(golden_dir))
     assert m.shape == g["mel"].shape
     assert np.abs(m - g["mel"]).max() <= 1e-5
+
+
+def _shifted_cases():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import MEL_SHIFTED_CASES
+    return MEL_SHIFTED_CASES
+
+
+SHIFTED = sorted(_shifted_cases())
+
+
+@pytest.mark.parametrize("tag", SHIFTED)
+def test_oracle_against_reference_get_mel_shifted(golden_dir, tag):
+    """keyshift / speed / center (nvSTFT.py:82-116) against the reference's own outputs"""
+    ks, sp, ce, which = _shifted_cases()[tag]
+    g = np.load(os.path.join(golden_dir, "mel_shifted.npz"))
+    m = O.get_mel(g[which], _basis(golden_dir), keyshift=ks, speed=sp, center=ce)
+    assert m.shape == g["mel_" + tag].shape
+    assert np.abs(m - g["mel_" + tag]).max() <= 1e-5
+
+
+def test_oracle_against_reference_get_mel_other_configurations(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel_shifted.npz"))
+    for tag, kw in (("win1024", {}), ("win1024_ks5", {"keyshift": 5})):           # window centred in a longer transform
+        m = O.get_mel(g["audio"], _basis(golden_dir), win_size=1024, **kw)
+        assert m.shape == g["mel_" + tag].shape and np.abs(m - g["mel_" + tag]).max() <= 1e-5
+    g = np.load(os.path.join(golden_dir, "mel_shifted_22k.npz"))                  # the class's default configuration
+    for tag, kw in (("plain", {}), ("ks5", {"keyshift": 5}), ("ksm4_center", {"keyshift": -4, "center": True})):
+        m = O.get_mel(g["audio"], g["basis"], 1024, 1024, 256, **kw)
+        assert m.shape == g["mel_" + tag].shape and np.abs(m - g["mel_" + tag]).max() <= 1e-5
 
 
 def test_filterbank_restatement_properties(golden_dir):
@@ -80,6 +112,59 @@ def test_get_mel_golden(dev, golden_dir, tag):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("tag", SHIFTED)
+def test_get_mel_shifted_golden(dev, golden_dir, tag):
+    """the chirp-z kernel against the reference's outputs: one and two chunks per frame, an odd transform length, zero-filled
+    bins, the scaled hop, torch.stft's centring, the zero-padding branch"""
+    from ddsp_svc_amd import mel as M
+    ks, sp, ce, which = _shifted_cases()[tag]
+    g = np.load(os.path.join(golden_dir, "mel_shifted.npz"))
+    stft = M.STFT(**CFG, mel_basis=torch.from_numpy(_basis(golden_dir)))
+    out = stft.get_mel(torch.from_numpy(g[which]).to(dev), keyshift=ks, speed=sp, center=ce)
+    assert tuple(out.shape) == g["mel_" + tag].shape
+    assert out.transpose(1, 2).is_contiguous()
+    _check(out.cpu().numpy(), g["mel_" + tag])
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_get_mel_other_configurations_golden(dev, golden_dir):
+    """a window shorter than the transform (centred, as torch.stft places it) and the class's default 22.05 kHz configuration
+    (n_fft 1024, hop 256, 80 bands: the 2048-point convolution plan), plain and shifted"""
+    from ddsp_svc_amd import mel as M
+    g = np.load(os.path.join(golden_dir, "mel_shifted.npz"))
+    stft = M.STFT(**dict(CFG, win_size=1024), mel_basis=torch.from_numpy(_basis(golden_dir)))
+    y = torch.from_numpy(g["audio"]).to(dev)
+    _check(stft.get_mel(y).cpu().numpy(), g["mel_win1024"])
+    _check(stft.get_mel(y, keyshift=5).cpu().numpy(), g["mel_win1024_ks5"])
+    g = np.load(os.path.join(golden_dir, "mel_shifted_22k.npz"))
+    stft = M.STFT(mel_basis=torch.from_numpy(g["basis"]))
+    y = torch.from_numpy(g["audio"]).to(dev)
+    _check(stft.get_mel(y).cpu().numpy(), g["mel_plain"])
+    _check(stft.get_mel(y, keyshift=5).cpu().numpy(), g["mel_ks5"])
+    _check(stft.get_mel(y, keyshift=-4, center=True).cpu().numpy(), g["mel_ksm4_center"])
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,T,kw", [
+    (3, 512 * 9 + 100, {"speed": 0.5}),                       # 2048 points through the chirp-z kernel: exactly one chunk
+    (1, 512 * 11 + 7, {"keyshift": 0.0141}),                  # 2050 points: the second chunk holds two samples
+    (2, 512 * 14, {"keyshift": 12.01}),                       # 4098 points: three chunks
+    (1, 512 * 30, {"keyshift": 24}),                          # 8192 points: four chunks, the kernel's limit
+    (2, 300, {"keyshift": -7, "center": True}),               # zeros instead of the reflection, then torch.stft's own
+    (1, 512 * 40 + 3, {"keyshift": -2.5, "speed": 2.0}),      # 1772 points, hop 1024: several frames per workgroup run
+])
+def test_get_mel_shifted_shapes(dev, B, T, kw):
+    from ddsp_svc_amd import mel as M
+    rng = np.random.default_rng(T)
+    t = np.arange(T) / 44100.0
+    y = (0.4 * np.sin(2 * np.pi * 330.0 * t)[None] + 0.1 * rng.standard_normal((B, T))).astype(np.float32)
+    out = M.STFT(**CFG).get_mel(torch.from_numpy(y).to(dev), **kw).cpu().numpy()
+    ref = O.get_mel(y, O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000), **kw)
+    assert out.shape == ref.shape
+    _check(out, ref)
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("B,T,run", [(1, 512 * 7, 1), (3, 512 * 9 + 100, 2), (1, 700, 4), (2, 300, 4), (1, 512 * 33, 3)])
 def test_get_mel_shapes(dev, B, T, run, knobs):
     """odd frame counts, lengths that are not a multiple of the hop, signals shorter than the padding (zero-padding
@@ -115,14 +200,25 @@ def test_get_mel_contract(dev):
     y = torch.zeros(1, 2048, device=dev)
     out = stft.get_mel(y)                                                            # silence: sqrt(1e-9) per bin
     assert torch.isfinite(out).all() and out.shape == (1, 128, 4)
-    # the augmentation variants (nvSTFT.py:83-85,109-114) change the transform length / hop: no kernel takes them, and the
-    # stand-alone class says so instead of walking the reference's operators (a patched reference class keeps them on its own code)
     y2 = torch.randn(1, 8192, generator=torch.Generator().manual_seed(1)).to(dev)
-    for kw in ({"keyshift": 2}, {"keyshift": -5}, {"speed": 2}, {"center": True}):
-        with pytest.raises(NotImplementedError):
+    assert stft.get_mel(y2, keyshift=2).shape == (1, 128, 16) and stft.get_mel(y2, speed=2).shape == (1, 128, 8)
+    assert stft.get_mel(y2, center=True).shape == (1, 128, 20)
+    assert len(stft._shifted) == 2                                                   # tables per (transform, window) length
+    # where the reference raises (torch.stft / F.pad) or the kernel's range ends, so does the drop-in
+    for kw in ({"keyshift": 24.1},                                                   # 8239 points: beyond four chunks
+               {"speed": 5},                                                         # hop 2560 > window
+               {"keyshift": 12, "center": True}):                                    # fine ...
+        if kw == {"keyshift": 12, "center": True}:
+            assert stft.get_mel(y2, **kw).shape[1] == 128
+            continue
+        with pytest.raises(RuntimeError):
             stft.get_mel(y2, **kw)
-    with pytest.raises(RuntimeError):                                                # unsupported transform length
-        M.STFT(44100, 80, 1024, 1024, 256, 40, 16000).get_mel(y)
+    with pytest.raises(RuntimeError):                                                # window longer than the transform
+        M.STFT(44100, 128, 1024, 2048, 512, 40, 16000).get_mel(y2)
+    with pytest.raises(RuntimeError):                                                # a basis of more than 1025 bins
+        M.STFT(44100, 128, 8192, 8192, 512, 40, 16000).get_mel(y2, keyshift=1)
+    with pytest.raises(ValueError):
+        stft.get_mel(y2[0], keyshift=1)                                              # [T]: the kernels take [B, T]
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
@@ -144,9 +240,13 @@ def test_against_reference_stft_class(dev):
     y = torch.randn(2, 512 * 12, generator=g) * 0.2
     with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis):
         ref = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y)
+        ref_shift = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y, keyshift=-1.5, speed=1.1, center=True)
     ours = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y.to(dev)).cpu()
     assert ours.shape == ref.shape
     _check(ours.numpy(), ref.numpy())
+    ours = M.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y.to(dev), keyshift=-1.5, speed=1.1, center=True).cpu()
+    assert ours.shape == ref_shift.shape
+    _check(ours.numpy(), ref_shift.numpy())
 
 
 def test_patch_reference_stft_keeps_cpu_calls_on_the_reference():
