@@ -271,3 +271,38 @@ def test_patch_reference_stft_keeps_cpu_calls_on_the_reference():
         finally:
             nv.STFT.get_mel = nv.STFT._reference_get_mel
             del nv.STFT._reference_get_mel
+
+
+@pytest.mark.gpu
+def test_patched_reference_stft_takes_shifted_calls_on_the_gpu():
+    """main_diff.py:359: ``vocoder.extract(seg_ddsp_output, sr, keyshift=formant_shift_key)`` -> ``STFT.get_mel(audio, keyshift)``
+    of the patched reference class: a GPU tensor goes through csrc/mel_czt.hip (the call leaves its chirp tables on the
+    instance) and agrees with the reference's own code on the same audio; a transform beyond the kernel's range stays on the
+    reference's code."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ref_root = os.environ.get("DDSP_REFERENCE_PATH", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "nsf_hifigan")):
+        pytest.skip("reference checkout not present (only in the build container)")
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    for name in ["librosa", "librosa.util", "librosa.filters", "librosa.core", "librosa.sequence", "soundfile", "torchaudio",
+                 "torchaudio.transforms"]:
+        sys.modules.setdefault(name, MagicMock())
+    import nsf_hifigan.nvSTFT as nv
+    from ddsp_svc_amd import mel as M
+    basis = O.mel_filterbank_slaney(44100, 2048, 128, 40, 16000)
+    y = torch.randn(2, 512 * 16, generator=torch.Generator().manual_seed(9)) * 0.1
+    with mock.patch.object(nv, "librosa_mel_fn", side_effect=lambda **kw: basis):
+        want = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y, keyshift=3.0)
+        try:
+            M.patch_reference_stft()
+            stft = nv.STFT(44100, 128, 2048, 2048, 512, 40, 16000)
+            got = stft.get_mel(y.cuda(), keyshift=3.0)
+            assert got.is_cuda and len(stft.__dict__.get("_hip_shifted", {})) == 1
+            _check(got.cpu().numpy(), want.numpy())
+            far = stft.get_mel(y.cuda(), keyshift=25.0)                              # 8680 points: the reference's operators
+            assert far.is_cuda and len(stft._hip_shifted) == 1
+        finally:
+            nv.STFT.get_mel = nv.STFT._reference_get_mel
+            del nv.STFT._reference_get_mel

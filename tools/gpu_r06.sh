@@ -107,6 +107,8 @@ final)
     LAST=100 python "$R/tools/rocpd_launches.py" "$f" k_phase_frame_sums 2>&1 | head -40 > "$O/${V}_train_combsub_launches.txt"; rm -rf "$O/tp" )
   timeout 300 python tools/latency_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee "$O/${V}_latency_small_shapes.txt"
   timeout 300 python tools/mel_pair_probe.py 2>&1 | tail -1 | tee "$O/${V}_mel_pair.txt"
+  timeout 300 python tools/mel_shifted_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee "$O/${V}_mel_shifted.txt"
+  timeout 300 python bench.py --model mel --keyshift 3 --no-also --no-live-traffic 2>/dev/null | tail -1 > "$O/${V}_bench_mel_keyshift3.json"; cut -c1-400 "$O/${V}_bench_mel_keyshift3.json"
   echo "== communicator" | tee "$O/${V}_pg_check.txt"
   for q in 4 8; do for m in none nccl; do GPU_MAX_HW_QUEUES=$q timeout 200 python tools/pg_probe.py $m 2>&1 | grep "ms/step" | sed "s/^/queues=$q /" | tee -a "$O/${V}_pg_check.txt"; done; done
   if [ -n "${DDSP_REFERENCE_PATH:-}" ]; then
