@@ -281,7 +281,7 @@ int launch_mel_czt(const float* audio, int B, int T, const float* tab, int n_new
                    long sb, long sm, long sf, hipStream_t st) {
   const int R = mel_czt_plan(n_new, n_bins);
   const int frames = mel_czt_frames(T, n_new, win_new, hop_new, center);
-  if (!R || frames < 1 || B < 1 || B > 65535 || n_mels < 1) return -1;
+  if (!R || frames < 1 || B < 1 || n_mels < 1) return -1;
   MelCztGeom g;
   g.pairs = (mel_czt_chunks(n_new, R) + 1) / 2;
   g.T = T; g.frames = frames;
@@ -295,16 +295,26 @@ int launch_mel_czt(const float* audio, int B, int T, const float* tab, int n_new
   g.bins_eff = mel_czt_bins(n_new, n_bins);
   g.n_mels = n_mels; g.clip = clip; g.mag_scale = mag_scale;
   g.sb = sb; g.sm = sm; g.sf = sf;
-  // a run of frames per workgroup amortises the twiddles and the filter spectrum (32 registers' worth of loads and sincos);
-  // about two rounds of workgroups on the chip when there are frames enough
-  long span = ((long)B * frames + 1023) / 1024;
-  if (span < 1) span = 1;
-  if (span > 16) span = 16;
-  g.span = (int)span;
-  const dim3 grid((unsigned)((frames + g.span - 1) / g.span), (unsigned)B);
+  // A run of frames per workgroup amortises the twiddles and the filter spectrum (32 registers' worth of loads and sincos: about
+  // 1.5 frames' time).  One workgroup per CU is resident (161 registers x 512 threads): the run length that fills whole rounds of
+  // 256 workgroups with the least work per round.
+  const int per_round = R == 8 ? 256 : 512;
+  long best = -1;
+  g.span = 1;
+  for (int sp = 1; sp <= 32 && sp <= frames; ++sp) {
+    const long wgs = (long)((frames + sp - 1) / sp) * B;
+    const long cost = ((wgs + per_round - 1) / per_round) * (2 * sp + 3);
+    if (best < 0 || cost < best) { best = cost; g.span = sp; }
+  }
   const float2* tb = reinterpret_cast<const float2*>(tab);
-  if (R == 4) hipLaunchKernelGGL(k_mel_czt<4>, grid, dim3(256), 0, st, audio, tb, band, packed, out, g);
-  else        hipLaunchKernelGGL(k_mel_czt<8>, grid, dim3(512), 0, st, audio, tb, band, packed, out, g);
+  for (int b0 = 0; b0 < B; b0 += 65535) {                    // grid.y holds 65535 utterances
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    const dim3 grid((unsigned)((frames + g.span - 1) / g.span), (unsigned)nb);
+    const float* a = audio + (long)b0 * T;
+    float* o = out + (long)b0 * sb;
+    if (R == 4) hipLaunchKernelGGL(k_mel_czt<4>, grid, dim3(256), 0, st, a, tb, band, packed, o, g);
+    else        hipLaunchKernelGGL(k_mel_czt<8>, grid, dim3(512), 0, st, a, tb, band, packed, o, g);
+  }
   return 0;
 }
 

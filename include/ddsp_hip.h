@@ -324,7 +324,7 @@ int ddsp_hip_mel_spectrogram(const float* audio, int B, int T, const float* wind
  * tables: ddsp_hip_mel_shifted_table_bytes(n_fft_new, n_bins) bytes filled once per (n_fft_new, win_new, n_bins) by
  * ddsp_hip_mel_shifted_tables (the caller caches them per keyshift, as the reference caches its windows, :92-94).
  * Supported: n_bins <= 1025 (n_fft <= 2048); n_fft_new <= 8192 (<= 4096 when min(n_bins, n_fft_new/2 + 1) <= 513: the
- * 2048-point convolution plan); win_new <= n_fft_new, hop_new <= win_new; B <= 65535: _table_bytes returns 0 outside.
+ * 2048-point convolution plan); win_new <= n_fft_new, hop_new <= win_new: _table_bytes returns 0 outside.
  * One convolution of 4096 (2048) points per frame up to n_fft_new = 4096 (2048), two beyond.  _frames: the frame count, or
  * DDSP_HIP_EINVAL where torch.stft / F.pad raise (transform longer than the padded signal, center's reflection not
  * shorter than it). */
