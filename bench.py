@@ -1472,7 +1472,7 @@ def bench_cascade_ref(a, rank, world, device):
         ddsp, diff, gen, stft = mods
         with torch.no_grad():
             wav, _, _ = ddsp(units, f0, vol)                                          # main_diff.py:359
-            mel = stft.get_mel(wav).transpose(1, 2)                                   # :360, diffusion/vocoder.py:147
+            mel = stft.get_mel(wav, keyshift=a.keyshift).transpose(1, 2)              # :359 (formant_shift_key), diffusion/vocoder.py:147
             out = diff(units, f0, vol, gt_spec=mel, infer=True, infer_speedup=10, method="dpm-solver", k_step=100,
                        use_tqdm=False)                                                # :366-378
             return gen(out.transpose(1, 2), f0[:, :out.size(1), 0])                   # :379, diffusion/vocoder.py:151-153
@@ -1511,7 +1511,7 @@ def bench_cascade_ref(a, rank, world, device):
                 s2 = synth.phase(f0, SR, HOP)
                 w = synth.combsub_synth(f0, s2, ctrls["group_delay"], ctrls["harmonic_magnitude"], ctrls["noise_magnitude"], u, SR,
                                         HOP, noise_is_u01=True, want_components=False)[0]
-                m = mods[3].get_mel(w)
+                m = mods[3].get_mel(w, keyshift=a.keyshift)
                 e = NS.sine_source(f0[..., 0], HOP, SR, src.l_linear.weight, src.l_linear.bias, ri, nz9)
                 return m, e
             dsp_ms = time_alone(dsp, 10)
@@ -1525,7 +1525,8 @@ def bench_cascade_ref(a, rank, world, device):
     if rank != 0:
         return
     emit({
-        "metric": "audio samples/sec, main_diff.py end to end with the reference's networks (cfg 5)", "value": B * world * T / t_hip,
+        "metric": "audio samples/sec, main_diff.py end to end with the reference's networks (cfg 5)" +
+                  ("" if a.keyshift == 0 else ", formant shift %g semitones" % a.keyshift), "value": B * world * T / t_hip,
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": t_hip * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic, random weights",
         "config": {"workload": "main_diff.py:356-379 for B=%d/GPU x %.0f s (F=%d, T=%d): reference CombSub(256/256/256) + Unit2Control, "
@@ -1548,7 +1549,7 @@ def main(argv=None):
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--keyshift", type=float, default=0.0,
-                    help="--model mel: get_mel's key shift in semitones (the cascade's formant shift, main_diff.py:359)")
+                    help="--model mel / cascade_ref: get_mel's key shift in semitones (the cascade's formant shift, main_diff.py:359)")
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--fir-impl", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
