@@ -20,7 +20,7 @@
 // (overlapped, through L2) and [B, frames, n_mels] written.  Bound: arithmetic, 2 transforms of N points per chunk pair.
 //   k_mel_czt_tables : bhat[N] | (w c)[2 Cp][L] | G1[Cp][K'] | G2[Cp][K'] for one (n', win', K), float64 phases reduced in
 //                      integers; K' = N/4 + 1
-//   k_mel_czt<R>     : the frames
+//   k_mel_czt<R>     : the frames, two in lockstep
 #include "fft_r.h"
 #include "kernels.h"
 
@@ -126,16 +126,19 @@ struct MelCztGeom {
 
 constexpr int MZ_MAGS = 1032;                                // floats of a frame's magnitudes in LDS (a basis of <= 1025 bins)
 
-// Two waves per SIMD (161 registers, none spilled): the forms cut to 128 registers for four spill 25 - 40 of them and take 0.96 ms
-// where this one takes 0.69 (B = 32 x 10 s, any shift up to +12 semitones; r06_v30_mel_shifted_forms.txt).
+// TWO frames in lockstep (Plan::forward2: the same arithmetic as two transforms, behind shared barriers -- twice the work between
+// two barriers, one frame's exchange latency under the other's butterflies): 0.627 ms against 0.667 one frame at a time (B = 32 x
+// 10 s, r06_v36_mel_shifted_lockstep.txt).  A run with an odd number of frames does its last one twice (the copy is not stored).
+// Two waves per SIMD (237 registers, none spilled; 136 KB of LDS at N = 4096: one workgroup per CU).  The one-frame form cut to 128
+// registers for four waves spilled 25 - 40 of them and took 0.96 ms against 0.69 (r06_v30_mel_shifted_forms.txt).
 template <int R>
 __global__ void __launch_bounds__(64 * R, 2) k_mel_czt(const float* __restrict__ audio, const float2* __restrict__ tab,
-                                                       const int* __restrict__ band, const float* __restrict__ packed,
-                                                       float* __restrict__ out, MelCztGeom g) {
+                                                        const int* __restrict__ band, const float* __restrict__ packed,
+                                                        float* __restrict__ out, MelCztGeom g) {
   using PL = fft::Plan<R>;
   constexpr int N = PL::N, P = PL::P, L = N / 2, KT = N / 4 + 1;
-  __shared__ __attribute__((aligned(16))) f32x2 ex[2][N];
-  __shared__ float mags[MZ_MAGS];
+  __shared__ __attribute__((aligned(16))) f32x2 ex[4][N];
+  __shared__ float mags[2][MZ_MAGS];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int f_lo = blockIdx.x * g.span;
@@ -171,41 +174,57 @@ __global__ void __launch_bounds__(64 * R, 2) k_mel_czt(const float* __restrict__
     const float v = ab[u];
     return ok ? v : 0.f;
   };
-  float nx[2][4];                                            // the NEXT chunk pair's samples: in flight during this one's transforms
+  float nx[2][2][4];                                         // [frame of the pair][chunk of the pair][slot]: the NEXT convolution's samples
   auto fetch = [&](int f, int p) {
-    const int base = f * g.hop + 2 * p * L;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int e = 0; e < 2; ++e) {
+      const int fe = f + e < f_hi ? f + e : f_hi - 1;
+      const int base = fe * g.hop + 2 * p * L;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) nx[h][m] = sample(base + h * L + P * m + tid);
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) nx[e][h][m] = sample(base + h * L + P * m + tid);
+    }
   };
   if (f_lo < f_hi) fetch(f_lo, 0);
-  for (int f = f_lo; f < f_hi; ++f) {
-    f32x2 acc[3];                                            // X[k], k = P m + tid <= N/4: the slots 0, 1 and (thread 0) 2
+  for (int f = f_lo; f < f_hi; f += 2) {
+    f32x2 acc[2][3];                                         // X[k], k = P m + tid <= N/4: the slots 0, 1 and (thread 0) 2
 #pragma unroll
-    for (int m = 0; m < 3; ++m) acc[m] = f32x2{0.f, 0.f};
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) acc[e][m] = f32x2{0.f, 0.f};
     for (int p = 0; p < g.pairs; ++p) {
-      f32x2 v[8];
+      f32x2 v[2][8];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {                          // (a w + i b w') c: the two chunks' windows differ, the chirp does not
         const f32x2 wa = wc[(2 * p) * L + P * m + tid], wb = wc[(2 * p + 1) * L + P * m + tid];
-        v[m] = f32x2{nx[0][m] * wa.x - nx[1][m] * wb.y, nx[0][m] * wa.y + nx[1][m] * wb.x};
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          v[e][m] = f32x2{nx[e][0][m] * wa.x - nx[e][1][m] * wb.y, nx[e][0][m] * wa.y + nx[e][1][m] * wb.x};
       }
 #pragma unroll
-      for (int m = 4; m < 8; ++m) v[m] = f32x2{0.f, 0.f};
-      if (p + 1 < g.pairs) fetch(f, p + 1);
-      else if (f + 1 < f_hi) fetch(f + 1, 0);
-      __syncthreads();                                       // the last transform's pass 4 still reads ex[0]
-      PL::template forward<true>(v, tw, ex[0], ex[1], tid);
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = cconj(cmul(v[m], gq[m]));
+        for (int m = 4; m < 8; ++m) v[e][m] = f32x2{0.f, 0.f};
+      if (p + 1 < g.pairs) fetch(f, p + 1);
+      else if (f + 2 < f_hi) fetch(f + 2, 0);
+      __syncthreads();                                       // the last transforms' pass 4 still reads ex[0], ex[2]
+      PL::template forward2<true>(v[0], v[1], tw, ex[0], ex[1], ex[2], ex[3], tid);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        v[0][m] = cconj(cmul(v[0][m], gq[m]));
+        v[1][m] = cconj(cmul(v[1][m], gq[m]));
+      }
       __syncthreads();
-      PL::forward(v, tw, ex[0], ex[1], tid);                 // v = conj(N y), natural order: index P m + tid
-      // the bins -N/4 .. -1 sit at the indices 3N/4 .. N-1 (slots 6, 7): through ex[1] (free since pass 3) to their mirror
-      f32x2* Y = ex[1];
-      Y[6 * P + tid] = v[6];
-      Y[7 * P + tid] = v[7];
-      if (tid == 0) Y[0] = v[0];
+      PL::forward2(v[0], v[1], tw, ex[0], ex[1], ex[2], ex[3], tid);   // v = conj(N y), natural order: index P m + tid
+      // the bins -N/4 .. -1 sit at the indices 3N/4 .. N-1 (slots 6, 7): through ex[1] / ex[3] (free since pass 3) to their mirror
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x2* Y = ex[1 + 2 * e];
+        Y[6 * P + tid] = v[e][6];
+        Y[7 * P + tid] = v[e][7];
+        if (tid == 0) Y[0] = v[e][0];
+      }
       f32x2 q1[3], q2[3];
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
@@ -216,36 +235,44 @@ __global__ void __launch_bounds__(64 * R, 2) k_mel_czt(const float* __restrict__
       }
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int k = P * m + tid;
-        if (k < KT) {
-          const f32x2 ym = Y[(N - k) & (N - 1)];              // conj(N y[-k])
-          const f32x2 x = cmul(cconj(v[m]), q1[m]), z = cmul(ym, q2[m]);
-          acc[m] = f32x2{acc[m].x + (x.x + z.x), acc[m].y + (x.y + z.y)};
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int k = P * m + tid;
+          if (k < KT) {
+            const f32x2 ym = ex[1 + 2 * e][(N - k) & (N - 1)];   // conj(N y[-k])
+            const f32x2 x = cmul(cconj(v[e][m]), q1[m]), z = cmul(ym, q2[m]);
+            acc[e][m] = f32x2{acc[e][m].x + (x.x + z.x), acc[e][m].y + (x.y + z.y)};
+          }
         }
-      }
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int k = P * m + tid;
-      if (k < KT && k < g.bins_eff) mags[k] = sqrtf(fmaf(acc[m].x, acc[m].x, acc[m].y * acc[m].y) + 1e-9f) * g.mag_scale;
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int k = P * m + tid;
+        if (k < KT && k < g.bins_eff)
+          mags[e][k] = sqrtf(fmaf(acc[e][m].x, acc[e][m].x, acc[e][m].y * acc[e][m].y) + 1e-9f) * g.mag_scale;
+      }
+      for (int k = g.bins_eff + tid; k < g.bins; k += P) mags[e][k] = 0.f;    // nvSTFT.py:110-113: zeros above the shifted Nyquist
     }
-    for (int k = g.bins_eff + tid; k < g.bins; k += P) mags[k] = 0.f;    // nvSTFT.py:110-113: zeros above the shifted Nyquist
     __syncthreads();
     // banded mel projection (nvSTFT.py:115-116): four lanes per filter, every fourth bin of its band each
-    for (int c0 = 0; c0 < g.n_mels; c0 += P / 4) {
-      const int c = c0 + (tid >> 2), part = tid & 3;
-      float a = 0.f;
-      if (c < g.n_mels) {
-        const int lo = band[4 * c], hi = band[4 * c + 1];
-        const float* wr = packed + band[4 * c + 2] - lo;
-        for (int k = lo + part; k < hi; k += 4) a = fmaf(wr[k], mags[k], a);
+    for (int e = 0; e < 2 && f + e < f_hi; ++e) {
+      for (int c0 = 0; c0 < g.n_mels; c0 += P / 4) {
+        const int c = c0 + (tid >> 2), part = tid & 3;
+        float a = 0.f;
+        if (c < g.n_mels) {
+          const int lo = band[4 * c], hi = band[4 * c + 1];
+          const float* wr = packed + band[4 * c + 2] - lo;
+          for (int k = lo + part; k < hi; k += 4) a = fmaf(wr[k], mags[e][k], a);
+        }
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        if (c < g.n_mels && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(f + e) * g.sf] = logf(fmaxf(a, g.clip));
       }
-      a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-      a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-      if (c < g.n_mels && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)f * g.sf] = logf(fmaxf(a, g.clip));
     }
-    // no barrier: the next frame writes mags (and ex[1]) behind its transforms' barriers
+    // no barrier: the next frames write mags (and ex[1], ex[3]) behind their transforms' barriers
   }
 }
 
@@ -296,12 +323,12 @@ int launch_mel_czt(const float* audio, int B, int T, const float* tab, int n_new
   g.n_mels = n_mels; g.clip = clip; g.mag_scale = mag_scale;
   g.sb = sb; g.sm = sm; g.sf = sf;
   // A run of frames per workgroup amortises the twiddles and the filter spectrum (32 registers' worth of loads and sincos: about
-  // 1.5 frames' time).  One workgroup per CU is resident (161 registers x 512 threads): the run length that fills whole rounds of
+  // 1.5 frames' time).  One workgroup per CU is resident (N = 4096; two at 2048): the run length that fills whole rounds of
   // 256 workgroups with the least work per round.
   const int per_round = R == 8 ? 256 : 512;
   long best = -1;
-  g.span = 1;
-  for (int sp = 1; sp <= 32 && sp <= frames; ++sp) {
+  g.span = 2;
+  for (int sp = 2; sp <= 32; sp += 2) {                      // frames go through in pairs
     const long wgs = (long)((frames + sp - 1) / sp) * B;
     const long cost = ((wgs + per_round - 1) / per_round) * (2 * sp + 3);
     if (best < 0 || cost < best) { best = cost; g.span = sp; }
