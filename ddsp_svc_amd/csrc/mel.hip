@@ -9,7 +9,7 @@
 // The reference materialises a [B, 1025, F] complex spectrum and its magnitude.  Here a 256-thread workgroup walks a
 // run of frame PAIRS: frame j rides in the real and frame j+1 in the imaginary part of ONE 2048-point complex
 // transform (fft_r.h), the two spectra are separated with the mirrored bin Z[-k] through LDS, the magnitudes of
-// both frames are parked in LDS, and 2 x n_mels threads reduce them against their filter's band -- a mel basis row
+// both frames are parked in LDS, and four lanes per (filter, frame) reduce them against the filter's band -- a mel basis row
 // is a short contiguous band (2..90 bins of 1025), so the projection reads ~2 k weights per frame instead of the
 // 131 k of the dense matmul.  Only the waveform (4x overlapped, through L2) and the [B, F, n_mels] result touch HBM.
 #include "fft_r.h"
@@ -122,22 +122,28 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
       }
     }
     __syncthreads();
-    // banded mel projection: thread (h, c) reduces frame j0 + h against filter c (nvSTFT.py:115-116)
-    const int h = tid >> 7;
-    if (h == 0 || live1) {
-      for (int c = tid & 127; c < g.n_mels; c += 128) {
+    // banded mel projection (nvSTFT.py:115-116): four lanes per (filter, frame), every fourth bin of the band each; a round of
+    // 256 lanes takes 32 consecutive filters of both frames, so its lanes' bands are about equally long (a Slaney band grows from
+    // 2 to 90 bins across the filters: one thread per filter made every wave wait for the longest; 0.1217 -> 0.1209 ms, r06_v37_mel_quad.txt)
+    for (int t0 = 0; t0 < 8 * g.n_mels; t0 += P) {
+      const int task = t0 + tid, part = task & 3, fc = task >> 2;
+      const int c = fc >> 1, h = fc & 1;
+      const bool on = c < g.n_mels && (h == 0 || live1);
+      float acc = 0.f;
+      if (on) {
         const int lo = band[4 * c], hi = band[4 * c + 1];
         const float* mg = mags + h * MROW;
-        float acc = 0.f;
         if (g.packed_len > 0) {
           const float* wr = wl + band[4 * c + 2] - lo;
-          for (int k = lo; k < hi; ++k) acc = fmaf(wr[k], mg[k], acc);
+          for (int k = lo + part; k < hi; k += 4) acc = fmaf(wr[k], mg[k], acc);
         } else {
           const float* wr = basis + (long)c * BINS;
-          for (int k = lo; k < hi; ++k) acc = fmaf(wr[k], mg[k], acc);
+          for (int k = lo + part; k < hi; k += 4) acc = fmaf(wr[k], mg[k], acc);
         }
-        out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
       }
+      acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+      acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+      if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
     }
     // no barrier: the next transform writes Bx first (its readers are behind the barrier above) and A -- the
     // magnitudes -- only after its own first barrier, which every thread reaches after its projection loop
