@@ -152,6 +152,9 @@ def test_get_mel_other_configurations_golden(dev, golden_dir):
     (1, 512 * 30, {"keyshift": 24}),                          # 8192 points: four chunks, the kernel's limit
     (2, 300, {"keyshift": -7, "center": True}),               # zeros instead of the reflection, then torch.stft's own
     (1, 512 * 40 + 3, {"keyshift": -2.5, "speed": 2.0}),      # 1772 points, hop 1024: several frames per workgroup run
+    (2, 1, {"keyshift": 3}),                                  # one sample: everything else is zero padding
+    (2, 2, {"keyshift": -3, "center": True}),
+    (1, 5, {"speed": 0.3}),                                   # hop 154
 ])
 def test_get_mel_shifted_shapes(dev, B, T, kw):
     from ddsp_svc_amd import mel as M
@@ -191,6 +194,18 @@ def test_get_mel_dense_basis(dev):
     cfg = dict(CFG, n_mels=40)
     out = M.STFT(**cfg, mel_basis=torch.from_numpy(W)).get_mel(torch.from_numpy(y).to(dev)).cpu().numpy()
     _check(out, O.get_mel(y, W))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_get_mel_shifted_dense_basis(dev):
+    """more filters than one pass of the projection takes (200 > 128), none of them banded"""
+    from ddsp_svc_amd import mel as M
+    rng = np.random.default_rng(6)
+    W = (rng.random((200, 1025)) * 1e-2).astype(np.float32)
+    y = (0.1 * rng.standard_normal((2, 512 * 6))).astype(np.float32)
+    cfg = dict(CFG, n_mels=200)
+    out = M.STFT(**cfg, mel_basis=torch.from_numpy(W)).get_mel(torch.from_numpy(y).to(dev), keyshift=1.3).cpu().numpy()
+    _check(out, O.get_mel(y, W, keyshift=1.3))
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
