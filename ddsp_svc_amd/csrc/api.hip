@@ -18,7 +18,7 @@ thread_local int t_geometry_batch = 0;
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS", "TAPS_FULL"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 // A knob whose kernel generation is not compiled into this build (the product library ships ONE generation per kernel; the
@@ -325,6 +325,20 @@ bool fused_shape_ok(long R, int F, int hop, int n0, int n1, int n2, int fir_impl
     return true;
   }
   return n1 == 256 && n2 == 256;                              // Sins: all-pass and noise filter at 256 bins (n0 = harmonics)
+}
+
+// The fused layouts keep the tap rows of the NOISE filter (zero phase, Hann window: an even response, tap N - j is tap j) as the first
+// n = N/2 + 1 taps, and the filter reads them so (launch_taps_pfa510's half_rows, launch_fir_blk's taps_half) -- 56 MB less through
+// HBM per step at B = 32 x 10 s and half the window factors and stores of that tap synthesis.  (CombSub's harmonic filter is zero
+// phase too, but its dynamic window clamps the upper side only, core.py:245: not even.)  Knob TAPS_FULL = 1: whole rows (same-box
+// A/Bs; same bits either way: the whole rows hold the same numbers twice).  No backward kernel reads these taps.
+bool taps_half_ok(int F, int hop, int fir_impl) {
+#if defined(DDSP_AB_GENERATIONS) || defined(DDSP_PFA_NOSYM)
+  (void)F; (void)hop; (void)fir_impl;
+  return false;
+#else
+  return knob(KNOB_TAPS_FULL) != 1 && hop == 512 && (fir_impl == 0 || fir_impl == 5) && (long)F * hop < (1L << 28);
+#endif
 }
 
 size_t carve_synth(Carver& c, int B, int F, int hop, int n_max, SynthWs& w) {
@@ -673,12 +687,16 @@ int sins_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
     if (r == -2) return DDSP_HIP_ESHAPE;
     TapsJobs jobs;
     jobs.n = 0;
+    const int half = taps_half_ok(F, hop, a.fir_impl) ? 1 : 0;  // the noise filter's taps as half rows (its launch is then the hop-block form's own)
     int ok = launch_taps_pfa510(a.c2, a.ld2, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R,
-                                n_nz, w.taps_nz, st, 0.f, &jobs);
+                                n_nz, w.taps_nz, st, 0.f, &jobs, half);
     ok |= launch_taps_pfa510(a.c1, a.ld1, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, a.t1, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
                              w.taps, st, 0.f, &jobs);
     if (ok != 0 || launch_taps_pfa510_batch(jobs, st) != 0) return DDSP_HIP_ESHAPE;
-    if (launch_fir(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), a.fir_impl, st, &a.gen) < 0)
+    if (half) {
+      if (launch_fir_blk(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), st, &a.gen, nullptr, 1) < 0)
+        return DDSP_HIP_ESHAPE;
+    } else if (launch_fir(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), a.fir_impl, st, &a.gen) < 0)
       return DDSP_HIP_ESHAPE;
     if (launch_fir(w.buf0, 0, w.taps, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_ap - 1), a.fir_impl, st) < 0)
       return DDSP_HIP_ESHAPE;
@@ -729,14 +747,15 @@ int combsub_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream
     if (make_exciter_job(a.f0_frames, a.initial_phase, B, F, hop, a.sr, a.infer, a.phase0, w.buf0, &exc) != 0) return DDSP_HIP_EHOP;
     TapsJobs jobs;
     jobs.n = 0;
+    const int half = taps_half_ok(F, hop, a.fir_impl) ? 1 : 0;  // the noise filter's taps as half rows
     int ok = launch_taps_pfa510(a.c2, a.ld2, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f / 128.0f, a.t2, DDSP_HIP_MODE_HANN, nullptr, R,
-                                n_nz, w.taps_nz, st, 0.f, &jobs);
+                                n_nz, w.taps_nz, st, 0.f, &jobs, half);
     ok |= launch_taps_pfa510(a.c0, a.ld0, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, a.t0, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
                              w.taps, st, 0.f, &jobs);
     ok |= launch_taps_pfa510(a.c1, a.ld1, nullptr, 0, 0, DDSP_HIP_ACT_EXP, 1.0f, a.t1, DDSP_HIP_MODE_DYNAMIC, a.f0_frames, R,
                              n_harm, w.taps3, st, (float)a.sr, &jobs);
     if (ok != 0 || launch_taps_pfa510_batch(jobs, st, &exc) != 0) return DDSP_HIP_ESHAPE;   // exciter + the three tap syntheses
-    const FirSecond second{a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr};
+    const FirSecond second{a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, half};
     if (launch_fir_blk(w.buf0, 0, w.taps, nullptr, w.buf1, nullptr, B, F, hop, 2 * (n_ap - 1), st, a.gen.on ? &a.gen : nullptr, &second) < 0)
       return DDSP_HIP_ESHAPE;
     if (launch_fir(w.buf1, 0, w.taps3, nz, a.signal, a.harmonic, B, F, hop, 2 * (n_harm - 1), a.fir_impl, st) < 0)

@@ -382,6 +382,7 @@ struct FirJob {
   const float* taps; const float* addend;
   float* out; float* out_plain;
   int rng;                      // k_fir_blk6<true> only: THIS job's input is drawn in the load path (the other job of a launch may read its)
+  int taps_half;                // rows of N/2 + 1 taps of an even response (kernels.h): tap N - j is read from j
 };
 struct FirJobs { FirJob j[2]; };
 
@@ -409,7 +410,8 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
   const int SH = FB_HOP / 2 - (g.N >> 1);
   const int bu = __builtin_amdgcn_readfirstlane(b);
   const float* xb = x + (long)bu * g.T;
-  const float* tb = taps + (long)bu * g.F * g.N;
+  const int tap_ld = J.taps_half ? (g.N >> 1) + 1 : g.N;    // floats per tap row (workgroup-uniform)
+  const float* tb = taps + (long)bu * g.F * tap_ld;
   const long ob = (long)bu * g.T;
   const BufF32 out_buf = BufF32::make(out + ob, g.T);
   const BufF32 plain_buf = BufF32::make(out_plain ? out_plain + ob : out + ob, out_plain ? g.T : 0);
@@ -427,14 +429,15 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int i = P * m + tid - SH;
-    tap_off[m] = i >= 0 ? 4 * i : BufF32::kOutOfRange;
+    const int ih = i >= g.N ? -1 : ((J.taps_half && i > (g.N >> 1)) ? g.N - i : i);   // an even response: tap N - j is tap j
+    tap_off[m] = ih >= 0 ? 4 * ih : BufF32::kOutOfRange;
   }
   // live == false (workgroup-uniform): the run ends before this row / block would be used -- the descriptor then spans 0 bytes
   // and the loads touch no memory (a load is issued a pass ahead of its use, so every run used to fetch 8 - 12 KB past its end)
   auto load_taps = [&](int j, bool live = true) -> TapRow {
     TapRow r;
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
-    const BufF32 tr = BufF32::make(tb + (long)row * g.N, live ? g.N : 0);
+    const BufF32 tr = BufF32::make(tb + (long)row * tap_ld, live ? tap_ld : 0);
 #pragma unroll
     for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
     return r;
@@ -676,7 +679,7 @@ int launch_uniform_noise(unsigned long long seed, unsigned long long offset, int
 
 // returns the implementation id (5) or < 0 when the shape is outside this kernel
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
-                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen, const FirSecond* second) {
+                   int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen, const FirSecond* second, int taps_half) {
   if (hop != FB_HOP || N < 2 || (N & 1) || N > 512 || (long)F * hop >= (1L << 28)) return -1;   // one utterance stays below 2^30 bytes (buffer descriptors, BufF32::kOutOfRange)
   FirBlkGeom g;
   g.F = F; g.N = N; g.T = F * hop;
@@ -709,14 +712,17 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   if (wgs > 0x7fffffffL) return -1;
   NoiseGen rng{0ull, 0ull, 0};
   FirJobs jobs;
-  jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain, 0};
+#ifdef DDSP_AB_GENERATIONS
+  if (taps_half || (second && second->taps_half)) return -1;   // (the two-wave kernel reads whole rows)
+#endif
+  jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain, 0, taps_half};
   jobs.j[1] = jobs.j[0];
   if (noise_gen && noise_gen->on && second) {                   // two jobs, the SECOND one's input drawn in the kernel (its x may be null)
 #ifdef DDSP_AB_GENERATIONS
     if (wps < 3) return -1;
 #endif
     rng = *noise_gen;
-    jobs.j[1] = FirJob{second->x, 0, second->taps, second->addend, second->out, second->out_plain, 1};
+    jobs.j[1] = FirJob{second->x, 0, second->taps, second->addend, second->out, second->out_plain, 1, second->taps_half};
     hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs, 2u), dim3(128), 0, st, jobs, g, rng);
     return 5;
   }
@@ -734,7 +740,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
     return 5;
   }
   if (second && wps >= 3) {                                     // two independent filters of this shape in one launch
-    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain, 0};
+    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain, 0, second->taps_half};
     hipLaunchKernelGGL((k_fir_blk6<false>), dim3((unsigned)wgs, 2u), dim3(128), 0, st, jobs, g, rng);
     return 5;
   }

@@ -308,6 +308,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   const float* __restrict__ half_width = J.half_width;
   const long rows = J.rows;
   float* __restrict__ taps = J.taps;
+  const bool half = J.half != 0;                            // rows of NB = N/2 + 1 taps (an even response under an even window: tap N - j is tap j)
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * ROWS;
   float* re_s = U;
@@ -497,19 +498,31 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
     }
     if (act) {
       dft30(v);
-      float* oa = O + (2 * t) * NT;
-      float* ob = oa + NT;
+      // an even response (sym): only the results at taps j <= N/2 are used -- tap N - j is the same number.  (Row k1 = 0 holds
+      // both j and N - j of its own; they agree to rounding only, so the one at j <= N/2 serves both and a response comes out
+      // EXACTLY even whichever layout stores it.)  half: the staging rows hold the NB taps j <= N/2.
+      const int rl = half ? NB : NT;
+      float* oa = O + (2 * t) * rl;
+      float* ob = oa + rl;
       const int base = (120 * k1 + HALF) % NT;
 #pragma unroll
       for (int k2 = 0; k2 < 30; ++k2) {
         int j = base + (391 * k2) % NT;                     // the second term is a compile-time constant
         if (j >= NT) j -= NT;
-        oa[j] = v[k2].x;
-        ob[j] = v[k2].y;
-        if (sym && k1 != 0) {                               // z[-m] = z[m]: tap 510 - j (row k1 = 0 holds both of its own)
-          const int jm = j ? NT - j : 0;
-          oa[jm] = v[k2].x;
-          ob[jm] = v[k2].y;
+        if (!sym) {
+          oa[j] = v[k2].x;
+          ob[j] = v[k2].y;
+        } else {
+          const int jm = j ? NT - j : 0;                    // z[-m] = z[m]: tap 510 - j
+          const int jl = j <= HALF ? j : jm;                // the one of the two at or below N/2
+          if (k1 != 0 || j <= HALF) {
+            oa[jl] = v[k2].x;
+            ob[jl] = v[k2].y;
+            if (!half) {
+              const int jh = NT - jl;                       // its mirror image (jl = 0 has none; jl = N/2 is its own)
+              if (jl != 0) { oa[jh] = v[k2].x; ob[jh] = v[k2].y; }
+            }
+          }
         }
       }
     }
@@ -521,6 +534,29 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   // groups of four are 1024 floats apart: row + 2, tap + 4 (mod 510).  Eight groups per thread, unrolled: the window
   // values of all eight are fetched first (MODE_HANN) or come from LDS (MODE_DYNAMIC), so a memory latency is paid once
   // and not once per group (tools/pfa_timeline.py: stage C 3.5 -> 2.2 us and 4.9 -> 4.0 us) ----
+  if (half) {
+    // rows of NB = 256 taps: a thread's groups of four are four rows apart at the same taps j .. j + 3 -- one window fetch serves
+    // all of them (MODE_HANN), half the stores and window factors of the full rows
+    static_assert(NB == 256, "the half-row store: 64 threads per row");
+    float* dst = taps + row0 * NB;
+    const long left = rows - row0;                         // rows left in the tensor from this batch on
+    const int j = 4 * (tid & 63), rb = tid >> 6;
+    float2 wa = make_float2(1.f, 1.f), wb = wa;
+    if (MODE == MODE_HANN) {
+      wa = *reinterpret_cast<const float2*>(hann + j);
+      wb = *reinterpret_cast<const float2*>(hann + j + 2);
+    }
+#pragma unroll
+    for (int it = 0; it < (ROWS + 3) / 4; ++it) {
+      const int r = rb + 4 * it;
+      if (ROWS % 4 != 0 && r >= ROWS) break;
+      const float4 o = *reinterpret_cast<const float4*>(O + r * NB + j);
+      const float w[4] = {wa.x, wa.y, wb.x, wb.y};          // (never MODE_DYNAMIC: that window is not even, launch_taps_pfa510)
+      if (r < left) *reinterpret_cast<float4*>(dst + r * NB + j) = make_float4(o.x * w[0], o.y * w[1], o.z * w[2], o.w * w[3]);
+    }
+    PFA_STAMP(4);
+    return;
+  }
   float* dst = taps + row0 * NT;
   const long total = rows * (long)NT - row0 * NT;         // floats left in the tensor from this batch on
   constexpr int GROUPS = (ROWS * NT / 4 + 255) / 256;     // 8; the last one is partial
@@ -815,7 +851,7 @@ int launch_taps_pfa510_bwd_jobs(const TapsBwdJobs& in, const float* table, long 
 // returns 0 when the fast form took the call, -1 when the shape is not its (the caller then uses the dense contraction)
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                       hipStream_t st, float hw_from_f0_sr, TapsJobs* batch) {
+                       hipStream_t st, float hw_from_f0_sr, TapsJobs* batch, int half_rows) {
   if (n != pfa::NB || rows <= 0) return -1;                 // (knob TAPS_GEMM is the caller's decision: read once per API call)
   if ((reinterpret_cast<uintptr_t>(taps) & 15) != 0) return -1;
   const long KP = ((long)n + 15) / 16 * 16, NP = ((long)n + 255) / 256 * 256;
@@ -830,7 +866,11 @@ int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld
     kind = pfa::KIND_COMPLEX;
   }
   const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
-  TapsJob job{kind, act == 1 ? 1 : 0, m, a_re, ld_re, a_im, ld_im, scale, hann, half_width, hw_from_f0_sr, rows, taps};
+#ifdef DDSP_PFA_NOSYM
+  if (half_rows) return -1;
+#endif
+  if (half_rows && (kind != pfa::KIND_REAL || m == pfa::MODE_DYNAMIC)) return -1;   // a zero-phase response under an even window (the dynamic one clamps one side only, core.py:245)
+  TapsJob job{kind, act == 1 ? 1 : 0, m, a_re, ld_re, a_im, ld_im, scale, hann, half_width, hw_from_f0_sr, rows, taps, half_rows ? 1 : 0};
   if (batch) {                                              // collected, launched by launch_taps_pfa510_batch (all jobs: the same row count)
     if (batch->n >= 3 || (batch->n > 0 && batch->j[0].rows != rows)) return -1;
     batch->j[batch->n++] = job;

@@ -53,12 +53,13 @@ struct TapsJob {
   float hw_sr;
   long rows;
   float* taps;
+  int half;                // real kinds under an even window (Hann, none) only: rows of n = N/2 + 1 taps (j <= N/2; tap N - j is tap j)
 };
 struct TapsJobs { TapsJob j[3]; int n; };
 // batch != null: the job is appended to *batch instead of being launched (launch_taps_pfa510_batch launches them together)
 int launch_taps_pfa510(const float* a_re, long ld_re, const float* a_im, long ld_im, int allpass_from_control, int act,
                        float scale, const float* table, int mode, const float* half_width, long rows, int n, float* taps,
-                       hipStream_t st, float hw_from_f0_sr = 0.f, TapsJobs* batch = nullptr);
+                       hipStream_t st, float hw_from_f0_sr = 0.f, TapsJobs* batch = nullptr, int half_rows = 0);
 // the exciter of a streaming-shape CombSub step as data (launch_combtooth's arguments): rides in the tap launch (k_front_small)
 struct ExciterJob {
   const float* f0_frames; const float* initial_phase;
@@ -95,10 +96,13 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
                    int B, int F, int hop, int N, hipStream_t st);
 // second != null: a second, independent filter of the same shape (B, F, hop, N) rides in the same launch (k_fir_blk6, grid.y);
 // -1 when this launch cannot take it (the in-kernel noise draw, the two-wave kernel)
-struct FirSecond { const float* x; int x_is_u01; const float* taps; const float* addend; float* out; float* out_plain; };
+// taps_half: the tap rows are the first N/2 + 1 taps of an EVEN response (a zero-phase magnitude filter's under the Hann window:
+// tap N - j is tap j), [B, F, N/2 + 1] -- what launch_taps_pfa510(.., half_rows = 1) writes; the fused layouts of api.hip keep the
+// noise filter's taps so.  (NOT the harmonic filter's: the dynamic window clamps its upper side only, core.py:245, and is not even.)
+struct FirSecond { const float* x; int x_is_u01; const float* taps; const float* addend; float* out; float* out_plain; int taps_half; };
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr,
-                   const FirSecond* second = nullptr);
+                   const FirSecond* second = nullptr, int taps_half = 0);
 // second != null: a second, independent TAP gradient of the same shape rides in the same launch (k_fir_blk_bwd6, grid.y); -1 when
 // this launch cannot take it (an input gradient is wanted, knob BWD_WPS = 2)
 struct FirBwdSecond { const float* x; int x_is_u01; const float* grad_out; float* d_taps; };

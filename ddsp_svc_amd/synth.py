@@ -439,6 +439,8 @@ class SinsTailFunction(torch.autograd.Function):
         f0, ca, cg, cn, nz, ws = ctx.saved_tensors
         lda, ldg, ldn, u01, sr, hop, lay, state, (B, F, T, N, H) = ctx.cfg
         sinus = _ws_view(ws, lay[0], (B, T))
+        # (the noise taps: only their shape is used below -- no input gradient is asked of that filter, so its adjoint reads no
+        # taps; the workspace may hold them as half rows, ddsp_hip.h)
         taps_ap, taps_nz = _ws_view(ws, lay[2], (B, F, N)), _ws_view(ws, lay[4], (B, F, N))
         gh = _sum_cot((B, T), f0.device, g_sig, g_harm)
         gn = _sum_cot((B, T), f0.device, g_sig, g_nz)

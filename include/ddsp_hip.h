@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 163          /* 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
+#define DDSP_HIP_VERSION 164          /* 0.1.6.4: the fused layouts keep the noise filter's (even) tap rows as their first half, knob TAPS_FULL; 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -60,7 +60,9 @@ const char* ddsp_hip_error_string(int code);
  * backward kernel: 0 = on, 2 = off), BLK_WPS (the hop-block filter: 0 / 3 = k_fir_blk6, three waves per SIMD; 2 = round 3's
  * two-wave kernel, kept for same-box A/B runs), SINS_NOSKIP (1 = the sinusoid bank also sums the harmonics that are masked
  * to 1e-7 in both frames of a hop), SMALL_PATH (1 = never take the fused launches of the streaming shapes, B F < 4096: the
- * batch layout at every size; the results are the same bits either way); the rest are run lengths. */
+ * batch layout at every size; the results are the same bits either way), TAPS_FULL (1 = the fused layouts keep the noise
+ * filter's tap rows whole, [B,F,N], instead of their first N/2 + 1 taps -- an even response; same bits either way); the rest
+ * are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 
@@ -203,8 +205,8 @@ size_t ddsp_hip_synth_workspace_bytes(int B, int F, int hop, int n_max);
  * n2 = n_nz) call of this shape LEAVES ITS INTERMEDIATES in the workspace -- what a training caller keeps for the backward pass
  * (solver.py:93-103: the same forward with gradients) instead of recomputing or re-running the tail as separate operators:
  * byte offsets into `ws` of [0] the exciter [B,T], [1] the all-pass filter's output [B,T] (CombSub), [2] the all-pass taps
- * [B,F,N], [3] the harmonic taps (CombSub), [4] the noise taps, [5] the filtered noise (when no noise output was passed); -1 =
- * not kept.  Returns 1 when the call takes the fused layout and the offsets are valid until the workspace is written again, 0
+ * [B,F,N], [3] the harmonic taps (CombSub), [4] the noise taps -- [B,F,N/2+1]: the first N/2 + 1 taps of an even response (tap
+ * N - j is tap j) unless knob TAPS_FULL --, [5] the filtered noise (when no noise output was passed); -1 = not kept.  Returns 1 when the call takes the fused layout and the offsets are valid until the workspace is written again, 0
  * when it does not (other bin counts / hops, in-kernel noise, sub-batch lanes: nothing is promised), < 0 on bad arguments. */
 int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int n2, int fir_impl, int in_kernel_noise,
                          long long offsets[6]);

@@ -180,3 +180,25 @@ def test_superfast_streaming_layout_same_bits(dev, B, F, knobs):
     ref = O.combsubsuperfast_dsp(f0, hm, hp, nm, nph, gz, SR, HOP, 2048, w.numpy())["signal"]
     e = rms(a.cpu().numpy() - ref)
     assert e <= 1e-5 * rms(ref), (e, rms(ref))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F", [(1, 33), (5, 820)])
+def test_half_tap_rows_of_the_noise_filter_same_bits(dev, B, F, knobs):
+    """The fused layouts keep the noise filter's tap rows -- a zero-phase response under the Hann window: even, tap N - j is tap j --
+    as their first N/2 + 1 taps and the filter reads them mirrored; knob TAPS_FULL = 1 keeps whole rows.  Same bits, CombSub and
+    Sins, at a streaming and at a batch shape (B F >= 4096: the paired filter launch)."""
+    from ddsp_svc_amd import synth
+    arrays, tensors = _inputs(B, F, dev, seed=7 + F)
+    f0, cg, ch, cn, u = tensors
+    amps = torch.from_numpy(O.synth_controls(B, F, [64], seed=F)[0]).to(dev)
+
+    def both():
+        st = synth.phase(f0, SR, HOP)
+        c = synth.combsub_synth(f0, st, cg, ch, cn, u, SR, HOP, noise_is_u01=True)
+        s = synth.sins_synth(f0, st, amps, cg, cn, u, SR, HOP, noise_is_u01=True)
+        return list(c) + list(s)
+    half = both()
+    knobs("TAPS_FULL", 1)
+    whole = both()
+    assert len(half) == 6 and all(torch.equal(a, b) for a, b in zip(half, whole))
