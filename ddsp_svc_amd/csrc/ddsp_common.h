@@ -146,6 +146,13 @@ struct BufF32 {
   __device__ __forceinline__ void st(float v, int byte_off) const {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 0);
   }
+  // the same with the non-temporal policy (aux bit 1): a stream this CU touches once
+  __device__ __forceinline__ float ld_nt(int byte_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 2));
+  }
+  __device__ __forceinline__ void st_nt(float v, int byte_off) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 2);
+  }
 };
 
 // A float64 through the DPP path of the vector ALU (two 32-bit moves): CTRL / ROW_MASK as in the ISA manual; lanes that the row mask

@@ -387,6 +387,35 @@ struct FirJob {
 struct FirJobs { FirJob j[2]; };
 
 template <bool RNG = false>
+// Cache policy of the kernel's input streams: every block, tap row and addend byte is read once by one CU, so they are loaded with the
+// non-temporal policy (aux bit 1 of the buffer instructions) instead of pushing each other and the next launch's inputs out of the L2;
+// the results keep the default policy (the next launch reads them).  [MI355X] CombSub step, same box, three interleaved repetitions
+// each: default policy 0.2884 ms | block loads 0.2838 | tap rows 0.2856 | stores 0.2877 | all three 0.2815 (r06_v41_bench_*.json);
+// on a second box 0.2972 | all three 0.2925 | + the addend 0.2890 | loads only 0.2901 (r06_v42_*); on a third 0.2862 | everything 0.2791 |
+// every load, default stores 0.2784 (r06_v43_*).  (A/B builds: -DDDSP_FIR_NT=<mask>: 1 block loads, 2 tap rows, 4 stores, 8 the addend.)
+#ifndef DDSP_FIR_NT
+#define DDSP_FIR_NT 11
+#endif
+#if DDSP_FIR_NT & 1
+#define FB_LD_X ld_nt
+#else
+#define FB_LD_X ld
+#endif
+#if DDSP_FIR_NT & 2
+#define FB_LD_T ld_nt
+#else
+#define FB_LD_T ld
+#endif
+#if DDSP_FIR_NT & 4
+#define FB_ST st_nt
+#else
+#define FB_ST st
+#endif
+#if DDSP_FIR_NT & 8
+#define FB_LD_A ld_nt
+#else
+#define FB_LD_A ld
+#endif
 __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g, NoiseGen rng) {
   const FirJob& J = jobs.j[blockIdx.y];
   const float* __restrict__ x = J.x;
@@ -439,7 +468,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     const int row = j < g.F ? j : g.F - 1;                     // core.py:167
     const BufF32 tr = BufF32::make(tb + (long)row * tap_ld, live ? tap_ld : 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) r.v[m] = tr.ld(tap_off[m]);
+    for (int m = 0; m < 4; ++m) r.v[m] = tr.FB_LD_T(tap_off[m]);
     return r;
   };
   struct Blk { float v[4]; };
@@ -453,7 +482,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     }
     const BufF32 xr = BufF32::make(xb + (long)bi * FB_HOP, bi < g.F && live ? FB_HOP : 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) r.v[m] = xr.ld(tid4 + 4 * P * m);
+    for (int m = 0; m < 4; ++m) r.v[m] = xr.FB_LD_X(tid4 + 4 * P * m);
     return r;
   };
   auto pack_taps = [&](const TapRow& ta, const TapRow& tb2, f32x2 (&z)[S]) {
@@ -611,7 +640,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
 #if defined(DDSP_B6_HALF_PASS_AHEAD)
     if (has_add && !warm) {
 #pragma unroll
-      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(t_off(i));
+      for (int i = 0; i < S; ++i) add[i] = add_buf.FB_LD_A(t_off(i));
     }
 #endif
     f32x2 zt[S];
@@ -628,17 +657,17 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
       for (int i = 0; i < S; ++i) d[i] = i < 4 ? z0[i].x - tail[i] : z0[i].x - z0[i - 4].y;
       if (has_plain) {
 #pragma unroll
-        for (int i = 0; i < S; ++i) plain_buf.st(sg * d[i], t_off(i));
+        for (int i = 0; i < S; ++i) plain_buf.FB_ST(sg * d[i], t_off(i));
       }
 #pragma unroll
-      for (int i = 0; i < S; ++i) out_buf.st(fmaf(sg, d[i], add[i]), t_off(i));
+      for (int i = 0; i < S; ++i) out_buf.FB_ST(fmaf(sg, d[i], add[i]), t_off(i));
       if (q == g.pairs - 1) {                                   // the last pair also emits the upper half of its second block
 #pragma unroll
         for (int m = 4; m < S; ++m) {
           const int off = t_off(4 + m);
           const float v = nsg * z0[m].y;
-          if (has_plain) plain_buf.st(v, off);
-          out_buf.st(v + (has_add ? add_buf.ld(off) : 0.f), off);
+          if (has_plain) plain_buf.FB_ST(v, off);
+          out_buf.FB_ST(v + (has_add ? add_buf.FB_LD_A(off) : 0.f), off);
         }
       }
     }
@@ -649,7 +678,7 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
       const int n0 = e0 + 2 * FB_HOP;                           // the next pass's first emitted time; negative only for b0 + 2 = 0
       const int nx_a = b0 + 2 > 0 ? 4 * n0 : BufF32::kOutOfRange, nx_b = 4 * n0 + 8 * P;
 #pragma unroll
-      for (int i = 0; i < S; ++i) add[i] = add_buf.ld(i < 2 ? nx_a + 4 * P * i : nx_b + 4 * P * (i - 2));
+      for (int i = 0; i < S; ++i) add[i] = add_buf.FB_LD_A(i < 2 ? nx_a + 4 * P * i : nx_b + 4 * P * (i - 2));
     }
 #endif
   }

@@ -40,6 +40,21 @@ __global__ void k_set_pfa_timeline(long long* p) { g_pfa_timeline = p; }
 
 namespace pfa {
 
+// the 16-byte store of four taps (A/B builds: -DDDSP_PFA_NT = with the non-temporal policy)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+#ifdef DDSP_PFA_NT
+  __builtin_nontemporal_store(v4f_t{a, b, c, d}, reinterpret_cast<v4f_t*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
+
+#ifdef DDSP_PFA_NT_LD
+#define PFA_LD(p) __builtin_nontemporal_load(p)
+#else
+#define PFA_LD(p) (*(p))
+#endif
 constexpr int NB = 256, NT = 510, HALF = 255;
 #ifndef DDSP_PFA_ROWS
 #define DDSP_PFA_ROWS 16
@@ -384,7 +399,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       if (live) {
         const float* src = a_re + gr * ld_re + k;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][e] = src[e];
+        for (int e = 0; e < 4; ++e) v[q][e] = PFA_LD(src + e);
         if (KIND == KIND_COMPLEX) {
           const float* si = a_im + gr * ld_im + k;
 #pragma unroll
@@ -552,7 +567,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
       if (ROWS % 4 != 0 && r >= ROWS) break;
       const float4 o = *reinterpret_cast<const float4*>(O + r * NB + j);
       const float w[4] = {wa.x, wa.y, wb.x, wb.y};          // (never MODE_DYNAMIC: that window is not even, launch_taps_pfa510)
-      if (r < left) *reinterpret_cast<float4*>(dst + r * NB + j) = make_float4(o.x * w[0], o.y * w[1], o.z * w[2], o.w * w[3]);
+      if (r < left) store4(dst + r * NB + j, o.x * w[0], o.y * w[1], o.z * w[2], o.w * w[3]);
     }
     PFA_STAMP(4);
     return;
@@ -579,7 +594,7 @@ __device__ __forceinline__ void taps_pfa510_body(const TapsJobs& jobs, const Exc
   auto put = [&](int it, const float (&ov)[4]) {
     const int i = 4 * (tid + 256 * it);
     if (i + 3 < total) {
-      *reinterpret_cast<float4*>(dst + i) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      store4(dst + i, ov[0], ov[1], ov[2], ov[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
