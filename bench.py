@@ -1759,6 +1759,9 @@ def main(argv=None):
                          "frac_alone": filt_bytes / (fir_ms * 1e-3) / 1e9 / 8000.0, "avg_ms_alone": fir_ms, "avg_ms": fir_ms,
                          "step_hbm_frac": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0,
                          "step_traffic_ratio": (tr["hbm_bytes"] / alg_bytes) if tr else None,
+                         # the bytes the step MOVES (PMC, intermediates included) over its time, against 8 TB/s: how close the step
+                         # as a whole sits to the memory roof (its kernels are issue-bound one by one, the step is not far from both)
+                         "step_traffic_hbm_frac": (tr["hbm_bytes"] / (ms * 1e-3) / 1e9 / 8000.0) if tr else None,
                          "in_step_kernels": instep,
                          "note": "frac = SURVEY 8-d algorithmic HBM bytes of what one launch of the dominant kernel processes / its "
                                  "average duration INSIDE the step (steady state) / 8 TB/s.  `bound` names the roof that binds the kernel: "
