@@ -18,7 +18,8 @@ thread_local int t_geometry_batch = 0;
 namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
-                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS", "TAPS_FULL"};
+                                            "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS", "TAPS_FULL",
+                                            "AP_BWD_SPLIT"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 // A knob whose kernel generation is not compiled into this build (the product library ships ONE generation per kernel; the
@@ -845,11 +846,12 @@ int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int
 }
 
 // ---- the backward pass of a fused CombSub tail call (solver.py:93-103: the same forward with gradients) --------------------
-// FOUR launches on the caller's stream, on the intermediates ddsp_hip_combsub_synth left in ITS workspace (ddsp_hip_tail_layout):
+// THREE launches on the caller's stream, on the intermediates ddsp_hip_combsub_synth left in ITS workspace (ddsp_hip_tail_layout):
 //     k_fir_blk_bwd<true>     harmonic filter: d h1 (input gradient) and d taps_h                  (vocoder.py:847-851 backwards)
 //     k_fir_blk_bwd6          all-pass filter's d taps (from d h1)  +  noise filter's d taps        (two jobs)
-//     k_taps_pfa510_bwd       the three tap-synthesis adjoints (dynamic window from f0, roll, Hann) (three jobs)
-//     k_allpass_backward_256  (d re, d im) -> d group-delay control
+//     k_taps_pfa510_bwd       the three tap-synthesis adjoints (dynamic window from f0, roll, Hann) (three jobs); the all-pass job
+//                             ends in the activation's adjoint, (d re, d im) -> d group-delay control, on its rows in LDS
+//                             (knob AP_BWD_SPLIT = 1: k_allpass_backward_256 as a launch of its own, the layout before)
 // g_harm / g_noise: the cotangents that reach the harmonic / the noise branch ([B,T]; NULL = none: that branch's gradients are
 // not touched).  ws: ddsp_hip_combsub_tail_backward_ws_bytes.
 size_t ddsp_hip_combsub_tail_backward_ws_bytes(int B, int F, int hop, int n_mag) {
@@ -906,13 +908,17 @@ int ddsp_hip_combsub_tail_backward(const float* f0_frames, const float* c_gd, lo
   }
   TapsBwdJobs jobs;
   jobs.n = 0;
+  const bool fuse_ap = (reinterpret_cast<uintptr_t>(d_gd) & 15) == 0 && knob(KNOB_AP_BWD_SPLIT) == 0;
   if (g_harm) {
     jobs.j[jobs.n++] = TapsBwdJob{1, 0, DDSP_HIP_MODE_DYNAMIC, dt_h, c_harm, ld_harm, 1.0f, nullptr, f0_frames, (float)sr, d_harm, nullptr};
-    jobs.j[jobs.n++] = TapsBwdJob{0, 1, DDSP_HIP_MODE_ROLL, dt_ap, nullptr, 0, 1.0f, nullptr, nullptr, 0.f, d_re, d_im};
+    // the all-pass activation's adjoint rides in that job's last stage (no d re / d im round trip, no fourth launch) when the
+    // control gradient can take its 16-byte stores
+    jobs.j[jobs.n++] = fuse_ap ? TapsBwdJob{0, 1, DDSP_HIP_MODE_ROLL, dt_ap, nullptr, 0, 1.0f, nullptr, nullptr, 0.f, d_re, d_im, c_gd, ld_gd, d_gd}
+                               : TapsBwdJob{0, 1, DDSP_HIP_MODE_ROLL, dt_ap, nullptr, 0, 1.0f, nullptr, nullptr, 0.f, d_re, d_im};
   }
   if (g_noise) jobs.j[jobs.n++] = TapsBwdJob{1, 0, DDSP_HIP_MODE_HANN, dt_nz, c_nz, ld_nz, 1.0f / 128.0f, nullptr, nullptr, 0.f, d_nz, nullptr};
   if (jobs.n && launch_taps_pfa510_bwd_jobs(jobs, table, (long)R, st) != 0) return DDSP_HIP_ESHAPE;
-  if (g_harm) launch_allpass_backward(c_gd, ld_gd, (long)R, n_mag, d_re, d_im, d_gd, st);
+  if (g_harm && !fuse_ap) launch_allpass_backward(c_gd, ld_gd, (long)R, n_mag, d_re, d_im, d_gd, st);
   return finish();
 }
 

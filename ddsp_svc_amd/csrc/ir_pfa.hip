@@ -807,6 +807,82 @@ __global__ void __launch_bounds__(256, 4) k_taps_pfa510_bwd(TapsBwdJobs jobs, lo
   }
   __syncthreads();
 
+  // ---- stage C with the all-pass activation's adjoint behind it (d_ap): the batch's (d re, d im) go to LDS row by row instead of
+  // to memory, then wave w takes rows 4w .. 4w+3, a lane owns four consecutive bins (the forward kernel's stage 0 backwards:
+  // theta_k = sum_{j<=k} pi tanh c_j in fixed-point revolutions, d theta_k = -sin theta_k d re_k + cos theta_k d im_k, and
+  // d c_j = pi (1 - tanh^2 c_j) sum_{k>=j} d theta_k, the suffix sum in float64 as k_allpass_backward_256 forms it) ----
+  if (J.d_ap) {                                             // workgroup-uniform
+    const int k = tid;
+    const int kn = k == 0 ? 0 : NT - k;
+    const float inv_n = 1.0f / (float)NT;
+    const float ce = (k == 0 || k == NB - 1) ? 0.5f * inv_n : inv_n;
+    const float ci = (k == 0 || k == NB - 1) ? 0.0f : inv_n;
+    float gre[ROWS], gim[ROWS];
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+      const f32x2 a = Out[t * NT + k], b = Out[t * NT + kn];
+      gre[2 * t] = ce * (a.x + b.x); gre[2 * t + 1] = ce * (-a.y - b.y);
+      gim[2 * t] = ci * (b.y - a.y); gim[2 * t + 1] = ci * (b.x - a.x);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const float* __restrict__ apc = J.ap_ctrl;
+    const long ld_ap = J.ld_ap;
+    float4 cq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                           // the wave's four control rows: in flight across the two barriers
+      const long gr = row0 + wave * 4 + q;
+      cq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < rows && wave * 4 + q < ROWS) {
+        const float* src = apc + gr * ld_ap + 4 * lane;
+        cq[q] = make_float4(src[0], src[1], src[2], src[3]);
+      }
+    }
+    __syncthreads();                                       // every thread holds its bins: Out becomes d re [16][256], d im [16][256]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) { U[r * NB + k] = gre[r]; U[(ROWS + r) * NB + k] = gim[r]; }
+    __syncthreads();
+    const double rev_fx = 683565275.57643158978229477;      // 2^32 / (2 pi): the forward kernel's phase, bit for bit
+    const double magic = 6755399441055744.0;                // 1.5 * 2^52
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                           // (unrolled: cq[q] stays in registers)
+      const int r = wave * 4 + q;
+      const long gr = row0 + r;
+      if (r >= ROWS || gr >= rows) break;                  // wave-uniform
+      const float4 rv = *reinterpret_cast<const float4*>(U + r * NB + 4 * lane);
+      const float4 iv = *reinterpret_cast<const float4*>(U + (ROWS + r) * NB + 4 * lane);
+      const float dr[4] = {rv.x, rv.y, rv.z, rv.w}, di[4] = {iv.x, iv.y, iv.z, iv.w};
+      const float th[4] = {tanh_hw(cq[q].x), tanh_hw(cq[q].y), tanh_hw(cq[q].z), tanh_hw(cq[q].w)};
+      unsigned s[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double m = fma((double)(kPiF * th[e]), rev_fx, magic);
+        const unsigned fx = (unsigned)__builtin_bit_cast(unsigned long long, m);
+        s[e] = e ? s[e - 1] + fx : fx;
+      }
+      const unsigned before = wave_incl_scan_u32(s[3]) - s[3];
+      float dth[4];
+      double dth_sum = 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float fr = (float)(int)(before + s[e]) * 2.3283064365386963e-10f;
+        const float co = __builtin_amdgcn_cosf(fr), si = __builtin_amdgcn_sinf(fr);
+        dth[e] = fmaf(-si, dr[e], co * di[e]);
+        dth_sum += (double)dth[e];
+      }
+      const double incl_before = wave_excl_scan(dth_sum, lane);
+      const double total = wave_sum(dth_sum);
+      double suffix = total - incl_before - dth_sum;
+      float o[4];
+#pragma unroll
+      for (int e = 3; e >= 0; --e) {
+        suffix += (double)dth[e];
+        o[e] = (float)suffix * (kPiF * (1.0f - th[e] * th[e]));
+      }
+      *reinterpret_cast<float4*>(J.d_ap + gr * NB + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
+
   // ---- stage C: separate the two rows of a transform, scale, activation derivative, coalesced stores (thread = bin) ----
   {
     const int k = tid;                                     // 0..255
@@ -844,7 +920,7 @@ int launch_taps_pfa510_bwd(const float* d_taps, const float* ctrl, long ld_ctrl,
   const int m = mode == pfa::MODE_HANN ? pfa::MODE_HANN : (mode == pfa::MODE_DYNAMIC ? pfa::MODE_DYNAMIC : pfa::MODE_ROLL);
   TapsBwdJobs jobs;
   jobs.n = 1;
-  jobs.j[0] = TapsBwdJob{act == 1 ? 1 : 0, has_im ? 1 : 0, m, d_taps, ctrl, ld_ctrl, scale, hann, half_width, 0.f, d_re, d_im};
+  jobs.j[0] = TapsBwdJob{act == 1 ? 1 : 0, has_im ? 1 : 0, m, d_taps, ctrl, ld_ctrl, scale, hann, half_width, 0.f, d_re, d_im, nullptr, 0, nullptr};
   jobs.j[1] = jobs.j[2] = jobs.j[0];
   hipLaunchKernelGGL(k_taps_pfa510_bwd, dim3((unsigned)((rows + pfa::ROWS - 1) / pfa::ROWS)), dim3(256), 0, st, jobs, rows);
   return 0;
@@ -856,6 +932,7 @@ int launch_taps_pfa510_bwd_jobs(const TapsBwdJobs& in, const float* table, long 
   TapsBwdJobs jobs = in;
   for (int i = 0; i < jobs.n; ++i) {
     if ((reinterpret_cast<uintptr_t>(jobs.j[i].d_taps) & 15) != 0) return -1;
+    if (jobs.j[i].d_ap && (!jobs.j[i].has_im || !jobs.j[i].ap_ctrl || (reinterpret_cast<uintptr_t>(jobs.j[i].d_ap) & 15) != 0)) return -1;
     jobs.j[i].hann = table + 2 * KP * NP;                   // the periodic Hann of the basis table (k_ir_table, ir.hip)
   }
   for (int i = jobs.n; i < 3; ++i) jobs.j[i] = jobs.j[0];

@@ -80,6 +80,10 @@ struct TapsBwdJob {
   const float* d_taps; const float* ctrl; long ld_ctrl; float scale;
   const float* hann; const float* half_width; float hw_sr;
   float* d_re; float* d_im;
+  // d_ap != null (a has_im job): the all-pass activation's adjoint (k_allpass_backward_256's arithmetic on the forward kernel's
+  // tanh and fixed-point phase) runs in the kernel's last stage on the batch's rows while they are in LDS: the job writes the
+  // gradient of the raw group-delay control ap_ctrl [rows, ld_ap] to d_ap [rows, 256] and d_re / d_im are not touched
+  const float* ap_ctrl; long ld_ap; float* d_ap;
 };
 struct TapsBwdJobs { TapsBwdJob j[3]; int n; };
 int launch_taps_pfa510_bwd_jobs(const TapsBwdJobs& jobs, const float* table, long rows, hipStream_t st);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 164          /* 0.1.6.4: the fused layouts keep the noise filter's (even) tap rows as their first half, knob TAPS_FULL; 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
+#define DDSP_HIP_VERSION 165          /* 0.1.6.5: ddsp_hip_combsub_tail_backward is three launches (the all-pass activation's adjoint in the tap adjoint's last stage), knob AP_BWD_SPLIT; 0.1.6.4: the fused layouts keep the noise filter's (even) tap rows as their first half, knob TAPS_FULL; 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -61,8 +61,9 @@ const char* ddsp_hip_error_string(int code);
  * two-wave kernel, kept for same-box A/B runs), SINS_NOSKIP (1 = the sinusoid bank also sums the harmonics that are masked
  * to 1e-7 in both frames of a hop), SMALL_PATH (1 = never take the fused launches of the streaming shapes, B F < 4096: the
  * batch layout at every size; the results are the same bits either way), TAPS_FULL (1 = the fused layouts keep the noise
- * filter's tap rows whole, [B,F,N], instead of their first N/2 + 1 taps -- an even response; same bits either way); the rest
- * are run lengths. */
+ * filter's tap rows whole, [B,F,N], instead of their first N/2 + 1 taps -- an even response; same bits either way),
+ * AP_BWD_SPLIT (1 = ddsp_hip_combsub_tail_backward runs the all-pass activation's adjoint as a launch of its own instead of
+ * in the last stage of the tap adjoint); the rest are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ddsp_hip_version() == 164
+    assert lib.ddsp_hip_version() == 165
 
 
 def test_argument_errors_are_reported_without_a_gpu():
