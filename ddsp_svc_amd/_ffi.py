@@ -33,6 +33,7 @@ SIGNATURES = {
     "ddsp_hip_allpass_taps": (c_int, [P, c_long, c_long, c_int, P, P, P, c_size_t, P]),
     "ddsp_hip_impulse_response_backward": (c_int, [P, P, c_long, c_int, c_float, c_int, P, c_long, c_int, P, P, P, P]),
     "ddsp_hip_allpass_backward": (c_int, [P, c_long, c_long, c_int, P, P, P, P]),
+    "ddsp_hip_allpass_taps_backward": (c_int, [P, P, c_long, c_long, c_int, P, P, P, P, P]),
     "ddsp_hip_fft_convolve": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "ddsp_hip_frequency_filter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ddsp_hip_frequency_filter": (c_int, [P, P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P,

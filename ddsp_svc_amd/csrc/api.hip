@@ -922,6 +922,30 @@ int ddsp_hip_combsub_tail_backward(const float* f0_frames, const float* c_gd, lo
   return finish();
 }
 
+// d taps [rows, 2 (n_mag - 1)] of the all-pass taps exp(1j cumsum(pi tanh c)) (vocoder.py:581,599 / :834,845 through core.py:254-270)
+// -> d c [rows, n_mag]: ddsp_hip_impulse_response_backward (MODE_ROLL, d_re + d_im) followed by ddsp_hip_allpass_backward -- as ONE
+// launch at 256 bins (the activation's adjoint in the tap adjoint's last stage: no d re / d im round trip); elsewhere the two
+// launches, through d_re_ws / d_im_ws ([rows, n_mag] each; DDSP_HIP_EWS when they are needed and NULL).
+int ddsp_hip_allpass_taps_backward(const float* d_taps, const float* c, long ld, long rows, int n_mag, const float* table,
+                                   float* d_c, float* d_re_ws, float* d_im_ws, void* stream) {
+  if (rows < 0 || n_mag < 2 || ld < n_mag) return DDSP_HIP_EINVAL;
+  if (rows == 0) return 0;
+  if (!d_taps || !c || !table || !d_c) return DDSP_HIP_EINVAL;
+  const TapsFormScope form;
+  if (n_mag == 256 && !t_taps_gemm && knob(KNOB_AP_BWD_SPLIT) == 0 && (reinterpret_cast<uintptr_t>(d_c) & 15) == 0) {
+    TapsBwdJobs jobs;
+    jobs.n = 1;
+    jobs.j[0] = TapsBwdJob{0, 1, DDSP_HIP_MODE_ROLL, d_taps, nullptr, 0, 1.0f, nullptr, nullptr, 0.f, nullptr, nullptr, c, ld, d_c};
+    if (launch_taps_pfa510_bwd_jobs(jobs, table, rows, S(stream)) == 0) return finish();
+  }
+  if (!d_re_ws || !d_im_ws) return DDSP_HIP_EWS;
+  const int rc = ddsp_hip_impulse_response_backward(d_taps, nullptr, 0, DDSP_HIP_ACT_NONE, 1.0f, DDSP_HIP_MODE_ROLL, nullptr, rows, n_mag,
+                                                    table, d_re_ws, d_im_ws, stream);
+  if (rc != 0) return rc;
+  launch_allpass_backward(c, ld, rows, n_mag, d_re_ws, d_im_ws, d_c, S(stream));
+  return finish();
+}
+
 int ddsp_hip_sins_synth(const float* f0_frames, const float* initial_phase, const double* phase0, const float* c_amp,
                         long ld_amp, const float* c_gd, long ld_gd, const float* c_nz, long ld_nz, const float* noise,
                         int noise_is_u01, int B, int F, int hop, double sr, int infer, int H, int n_ap, int n_nz,

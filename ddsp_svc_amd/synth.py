@@ -278,16 +278,7 @@ class AllpassTapsFunction(torch.autograd.Function):
     def backward(ctx, d_taps):
         (cc,) = ctx.saved_tensors
         B, F, n = cc.shape
-        dev = cc.device
-        d_re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
-        d_im = torch.empty_like(d_re)
-        d_c = torch.empty(B, F, n, dtype=torch.float32, device=dev)
-        g = _f32c(d_taps)
-        st = _ffi.stream_of(cc)
-        _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(g), None, 0, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
-                                                                 B * F, n, ptr(ir_table(n, dev)), ptr(d_re), ptr(d_im), st))
-        _ffi.check(_ffi.lib().ddsp_hip_allpass_backward(ptr(cc), ctx.ld, B * F, n, ptr(d_re), ptr(d_im), ptr(d_c), st))
-        return d_c
+        return _allpass_taps_bwd(_f32c(d_taps).view(B, F, 2 * (n - 1)), cc, ctx.ld)
 
 
 # ---- training through the FUSED tails (round 6): the forward pass of a training step is the inference call itself -------
@@ -338,13 +329,18 @@ def _allpass_taps_bwd(d_taps, c, ld):
     B, F, N = d_taps.shape
     n = N // 2 + 1
     dev = d_taps.device
-    d_re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
-    d_im = torch.empty_like(d_re)
     d_c = torch.empty(B, F, n, dtype=torch.float32, device=dev)
-    st = _ffi.stream_of(d_taps)
-    _ffi.check(_ffi.lib().ddsp_hip_impulse_response_backward(ptr(d_taps), None, 0, _ffi.ACT_NONE, 1.0, _ffi.MODE_ROLL, None,
-                                                             B * F, n, ptr(ir_table(n, dev)), ptr(d_re), ptr(d_im), st))
-    _ffi.check(_ffi.lib().ddsp_hip_allpass_backward(ptr(c), ld, B * F, n, ptr(d_re), ptr(d_im), ptr(d_c), st))
+
+    def call(d_re, d_im):
+        return _ffi.lib().ddsp_hip_allpass_taps_backward(ptr(d_taps), ptr(c), ld, B * F, n, ptr(ir_table(n, dev)), ptr(d_c),
+                                                         ptr(d_re), ptr(d_im), _ffi.stream_of(d_taps))
+    # one launch at 256 bins (the activation's adjoint in the tap adjoint's last stage); the other forms go through (d re, d im)
+    # and say so (DDSP_HIP_EWS = -4) when the scratch is missing
+    rc = call(None, None) if n == 256 else -4
+    if rc == -4:
+        d_re = torch.empty(B * F, n, dtype=torch.float32, device=dev)
+        rc = call(d_re, torch.empty_like(d_re))
+    _ffi.check(rc)
     return d_c
 
 

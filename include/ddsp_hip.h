@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_VERSION 165          /* 0.1.6.5: ddsp_hip_combsub_tail_backward is three launches (the all-pass activation's adjoint in the tap adjoint's last stage), knob AP_BWD_SPLIT; 0.1.6.4: the fused layouts keep the noise filter's (even) tap rows as their first half, knob TAPS_FULL; 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
+#define DDSP_HIP_VERSION 165          /* 0.1.6.5: + ddsp_hip_allpass_taps_backward; ddsp_hip_combsub_tail_backward is three launches (the all-pass activation's adjoint in the tap adjoint's last stage), knob AP_BWD_SPLIT; 0.1.6.4: the fused layouts keep the noise filter's (even) tap rows as their first half, knob TAPS_FULL; 0.1.6.3: + ddsp_hip_mel_shifted_* (get_mel with keyshift / speed / center, any transform length); 0.1.6.2: + ddsp_hip_tail_layout, ddsp_hip_combsub_tail_backward; the fused one-stream layout of the tails at every shape (knob STREAM_LAYOUT 1 / 4: the two-stream ones); knob BWD_WPS */
 
 #define DDSP_HIP_EINVAL   (-1)        /* bad size / null pointer */
 #define DDSP_HIP_EHOP     (-2)        /* hop > 2048: wave-per-frame phase scan does not cover it */
@@ -125,6 +125,12 @@ int ddsp_hip_window_impulse_response(const float* ir, int mode, const float* hal
                                      void* stream);
 int ddsp_hip_allpass_backward(const float* c, long ld, long rows, int n_mag, const float* d_re, const float* d_im,
                               float* d_c, void* stream);
+/* The two adjoints above back to back for the all-pass taps of vocoder.py:597-600 / :843-846 (what autograd returns for the raw
+ * group-delay control c [rows, ld] given d taps [rows, 2 (n_mag - 1)]): d_c [rows, n_mag].  ONE launch at 256 bins (d_c 16-byte
+ * aligned); elsewhere two launches through the scratch d_re_ws / d_im_ws ([rows, n_mag] each) -- DDSP_HIP_EWS when they are needed
+ * and NULL. */
+int ddsp_hip_allpass_taps_backward(const float* d_taps, const float* c, long ld, long rows, int n_mag, const float* table,
+                                   float* d_c, float* d_re_ws, float* d_im_ws, void* stream);
 
 /* ddsp/core.py:120-182  fft_convolve(audio[B,T], taps[B,F,N]) -> out[B,T]  (T = F*hop).
  * x_is_u01: the input is a raw U[0,1) draw and 2*u-1 is applied on load (vocoder.py:603,854);
@@ -213,7 +219,7 @@ int ddsp_hip_tail_layout(int combsub, int B, int F, int hop, int n0, int n1, int
                          long long offsets[6]);
 
 /* The backward pass of a fused ddsp_hip_combsub_synth call (256 / 256 / 256 bins, hop 512: where ddsp_hip_tail_layout returns 1) as
- * FOUR launches on `stream`: what autograd returns for the three raw controls of vocoder.py:834-862 given the cotangents that
+ * THREE launches on `stream`: what autograd returns for the three raw controls of vocoder.py:834-862 given the cotangents that
  * reach the harmonic branch (g_harm [B,T]: d signal + d harmonic) and the noise branch (g_noise [B,T]: d signal + d noise); either
  * may be NULL (that branch's gradients are not written).  fwd_ws is the forward call's workspace, untouched since; f0 / controls /
  * noise are that call's; table = the 256-bin basis table.  d_gd, d_harm, d_nz: [B,F,256] contiguous.  ws (16-byte aligned):

@@ -186,6 +186,44 @@ def test_allpass_backward_256_same_bits(dev):
     assert torch.equal(out_a, out_b) and float(out_a.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_allpass_taps_backward_one_launch(dev, knobs):
+    """ddsp_hip_allpass_taps_backward: at 256 bins the activation's adjoint runs in the tap adjoint's last stage (no scratch, any
+    row stride, a ragged last batch of rows) and agrees with the two launches it replaces (knob AP_BWD_SPLIT = 1, which then need
+    the scratch and say so) to rounding level and with the oracle's float64 adjoint; other bin counts need the scratch"""
+    from ddsp_svc_amd import _ffi, synth
+    from ddsp_svc_amd._ffi import ptr
+    rng = np.random.default_rng(5)
+    rows, n = 37, 256
+    N = 2 * (n - 1)
+    c = rng.standard_normal((rows, n)).astype(np.float32)
+    R = rng.standard_normal((rows, N)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    wide = torch.zeros(rows, n + 3, dtype=torch.float32, device=dev)
+    wide[:, :n] = t(c)
+    g, tab = t(R), synth.ir_table(n, dev)
+    lib, st = _ffi.lib(), _ffi.stream_of(g)
+    out, out_w, out_s = (torch.empty(rows, n, dtype=torch.float32, device=dev) for _ in range(3))
+    cc = t(c)
+    _ffi.check(lib.ddsp_hip_allpass_taps_backward(ptr(g), ptr(cc), n, rows, n, ptr(tab), ptr(out), None, None, st))
+    _ffi.check(lib.ddsp_hip_allpass_taps_backward(ptr(g), ptr(wide), n + 3, rows, n, ptr(tab), ptr(out_w), None, None, st))
+    assert torch.equal(out, out_w)
+    d_re, d_im = O.impulse_response_backward(R[None], O.MODE_ROLL)
+    want = O.allpass_backward(c[None], d_re, d_im)[0]
+    assert rms(out.cpu().numpy() - want) <= 2e-5 * rms(want)
+    knobs("AP_BWD_SPLIT", 1)
+    assert lib.ddsp_hip_allpass_taps_backward(ptr(g), ptr(cc), n, rows, n, ptr(tab), ptr(out_s), None, None, st) == -4
+    s1, s2 = torch.empty_like(out), torch.empty_like(out)
+    _ffi.check(lib.ddsp_hip_allpass_taps_backward(ptr(g), ptr(cc), n, rows, n, ptr(tab), ptr(out_s), ptr(s1), ptr(s2), st))
+    assert rms((out - out_s).cpu().numpy()) <= 2e-6 * rms(want)
+    knobs("AP_BWD_SPLIT", 0)
+    n2 = 129
+    g2 = t(rng.standard_normal((rows, 2 * (n2 - 1))).astype(np.float32))
+    c2 = t(rng.standard_normal((rows, n2)).astype(np.float32))
+    o2 = torch.empty(rows, n2, dtype=torch.float32, device=dev)
+    assert lib.ddsp_hip_allpass_taps_backward(ptr(g2), ptr(c2), n2, rows, n2, ptr(synth.ir_table(n2, dev)), ptr(o2), None, None, st) == -4
+
+
 # ---- tap synthesis backward + the CombSub training path ---------------------------------------------------------
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("n_mag,rows", [(256, 70), (129, 9), (65, 130), (5, 3)])
