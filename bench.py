@@ -483,7 +483,9 @@ def train_line(a, device, B, F, n, steps, warm):
     def step():
         st = synth.phase(f0, SR, HOP)
         sig = synth.combsub_synth(f0, st, c[0], c[1], c[2], noise, SR, HOP)[0]
-        return torch.autograd.grad((sig * R).sum(), c)
+        # the cotangent R is handed to autograd as a loss would hand it (the gradient of sum(signal * R), without timing torch's own
+        # multiply, reduction and two fills for that scalar: ~76 us that are neither the product nor the reference's)
+        return torch.autograd.grad(sig, c, grad_outputs=R)
     prewarm(step, min(a.prewarm_seconds, 0.3))
     el, ev_ms, grads = time_steps(step, steps, warm, torch.cuda.synchronize)
     t0 = time.perf_counter()
@@ -501,8 +503,9 @@ def train_line(a, device, B, F, n, steps, warm):
             "unit": "samples/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3, "ms_per_step_events": ev_ms,
             "dtype": "f32", "parity_vs_oracle": rec,
             "config": {"workload": "combsub B=%d x %.0f s (F=%d, T=%d), n_mag %d/%d/%d: phase + DSP tail forward, then "
-                                   "torch.autograd.grad of sum(signal * R) w.r.t. the three raw controls (solver.py:93-103's "
-                                   "use of the path, without the network and the loss)" % (B, a.seconds, F, T, n, n, n)}}
+                                   "torch.autograd.grad of signal w.r.t. the three raw controls with the cotangent R as grad_outputs "
+                                   "(= the gradient of sum(signal * R); solver.py:93-103's use of the path, without the network "
+                                   "and the loss)" % (B, a.seconds, F, T, n, n, n)}}
 
 
 def cfg4_line(a, rank, world, device, F, n, comm):
