@@ -80,6 +80,19 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
     }
     return r;
   };
+  // a thread's (filter, frame, quarter) tasks are the same for every pair: their band limits and weight offsets are fetched ONCE
+  // (up to four rounds of 256 tasks: 128 filters; more filters read them per pair as before)
+  constexpr int PRE = 4;
+  const bool pre = 8 * g.n_mels <= PRE * P;
+  int b_lo[PRE], b_hi[PRE], b_w[PRE];
+#pragma unroll
+  for (int r = 0; r < PRE; ++r) {
+    const int c = (r * P + tid) >> 3;
+    const bool in = pre && c < g.n_mels;
+    b_lo[r] = in ? band[4 * c] : 0;
+    b_hi[r] = in ? band[4 * c + 1] : 0;
+    b_w[r] = in ? band[4 * c + 2] : 0;
+  }
   Raw nxt = load_pair(p_first);
   for (int pr = p_first; pr < p_last; ++pr) {
     const int j0 = 2 * pr;
@@ -125,6 +138,25 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
     // banded mel projection (nvSTFT.py:115-116): four lanes per (filter, frame), every fourth bin of the band each; a round of
     // 256 lanes takes 32 consecutive filters of both frames, so its lanes' bands are about equally long (a Slaney band grows from
     // 2 to 90 bins across the filters: one thread per filter made every wave wait for the longest; 0.1217 -> 0.1209 ms, r06_v37_mel_quad.txt)
+    if (pre) {
+#pragma unroll
+      for (int r = 0; r < PRE; ++r) {
+        if (r * P >= 8 * g.n_mels) break;                       // workgroup-uniform
+        const int task = r * P + tid, part = task & 3, fc = task >> 2;
+        const int c = fc >> 1, h = fc & 1;
+        const bool on = c < g.n_mels && (h == 0 || live1);
+        float acc = 0.f;
+        if (on) {
+          const int lo = b_lo[r], hi = b_hi[r];
+          const float* mg = mags + h * MROW;
+          const float* wr = (g.packed_len > 0 ? wl + b_w[r] : basis + (long)c * BINS) - (g.packed_len > 0 ? lo : 0);
+          for (int k = lo + part; k < hi; k += 4) acc = fmaf(wr[k], mg[k], acc);
+        }
+        acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+        if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
+      }
+    } else
     for (int t0 = 0; t0 < 8 * g.n_mels; t0 += P) {
       const int task = t0 + tid, part = task & 3, fc = task >> 2;
       const int c = fc >> 1, h = fc & 1;
