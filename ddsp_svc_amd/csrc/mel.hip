@@ -62,9 +62,24 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
   // raw samples of a frame pair: issued unconditionally from clamped (reflected) addresses for the NEXT pair before
   // the current one is transformed, masked when used
   struct Raw { float v[S][2]; };
+  // (an INTERIOR pair -- both frames inside the signal, all but the first and the last of an utterance -- takes its 16 samples from
+  // one base address and instruction offsets; the reflected / clamped index arithmetic was ~130 of a pass's ~750 vector instructions)
+  auto interior = [&](int pr) -> bool {
+    const int s0 = 2 * pr * ME_HOP - PAD;
+    return s0 >= 0 && s0 + ME_HOP + N <= g.T;
+  };
   auto load_pair = [&](int pr) -> Raw {
     Raw r;
     const int s0 = 2 * pr * ME_HOP - PAD;
+    if (interior(pr)) {                                        // workgroup-uniform
+      const float* src = ab + s0 + tid;
+#pragma unroll
+      for (int m = 0; m < S; ++m) {
+        r.v[m][0] = src[P * m];
+        r.v[m][1] = src[ME_HOP + P * m];
+      }
+      return r;
+    }
 #pragma unroll
     for (int m = 0; m < S; ++m) {
 #pragma unroll
@@ -102,17 +117,22 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
     // the two windowed frames: j0 in the real, j0 + 1 in the imaginary part
     f32x2 z[S];
     const int s0 = j0 * ME_HOP - PAD;
+    if (interior(pr)) {
 #pragma unroll
-    for (int m = 0; m < S; ++m) {
-      float v[2];
+      for (int m = 0; m < S; ++m) z[m] = f32x2{w[m] * cr.v[m][0], w[m] * cr.v[m][1]};
+    } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int i = s0 + h * ME_HOP + P * m + tid;
-        // zero padding (constant mode) and the frame past the end of an odd count
-        const bool ok = (g.reflect || (i >= 0 && i < g.T)) && (h == 0 || live1);
-        v[h] = ok ? cr.v[m][h] : 0.f;
+      for (int m = 0; m < S; ++m) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int i = s0 + h * ME_HOP + P * m + tid;
+          // zero padding (constant mode) and the frame past the end of an odd count
+          const bool ok = (g.reflect || (i >= 0 && i < g.T)) && (h == 0 || live1);
+          v[h] = ok ? cr.v[m][h] : 0.f;
+        }
+        z[m] = f32x2{w[m] * v[0], w[m] * v[1]};
       }
-      z[m] = f32x2{w[m] * v[0], w[m] * v[1]};
     }
     f32x2* A = ex[cur];
     f32x2* Bx = ex[cur ^ 1];
@@ -130,8 +150,9 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
         const f32x2 zneg = Bx[(N - k) & (N - 1)];
         const f32x2 a2 = fft::add_conj(z[m], zneg);             // 2 X_j0[k]
         const f32x2 b2 = fft::sub_conj(z[m], zneg);             // 2i X_j0+1[k]
-        mags[k] = sqrtf(fmaf(0.25f * a2.x, a2.x, 0.25f * a2.y * a2.y) + 1e-9f);          // nvSTFT.py:108
-        mags[MROW + k] = sqrtf(fmaf(0.25f * b2.x, b2.x, 0.25f * b2.y * b2.y) + 1e-9f);
+        // (the hardware square root, 1 ulp: the correctly rounded one was ~20 instructions, ten times per thread and pair)
+        mags[k] = __builtin_amdgcn_sqrtf(fmaf(0.25f * a2.x, a2.x, 0.25f * a2.y * a2.y) + 1e-9f);          // nvSTFT.py:108
+        mags[MROW + k] = __builtin_amdgcn_sqrtf(fmaf(0.25f * b2.x, b2.x, 0.25f * b2.y * b2.y) + 1e-9f);
       }
     }
     __syncthreads();
