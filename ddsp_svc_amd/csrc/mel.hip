@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
         }
         acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
         acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-        if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
+        if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, g.clip));   // (hardware log2, 1 ulp)
       }
     } else
     for (int t0 = 0; t0 < 8 * g.n_mels; t0 += P) {
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, WPS) k_mel(const float* __restrict__ audi
       }
       acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
       acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-      if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = logf(fmaxf(acc, g.clip));
+      if (on && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(j0 + h) * g.sf] = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, g.clip));   // (hardware log2, 1 ulp)
     }
     // no barrier: the next transform writes Bx first (its readers are behind the barrier above) and A -- the
     // magnitudes -- only after its own first barrier, which every thread reaches after its projection loop

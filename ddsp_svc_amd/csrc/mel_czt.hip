@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64 * R, 2) k_mel_czt(const float* __restrict__
       for (int m = 0; m < 3; ++m) {
         const int k = P * m + tid;
         if (k < KT && k < g.bins_eff)
-          mags[e][k] = sqrtf(fmaf(acc[e][m].x, acc[e][m].x, acc[e][m].y * acc[e][m].y) + 1e-9f) * g.mag_scale;
+          mags[e][k] = __builtin_amdgcn_sqrtf(fmaf(acc[e][m].x, acc[e][m].x, acc[e][m].y * acc[e][m].y) + 1e-9f) * g.mag_scale;   // (hardware root, 1 ulp)
       }
       for (int k = g.bins_eff + tid; k < g.bins; k += P) mags[e][k] = 0.f;    // nvSTFT.py:110-113: zeros above the shifted Nyquist
     }
@@ -269,7 +269,9 @@ __global__ void __launch_bounds__(64 * R, 2) k_mel_czt(const float* __restrict__
         }
         a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
         a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-        if (c < g.n_mels && part == 0) out[(long)b * g.sb + (long)c * g.sm + (long)(f + e) * g.sf] = logf(fmaxf(a, g.clip));
+        // (the hardware logarithm, 1 ulp of log2: the whole wave paid libm's ~25 instructions for its 16 storing lanes)
+        if (c < g.n_mels && part == 0)
+          out[(long)b * g.sb + (long)c * g.sm + (long)(f + e) * g.sf] = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(a, g.clip));
       }
     }
     // no barrier: the next frames write mags (and ex[1], ex[3]) behind their transforms' barriers
