@@ -227,6 +227,15 @@ __device__ __forceinline__ float div_pos(float a, float b) {
   return fmaf(e, r, q0);
 }
 
+// tanh(x) = 1 - 2 / (exp(2 |x|) + 1) on the hardware exponential and reciprocal (1 ulp each), the sign copied back.  Absolute
+// error <= 1.5e-7 (rms 4e-8; ocml's tanhf: 6e-8 / 2e-8 at ~6 x the instructions and two divergent branches).  The all-pass group
+// delay pi tanh(c) (vocoder.py:581 / :834) and the NSF source's output activation (models.py:203) go through it.
+__device__ __forceinline__ float tanh_hw(float x) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.88539008f);        // exp(2 |x|); inf beyond 44: the quotient is 0
+  const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+  return copysignf(t, x);
+}
+
 // exp(x) on the hardware base-2 exponential: x log2(e) is split into its float32 rounding t and the residual r (two-constant
 // log2(e)), exp2(t) (1 + r ln 2).  Relative error ~1e-7 for |x| <= 80 (a bare exp2(x * log2e) is off by |x| * 6e-8); 3 fma / mul +
 // v_exp_f32 + 2 fma against the ~24 instructions of expf.  The control activations exp(c) of every module (vocoder.py:580, :603,

@@ -261,15 +261,8 @@ __device__ __forceinline__ void stage_window_rows(float* U, int lane, float hw) 
   if (lane == 0) U[HW_FLAG] = bad ? 1.0f : 0.0f;
 }
 
-// tanh(x) for the all-pass group delay pi tanh(c) (vocoder.py:581 / :834): 1 - 2 / (exp(2 |x|) + 1) on the hardware exponential
-// and reciprocal (1 ulp each), the sign copied back.  Absolute error <= 1.5e-7 (rms 4e-8; ocml's tanhf: 6e-8 / 2e-8 at ~6 x the
-// instructions and two divergent branches) -- what counts for a phase that is a SUM of these: 256 bins later 2e-6 rad rms, a
-// fifth of what the reference's own float32 rounding of that sum (ulp(100 rad) / 2 = 4e-6) does to it.
-__device__ __forceinline__ float tanh_hw(float x) {
-  const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.88539008f);        // exp(2 |x|); inf beyond 44: the quotient is 0
-  const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-  return copysignf(t, x);
-}
+// (tanh_hw, the all-pass group delay's hyperbolic tangent on the hardware units: ddsp_common.h; a sum of 256 of them is off by
+// 2e-6 rad rms, a fifth of what the reference's own float32 rounding of that sum -- ulp(100 rad) / 2 = 4e-6 -- does to it)
 
 // inclusive prefix sum of a 32-bit integer over the 64 lanes of a wave (the DPP steps of wave_incl_scan, ddsp_common.h)
 template <int CTRL, int ROW_MASK, bool BOUND>

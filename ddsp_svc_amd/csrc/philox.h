@@ -74,7 +74,7 @@ __device__ __forceinline__ Normal4 philox_normal4(const NoiseGen& g, unsigned ut
   for (int p = 0; p < 2; ++p) {
     const float u1 = (float)((x[2 * p] >> 8) + 1u) * 5.9604644775390625e-8f;
     const float u2 = (float)(x[2 * p + 1] >> 8) * 5.9604644775390625e-8f;
-    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // -2 ln 2 * log2(u1)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // -2 ln 2 * log2(u1); hardware root (1 ulp) behind the hardware log
     n.z[2 * p] = r * __builtin_amdgcn_cosf(u2);
     n.z[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);
   }

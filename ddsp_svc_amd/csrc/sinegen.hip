@@ -53,12 +53,14 @@ __global__ void __launch_bounds__(256) k_sinegen(const float* __restrict__ f0, c
                                                  const float* __restrict__ weight, const float* __restrict__ bias,
                                                  int L, int upp, float sr, float sine_amp, float noise_std,
                                                  float voiced_threshold, long total, float* __restrict__ out, NoiseGen rng) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  // grid (blocks of an utterance, utterance): no 64-bit division per thread (it was a fifth of the DRAW kernel's instructions)
   const long T = (long)L * upp;
-  const long b = i / T;
-  const int t = (int)(i - b * T);
-  const int l = t / upp, n = t - l * upp;
+  const long tl = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tl >= T) return;
+  const long b = blockIdx.y;
+  const long i = b * T + tl;
+  const unsigned t = (unsigned)tl;                                                   // T < 2^31 (launcher)
+  const int l = (int)(t / (unsigned)upp), n = (int)(t - (unsigned)l * (unsigned)upp);
   const float f = f0[b * L + l];
   float rad = (f / sr) * (float)(n + 1);                                             // models.py:141
   rad = rad + (l > 0 ? rad_acc[b * L + l - 1] : 0.0f);                               // models.py:144
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256) k_sinegen(const float* __restrict__ f0, c
     const float wave = (voiced ? s : 0.0f) + namp * nz[h];                           // models.py:166-167
     acc = fmaf(weight[h], wave, acc);                                                // models.py:203 (Linear)
   }
-  out[i] = tanhf(acc);                                                               // models.py:203 (Tanh)
+  out[i] = tanh_hw(acc);                                                             // models.py:203 (Tanh; hardware exponential, <= 1.5e-7)
 }
 
 // the draw of k_sinegen<DIM, true> written out: z[B, T, dim] (tests; callers that need the numbers themselves)
@@ -118,8 +120,10 @@ int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const 
                        float voiced_threshold, float* rad_acc, float* out, hipStream_t st, const NoiseGen* gen) {
   if (dim != 9 && dim != 1) return -1;
   const long total = (long)B * L * upp;
-  const long blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffL) return -1;
+  const long T = (long)L * upp;
+  if (T >= (1L << 31) || B > 65535) return -1;
+  if (total == 0) return 0;
+  const dim3 grid((unsigned)((T + 255) / 256), (unsigned)B);
   const bool draw = gen && gen->on;
   if (draw && ((long)L * upp >= (1L << 32) || (gen->offset >> 62) != 0)) return -1;
   if (!draw && !noise) return -1;
@@ -127,7 +131,7 @@ int launch_sine_source(const float* f0, int B, int L, int upp, double sr, const 
   if (draw) rng = *gen;
   hipLaunchKernelGGL(k_sinegen_scan, dim3((unsigned)B), dim3(256), 0, st, f0, L, upp, (float)sr, rad_acc);
 #define DDSP_SINEGEN(D, R)                                                                                                     \
-  hipLaunchKernelGGL((k_sinegen<D, R>), dim3((unsigned)blocks), dim3(256), 0, st, f0, rad_acc, rand_ini, noise, weight, bias, L, \
+  hipLaunchKernelGGL((k_sinegen<D, R>), grid, dim3(256), 0, st, f0, rad_acc, rand_ini, noise, weight, bias, L, \
                      upp, (float)sr, sine_amp, noise_std, voiced_threshold, total, out, rng)
   if (dim == 9) { if (draw) DDSP_SINEGEN(9, true); else DDSP_SINEGEN(9, false); }
   else { if (draw) DDSP_SINEGEN(1, true); else DDSP_SINEGEN(1, false); }
