@@ -392,9 +392,9 @@ class CombSubTailFunction(torch.autograd.Function):
             return (None,) * 10
         n = N // 2 + 1
         lib = _ffi.lib()
-        # four launches (csrc/api.hip, ddsp_hip_combsub_tail_backward): harmonic filter's adjoint | all-pass + noise filter tap
-        # gradients (two jobs) | the three tap-synthesis adjoints (three jobs; the dynamic window's half widths from f0 in the kernel) |
-        # all-pass activation
+        # three launches (csrc/api.hip, ddsp_hip_combsub_tail_backward): harmonic filter's adjoint | all-pass + noise filter tap
+        # gradients (two jobs) | the three tap-synthesis adjoints (three jobs; the dynamic window's half widths from f0 in the kernel,
+        # the all-pass activation's adjoint in that job's last stage)
         need = lib.ddsp_hip_combsub_tail_backward_ws_bytes(B, F, hop, n)
         bws = torch.empty(need, dtype=torch.uint8, device=dev)
         d_cg = torch.empty(B, F, n, dtype=torch.float32, device=dev) if gh is not None else None
