@@ -19,7 +19,7 @@ namespace {
 const char* const kKnobNames[KNOB_COUNT] = {"BLK_WPS", "BLK_RUN", "BLK_PADLDS", "FFT_RUN", "STFT_WPS", "STFT_RUN",
                                             "MEL_WPS", "MEL_RUN", "FIR_MAX_SLOTS", "SINS_V1", "TAPS_GEMM", "STREAM_LAYOUT",
                                             "BLK_TURNS", "CZT_ROUNDS", "CZT_TURNS", "SINS_NOSKIP", "SMALL_PATH", "LANE_ROWS", "LANES", "FIR_BWD_DIRECT", "BWD_WPS", "TAPS_FULL",
-                                            "AP_BWD_SPLIT"};
+                                            "AP_BWD_SPLIT", "SINS_SEQ"};
 std::atomic<long> g_knobs[KNOB_COUNT];
 std::once_flag g_knobs_once;
 // A knob whose kernel generation is not compiled into this build (the product library ships ONE generation per kernel; the
@@ -694,6 +694,15 @@ int sins_rows(const TailCall& a, SynthWs& w, hipStream_t st, void* aux_stream) {
     ok |= launch_taps_pfa510(a.c1, a.ld1, nullptr, 0, 1, DDSP_HIP_ACT_NONE, 1.0f, a.t1, DDSP_HIP_MODE_ROLL, nullptr, R, n_ap,
                              w.taps, st, 0.f, &jobs);
     if (ok != 0 || launch_taps_pfa510_batch(jobs, st) != 0) return DDSP_HIP_ESHAPE;
+    // The two filters as ONE launch: a workgroup runs the noise filter over its run of block pairs and then the all-pass filter over
+    // the same run, reading back as addend what it has just stored (k_fir_blk6<.., SEQ>: no second ramp and drain, the same bits).
+    // [MI355X] same box: the two launches 68.5 + 70.9 us -> one of ~128 (knob SINS_SEQ = 1: the two launches).  Not with the in-kernel
+    // draw, not at other tap counts than the noise filter's (one geometry per launch).
+    if (half && !a.gen.on && n_ap == n_nz && knob(KNOB_SINS_SEQ) != 1) {
+      const FirSecond second{w.buf0, 0, w.taps, nz, a.signal, a.harmonic, 0, 1};
+      if (launch_fir_blk(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), st, nullptr, &second, 1) >= 0)
+        return 0;
+    }
     if (half) {
       if (launch_fir_blk(a.noise, a.noise_is_u01, w.taps_nz, nullptr, nz, nullptr, B, F, hop, 2 * (n_nz - 1), st, &a.gen, nullptr, 1) < 0)
         return DDSP_HIP_ESHAPE;

@@ -386,7 +386,11 @@ struct FirJob {
 };
 struct FirJobs { FirJob j[2]; };
 
-template <bool RNG = false>
+// SEQ: ONE row of workgroups runs job 0 and then job 1 of a launch over the same run of block pairs -- for two filters of which the
+// second takes the first one's result as its addend (Sins: signal = all-pass(sinusoids) + filtered noise, vocoder.py:597-609).  A
+// thread reads back as addend exactly the samples it stored itself a sub-run earlier (the same kernel code maps the same times to
+// the same thread), so the hand-over needs no flag and no other workgroup: one barrier and one wait for the stores between the two.
+template <bool RNG = false, bool SEQ = false>
 // Cache policy of the kernel's input streams: every block, tap row and addend byte is read once by one CU, so they are loaded with the
 // non-temporal policy (aux bit 1 of the buffer instructions) instead of pushing each other and the next launch's inputs out of the L2;
 // the results keep the default policy (the next launch reads them).  [MI355X] CombSub step, same box, three interleaved repetitions
@@ -417,7 +421,10 @@ template <bool RNG = false>
 #define FB_LD_A ld
 #endif
 __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g, NoiseGen rng) {
-  const FirJob& J = jobs.j[blockIdx.y];
+  int jb = SEQ ? 0 : (int)blockIdx.y;
+seq_next:
+ {
+  const FirJob& J = jobs.j[jb];
   const float* __restrict__ x = J.x;
   const int x_is_u01 = J.x_is_u01;
   const bool draw = RNG && J.rng != 0;                      // workgroup-uniform
@@ -682,6 +689,13 @@ __global__ void __launch_bounds__(128, 3) k_fir_blk6(FirJobs jobs, FirBlkGeom g,
     }
 #endif
   }
+ }
+  if (SEQ && jb == 0) {                                        // job 1 over the same run: its addend is what this thread has just stored
+    jb = 1;
+    __builtin_amdgcn_s_waitcnt(0);                              // the stores have reached the L2
+    __syncthreads();                                            // every wave has left job 0's last exchange
+    goto seq_next;
+  }
 }
 
 // the same draw written out as a [B,T] tensor of u in [0,1) (tests, the oracle comparison, and callers whose noise filter
@@ -726,7 +740,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
   long per_utt = slots / (Bg > 0 ? Bg : 1);
   // two jobs share the one round of resident workgroups: runs twice as long, half the warm-up passes (at streaming shapes every
   // workgroup is resident anyway and the split stays what the one-job launches of the same shape use: same bits)
-  if (second && (long)Bg * F >= kSmallRows) per_utt = slots / (2 * (Bg > 0 ? Bg : 1));
+  if (second && !second->seq && (long)Bg * F >= kSmallRows) per_utt = slots / (2 * (Bg > 0 ? Bg : 1));
   if (per_utt < 1) per_utt = 1;
   int run = (int)((g.pairs + per_utt - 1) / per_utt);
   // at least three pairs per workgroup (each pays a warm-up block and its twiddles) -- except at streaming shapes, where every
@@ -766,6 +780,12 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
     }
 #endif
     hipLaunchKernelGGL((k_fir_blk6<true>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
+    return 5;
+  }
+  if (second && second->seq) {                                  // job 0, then job 1 (which reads job 0's result as its addend) in ONE row of workgroups
+    if (wps < 3 || (noise_gen && noise_gen->on)) return -1;
+    jobs.j[1] = FirJob{second->x, second->x_is_u01, second->taps, second->addend, second->out, second->out_plain, 0, second->taps_half};
+    hipLaunchKernelGGL((k_fir_blk6<false, true>), dim3((unsigned)wgs), dim3(128), 0, st, jobs, g, rng);
     return 5;
   }
   if (second && wps >= 3) {                                     // two independent filters of this shape in one launch

@@ -103,7 +103,9 @@ int launch_fir_fft(const float* x, int x_is_u01, const float* taps, const float*
 // taps_half: the tap rows are the first N/2 + 1 taps of an EVEN response (a zero-phase magnitude filter's under the Hann window:
 // tap N - j is tap j), [B, F, N/2 + 1] -- what launch_taps_pfa510(.., half_rows = 1) writes; the fused layouts of api.hip keep the
 // noise filter's taps so.  (NOT the harmonic filter's: the dynamic window clamps its upper side only, core.py:245, and is not even.)
-struct FirSecond { const float* x; int x_is_u01; const float* taps; const float* addend; float* out; float* out_plain; int taps_half; };
+// seq: the second filter runs BEHIND the first in the same workgroups (one row of them, the one-job launch's run split) and may take
+// the first one's result as its addend (k_fir_blk6<.., SEQ>); -1 with the in-kernel draw
+struct FirSecond { const float* x; int x_is_u01; const float* taps; const float* addend; float* out; float* out_plain; int taps_half; int seq = 0; };
 int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float* addend, float* out, float* out_plain,
                    int B, int F, int hop, int N, hipStream_t st, const NoiseGen* noise_gen = nullptr,
                    const FirSecond* second = nullptr, int taps_half = 0);

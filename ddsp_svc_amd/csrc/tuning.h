@@ -10,7 +10,7 @@ enum Knob {
   KNOB_BLK_WPS = 0, KNOB_BLK_RUN, KNOB_BLK_PADLDS, KNOB_FFT_RUN, KNOB_STFT_WPS, KNOB_STFT_RUN, KNOB_MEL_WPS,
   KNOB_MEL_RUN, KNOB_FIR_MAX_SLOTS, KNOB_SINS_V1, KNOB_TAPS_GEMM, KNOB_STREAM_LAYOUT, KNOB_BLK_TURNS, KNOB_CZT_ROUNDS, KNOB_CZT_TURNS,
   KNOB_SINS_NOSKIP, KNOB_SMALL_PATH, KNOB_LANE_ROWS, KNOB_LANES, KNOB_FIR_BWD_DIRECT, KNOB_BWD_WPS, KNOB_TAPS_FULL,
-  KNOB_AP_BWD_SPLIT,
+  KNOB_AP_BWD_SPLIT, KNOB_SINS_SEQ,
   KNOB_COUNT
 };
 

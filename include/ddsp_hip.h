@@ -63,7 +63,8 @@ const char* ddsp_hip_error_string(int code);
  * batch layout at every size; the results are the same bits either way), TAPS_FULL (1 = the fused layouts keep the noise
  * filter's tap rows whole, [B,F,N], instead of their first N/2 + 1 taps -- an even response; same bits either way),
  * AP_BWD_SPLIT (1 = ddsp_hip_combsub_tail_backward runs the all-pass activation's adjoint as a launch of its own instead of
- * in the last stage of the tap adjoint); the rest are run lengths. */
+ * in the last stage of the tap adjoint), SINS_SEQ (1 = the Sins tail's two filters as two launches instead of one whose workgroups
+ * run the noise filter and then the all-pass filter over the same samples; same bits); the rest are run lengths. */
 int ddsp_hip_set_tuning(const char* name, long value);
 long ddsp_hip_get_tuning(const char* name);
 

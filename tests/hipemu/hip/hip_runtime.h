@@ -197,6 +197,7 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) {
   return hipemu::peek<int>(s, lane);
 }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)  /* the emulator's memory is sequentially consistent per thread */
 #define __builtin_amdgcn_s_getreg(x) (0)          /* hardware status registers: placement only, never data */
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)

@@ -202,3 +202,25 @@ def test_half_tap_rows_of_the_noise_filter_same_bits(dev, B, F, knobs):
     knobs("TAPS_FULL", 1)
     whole = both()
     assert len(half) == 6 and all(torch.equal(a, b) for a, b in zip(half, whole))
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+@pytest.mark.parametrize("B,F", [(1, 9), (2, 40), (3, 1400)])
+def test_sins_filters_in_one_launch_same_bits(dev, B, F, knobs):
+    """The Sins tail's two filters are ONE launch whose workgroups run the noise filter over their run of block pairs and then the
+    all-pass filter over the same run, each thread reading back as addend the samples it has just stored (k_fir_blk6<.., SEQ>); knob
+    SINS_SEQ = 1: the two launches it replaces.  Same bits in all three outputs -- one pair per workgroup, odd frame counts, and a
+    batch shape whose runs have several pairs and a warm-up pass each."""
+    from ddsp_svc_amd import synth
+    arrays, tensors = _inputs(B, F, dev, seed=21 + F)
+    f0, cg, ch, cn, u = tensors
+    amps = torch.from_numpy(O.synth_controls(B, F, [64], seed=F + 1)[0]).to(dev)
+
+    def run():
+        st = synth.phase(f0, SR, HOP)
+        return list(synth.sins_synth(f0, st, amps, cg, cn, u, SR, HOP, noise_is_u01=True))
+    one = run()
+    knobs("SINS_SEQ", 1)
+    two = run()
+    assert len(one) == 3 and all(torch.equal(a, b) for a, b in zip(one, two))
+    assert float(one[0].abs().sum()) > 0 and torch.equal(one[0], two[0])
