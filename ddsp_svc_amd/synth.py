@@ -795,3 +795,67 @@ def combsubsuperfast_synth(f0_frames, state: FastSourceState, harmonic_magnitude
         ptr(f0), ptr(state.rad_acc), ptr(hm), ldhm, ptr(hp), ldhp, ptr(nm), ldnm, ptr(npz), ldnp, ptr(nz),
         ptr(_f32c(window)), win, B, F, hop, float(sampling_rate), ptr(signal), ptr(ws), need, _ffi.stream_of(f0)))
     return signal
+
+
+class StreamingCombSubSuperFast:
+    """The CombSubSuperFast tail for the real-time caller (gui.py:118-133 runs THIS model, configs/combsub.yaml:19): ``source``
+    and ``synth`` of one fixed shape with every buffer allocated and every pointer bound once, as ``StreamingCombSub`` -- a call
+    is two C calls (``ddsp_hip_fast_source`` before ``Unit2Control``, ``ddsp_hip_combsubsuperfast_synth`` behind it) and nothing
+    else on the host.  The numbers are those of ``fast_source`` + ``combsubsuperfast_synth`` bit for bit.  The returned tensors are
+    the session's own buffers (the next call overwrites them); one session per host thread / stream; float32 controls
+    ``[B, F, win // 2 + 1]`` with a contiguous last dimension and one uniform frame stride (``torch.split`` views are fine)."""
+
+    def __init__(self, B, F, window, sampling_rate, block_size, device):
+        self.B, self.F, self.hop, self.sr = int(B), int(F), int(block_size), float(sampling_rate)
+        dev = torch.device(device)
+        self.window = _f32c(window.to(dev))
+        self.win = self.window.numel()
+        self.n = self.win // 2 + 1
+        self.state = FastSourceState(torch.empty(B, F, dtype=torch.float32, device=dev),
+                                     torch.empty(B, F, 1, dtype=torch.float32, device=dev), None)
+        self._ws, self._need = _stft_ws(B, F, self.hop, dev)
+        self.signal = torch.empty(B, F * self.hop, dtype=torch.float32, device=dev)
+        self._lib = _ffi.lib()
+        _ffi.check_device(self.signal)
+        self._dev = self.signal.device
+        self._stream = _ffi.stream_of(self.signal)
+
+    def _f0(self, f0_frames):
+        if f0_frames.numel() != self.B * self.F or not f0_frames.is_contiguous() or f0_frames.dtype != torch.float32 \
+                or f0_frames.device != self._dev:
+            raise ValueError("StreamingCombSubSuperFast: f0_frames must be a contiguous float32 [%d, %d(, 1)] tensor on %s"
+                             % (self.B, self.F, self._dev))
+        if _ffi.stream_of(f0_frames) != self._stream:
+            raise RuntimeError("StreamingCombSubSuperFast: called on a stream other than the one the session was created on")
+        return f0_frames
+
+    def _ctrl(self, t, what):
+        if t.device != self._dev or t.dtype != torch.float32 or tuple(t.shape) != (self.B, self.F, self.n) or t.stride(2) != 1 \
+                or t.stride(1) < self.n or (self.B > 1 and t.stride(0) != self.F * t.stride(1)):
+            raise ValueError("StreamingCombSubSuperFast: %s must be a float32 [%d, %d, %d] tensor on %s with a contiguous last dimension "
+                             "and one uniform frame stride (got %s %s, strides %s)"
+                             % (what, self.B, self.F, self.n, self._dev, t.dtype, tuple(t.shape), tuple(t.stride())))
+        return t
+
+    def source(self, f0_frames):
+        """``fast_source`` into the session's state (what ``Unit2Control`` needs is ``.phase_frames``)"""
+        f0 = self._f0(f0_frames)
+        st = self.state
+        _ffi.check(self._lib.ddsp_hip_fast_source(f0.data_ptr(), self.B, self.F, self.hop, self.sr, st.rad_acc.data_ptr(),
+                                                  st.phase_frames.data_ptr(), None, self._stream))
+        return st
+
+    def synth(self, f0_frames, harmonic_magnitude, harmonic_phase, noise_magnitude, noise_phase, noise):
+        """``combsubsuperfast_synth`` on the session's state and buffers -> ``signal [B, T]``"""
+        f0 = self._f0(f0_frames)
+        hm, hp = self._ctrl(harmonic_magnitude, "harmonic_magnitude"), self._ctrl(harmonic_phase, "harmonic_phase")
+        nm, npz = self._ctrl(noise_magnitude, "noise_magnitude"), self._ctrl(noise_phase, "noise_phase")
+        if noise.device != self._dev or noise.dtype != torch.float32 or noise.numel() != self.B * self.F * self.hop \
+                or not noise.is_contiguous():
+            raise ValueError("StreamingCombSubSuperFast: noise must be a contiguous float32 [%d, %d] tensor on %s"
+                             % (self.B, self.F * self.hop, self._dev))
+        _ffi.check(self._lib.ddsp_hip_combsubsuperfast_synth(
+            f0.data_ptr(), self.state.rad_acc.data_ptr(), hm.data_ptr(), hm.stride(1), hp.data_ptr(), hp.stride(1), nm.data_ptr(),
+            nm.stride(1), npz.data_ptr(), npz.stride(1), noise.data_ptr(), self.window.data_ptr(), self.win, self.B, self.F, self.hop,
+            self.sr, self.signal.data_ptr(), self._ws.data_ptr(), self._need, self._stream))
+        return self.signal

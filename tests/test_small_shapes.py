@@ -183,6 +183,33 @@ def test_superfast_streaming_layout_same_bits(dev, B, F, knobs):
 
 
 @pytest.mark.parametrize("dev", BACKENDS, indirect=True)
+def test_superfast_streaming_session_same_bits(dev):
+    """synth.StreamingCombSubSuperFast (the model gui.py runs): every buffer allocated and every pointer bound once, a call = two C
+    calls -- the functional API's numbers bit for bit, call after call, split views accepted, what does not fit the bound shape refused"""
+    from ddsp_svc_amd import synth
+    B, F, n = 1, 47, 1025
+    w = torch.hann_window(2048).to(dev)
+    sess = synth.StreamingCombSubSuperFast(B, F, w, SR, HOP, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for seed in (1, 2):
+        f0 = t(O.synth_f0(B, F, SR, HOP, seed=60 + seed))
+        hm, hp, nm, nph = (t(c) for c in O.synth_controls(B, F, [n] * 4, seed=seed))
+        gz = t(O.synth_gauss(B, F * HOP, seed=seed + 2))
+        fs = synth.fast_source(f0, SR, HOP)
+        want = synth.combsubsuperfast_synth(f0, fs, hm, hp, nm, nph, gz, w, SR, HOP)
+        st = sess.source(f0)
+        assert torch.equal(st.rad_acc, fs.rad_acc) and torch.equal(st.phase_frames, fs.phase_frames)
+        assert torch.equal(sess.synth(f0, hm, hp, nm, nph, gz), want)
+    v = torch.split(torch.cat([hm, hp, nm, nph], -1), [n] * 4, -1)            # Unit2Control's split views: frame stride 4100
+    assert torch.equal(sess.synth(f0, v[0], v[1], v[2], v[3], gz), want)
+    for bad in (lambda: sess.synth(f0, hm[:, :-1], hp, nm, nph, gz), lambda: sess.synth(f0, hm[..., :1024], hp, nm, nph, gz),
+                lambda: sess.synth(f0, hm.double(), hp, nm, nph, gz), lambda: sess.synth(f0, hm, hp, nm, nph, gz[:, :-512]),
+                lambda: sess.source(f0[:, :-1])):
+        with pytest.raises(ValueError):
+            bad()
+
+
+@pytest.mark.parametrize("dev", BACKENDS, indirect=True)
 @pytest.mark.parametrize("B,F", [(1, 33), (5, 820)])
 def test_half_tap_rows_of_the_noise_filter_same_bits(dev, B, F, knobs):
     """The fused layouts keep the noise filter's tap rows -- a zero-phase response under the Hann window: even, tap N - j is tap j --

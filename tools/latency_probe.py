@@ -68,6 +68,33 @@ for kind in ("combsub", "sins", "combsubsuperfast"):
         except Exception as e:
             line += "; graph capture failed: %s: %s" % (type(e).__name__, str(e)[:120])
         print(line, flush=True)
+        if kind == "combsubsuperfast":                           # the allocation-free session of the model gui.py runs
+            f0, (hm, hp, nm, nph), gz, w = inp["f0"], inp["ctrls"], inp["noise"], inp["window"]
+            sess = synth.StreamingCombSubSuperFast(B, F, w, SR, HOP, dev)
+
+            def fstep():
+                sess.source(f0)
+                return sess.synth(f0, hm, hp, nm, nph, gz)
+            same = bool(torch.equal(fstep(), step()))
+            us2 = timeit(fstep)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                fstep()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            print("%-17s B=%d %.2f s (F=%d): StreamingCombSubSuperFast session %.1f us back to back, %.1f us call-to-result, same bits %s"
+                  % (kind, B, seconds, F, us2, sorted(lat)[len(lat) // 2] * 1e6, same), flush=True)
+            lat = []
+            sess.source(f0)
+            for _ in range(50):
+                t0 = time.perf_counter()
+                sess.synth(f0, hm, hp, nm, nph, gz)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            print("%-17s B=%d %.2f s (F=%d): session, DSP tail alone %.1f us call-to-result" % (kind, B, seconds, F, sorted(lat)[len(lat) // 2] * 1e6),
+                  flush=True)
         if kind == "combsub":                                    # the allocation-free session: the same two C calls, nothing else on the host
             f0, (cg, ch, cn), u = inp["f0"], inp["ctrls"], inp["noise"]
             sess = synth.StreamingCombSub(B, F, 256, 256, 256, SR, HOP, dev)
