@@ -291,3 +291,30 @@ def test_fir_adjoints_full_size(cuda, batch, n_taps):
         finally:
             _ffi.set_tuning("FIR_BWD_DIRECT", 0)
         assert rms(dxd - dx) <= 5e-6 * rms(dxd) and rms(dtd - dt) <= 5e-6 * rms(dtd)
+
+
+def test_sins_one_launch_filters_fullsize_repeat(cuda, batch, knobs):
+    """The Sins tail's filters as ONE launch (k_fir_blk6<.., SEQ>: a thread of the all-pass sub-run reads back as addend what it stored
+    in the noise sub-run, ordered by the thread's own wait for its stores) at the BASELINE shape, many times over, with other work
+    thrashing the caches in between: every repetition is the two-launch form's result bit for bit -- a hand-over that could ever see a
+    stale sample would show here"""
+    from ddsp_svc_amd import synth
+    f0, (cg, _, cn), noise = batch
+    amps = torch.randn(B, F, 256, generator=torch.Generator().manual_seed(11)).to(cuda)
+    u = (noise + 1) / 2
+
+    def run():
+        st = synth.phase(f0, SR, HOP)
+        return synth.sins_synth(f0, st, amps, cg, cn, u, SR, HOP, noise_is_u01=True)
+    knobs("SINS_SEQ", 1)
+    want = [t.clone() for t in run()]
+    knobs("SINS_SEQ", 0)
+    filler = torch.empty(64 << 20, dtype=torch.float32, device=cuda)
+    bad = torch.zeros((), dtype=torch.int64, device=cuda)
+    for rep in range(60):
+        if rep % 3 == 0:
+            filler.fill_(float(rep))                                  # 256 MB through the L2s and the memory-side cache
+        got = run()
+        for a, b in zip(got, want):
+            bad += (a != b).sum()
+    assert int(bad) == 0
