@@ -760,6 +760,7 @@ int launch_fir_blk(const float* x, int x_is_u01, const float* taps, const float*
 #endif
   jobs.j[0] = FirJob{x, x_is_u01, taps, addend, out, out_plain, 0, taps_half};
   jobs.j[1] = jobs.j[0];
+  if (second && second->seq && noise_gen && noise_gen->on) return -1;   // (the chained form has no in-kernel draw)
   if (noise_gen && noise_gen->on && second) {                   // two jobs, the SECOND one's input drawn in the kernel (its x may be null)
 #ifdef DDSP_AB_GENERATIONS
     if (wps < 3) return -1;
