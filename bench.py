@@ -520,7 +520,7 @@ def cfg4_line(a, rank, world, device, F, n, comm):
     T = F * HOP
     if not a.cfg4_keep_cache and hasattr(RT, "empty_cache"):
         RT.empty_cache()                 # the headline's cached blocks go back to the driver: this line's buffers get fresh segments
-    step, _ = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
+    step, inp4 = build_step("combsub", B4, F, n, device, seed=9000 + rank, fir_impl=a.fir_impl)
     per = max(2, min(a.cfg4_round_steps, a.steps))
     rounds = 6 if a.steps >= 20 else 2
     if not dist.is_initialized() and world == 1 and not a.no_cfg4_gather:
@@ -574,8 +574,38 @@ def cfg4_line(a, rank, world, device, F, n, comm):
             pending[0]()
             pending[0] = None
         fence()
+
+    # the gather WITHOUT a copy of the rank's own shard: the receiving rank keeps the result tensor from step to step and its
+    # synthesis writes its waveforms straight into its slice of it (synth.combsub_synth(signal_out=), gather_utterances(out=)):
+    # nothing moves at one rank; at N ranks rank 0 saves the 113 MB device-to-device copy of its own shard
+    from ddsp_svc_amd import synth as _synth
+    result = [None]
+
+    def step_in_place():
+        if rank == 0 and result[0] is None:
+            result[0] = torch.empty(B4 * world, T, dtype=torch.float32, device=device)
+        f0, c, nzz = inp4["f0"], inp4["ctrls"], inp4["noise"]
+        st = _synth.phase(f0, SR, HOP)
+        mine = result[0][rank * B4:(rank + 1) * B4] if rank == 0 else None
+        y = _synth.combsub_synth(f0, st, c[0], c[1], c[2], nzz, SR, HOP, want_components=False, fir_impl=a.fir_impl, signal_out=mine)[0]
+        return sharding.gather_utterances(y, B4 * world, dst=0, out=result[0])
     prewarm(step, min(a.prewarm_seconds, 0.3))
     forms = [("plain", step, fence)] + ([("gather", step_g, fence), ("gather_async", step_async, fence_g)] if have_pg else [])
+    if have_pg:
+        failed = 0.0
+        try:                                                             # a form that fails costs its column, not the line
+            chk = step_in_place()
+            fence()
+            ref = step()                                                 # (every rank: the fences are collective)
+            fence()
+            if rank == 0:
+                assert chk is result[0] and torch.equal(chk[:B4], ref), "in-place gather: rank 0's slice is not the step's output"
+        except Exception as e:                                           # noqa: BLE001
+            failed = 1.0
+            comm["cfg4_in_place_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+        (failed,) = reduce_max(failed)                                   # every rank times the same forms
+        if failed == 0.0:
+            forms.append(("gather_in_place", step_in_place, fence))
     wall = {k: [] for k, _, _ in forms}
     ev = {k: [] for k, _, _ in forms}
     for _, fn, fc in forms:                                              # warm-up of every form (allocator, communicator buffers)
@@ -617,6 +647,13 @@ def cfg4_line(a, rank, world, device, F, n, comm):
                     "ms_per_step_with_gather_async": med(wall["gather_async"]),
                     "gather_async_overhead_ms": med([g - p for g, p in zip(wall["gather_async"], wall["plain"])]),
                     "gather_bytes_per_rank": 4.0 * B4 * T,
+                    "ms_per_step_with_gather_in_place": med(wall["gather_in_place"]) if "gather_in_place" in wall else None,
+                    "gather_in_place_overhead_ms": med([g - p for g, p in zip(wall["gather_in_place"], wall["plain"])])
+                    if "gather_in_place" in wall else None,
+                    "gather_in_place": "the receiving rank keeps the result tensor from step to step and its synthesis writes its "
+                                       "own shard straight into its slice (signal_out= / out=): no copy of the local shard -- at one "
+                                       "rank nothing moves" + ("" if "gather_in_place" in wall else
+                                                                "; NOT timed: %s" % comm.get("cfg4_in_place_error")),
                     "gather": "torch.distributed.gather (%s) of every step's [%d, T] waveforms into slices of the "
                               "result on rank 0, waited for before the next step starts; *_async: step k's gather issued async, "
                               "running under step k + 1's synthesis and waited for one step later (the last one inside the timed "

@@ -27,7 +27,8 @@ def take_shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[lo:hi]
 
 
-def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0, group=None, async_op: bool = False):
+def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0, group=None, async_op: bool = False,
+                      out: Optional[torch.Tensor] = None):
     """Collect the per-rank ``[b_local, T]`` waveforms into ``[n_total, T]``.
 
     ``dst=None`` -> all-gather (every rank gets the batch); otherwise only the rank whose rank INSIDE ``group`` is
@@ -35,6 +36,11 @@ def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0,
     ``gather`` whose receive buffers are slices of the result tensor (no second copy on the root); ragged shards are
     padded to the largest shard (at most one utterance of padding per rank).  On an 8-GPU MI355X node each peer's shard
     travels over its own xGMI link, so the gather is link-parallel; no ring is forced.
+
+    ``out`` (equal shards only): the result tensor ``[n_total, T]`` of a receiving rank, kept by the caller from step to step.  A
+    rank whose ``local`` IS its slice of it (``out[rank * b : (rank + 1) * b]`` -- e.g. the synthesis was handed that slice as
+    ``signal_out``) sends from there: its own shard is never copied (RCCL's in-place all-gather; a root's own slot of a gather),
+    and with one rank nothing moves at all.
 
     ``async_op=True`` returns ``(finish, work)`` instead: the collective is enqueued and ``finish()`` waits for it and
     returns the tensor (or None) -- a caller that synthesises in chunks can enqueue the gather of chunk i and start
@@ -55,8 +61,18 @@ def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0,
         pad = torch.zeros(mx - send.shape[0], T, dtype=send.dtype, device=send.device)
         send = torch.cat([send, pad], 0)
     receiver = dst is None or rank == dst
-    out = torch.empty(world * mx, T, dtype=send.dtype, device=send.device) if receiver else None
-    if dst is None:
+    in_place = False
+    if out is not None and receiver:
+        if any(c != mx for c in counts):
+            raise ValueError("out= needs equal shards")
+        if tuple(out.shape) != (world * mx, T) or out.dtype != send.dtype or out.device != send.device or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [%d, %d] tensor of the shards' dtype on their device" % (world * mx, T))
+        in_place = send.data_ptr() == out[rank * mx:(rank + 1) * mx].data_ptr()
+    else:
+        out = torch.empty(world * mx, T, dtype=send.dtype, device=send.device) if receiver else None
+    if world == 1 and in_place:
+        work = None                                              # the one shard is already where the result lives
+    elif dst is None:
         work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
     else:
         bufs = [out[r * mx:(r + 1) * mx] for r in range(world)] if receiver else None

@@ -511,7 +511,7 @@ def _sins_synth_train(f0_frames, state, amplitudes, group_delay, noise_magnitude
 
 def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude, noise_magnitude, noise,
                   sampling_rate, block_size, noise_is_u01=False, want_components=True, fir_impl=_ffi.FIR_AUTO,
-                  noise_seed=None, noise_offset=0):
+                  noise_seed=None, noise_offset=0, signal_out=None):
     """DSP tail of ``CombSub.forward`` (vocoder.py:834-862) from raw controls; ``noise=None``: the uniform draw happens
     inside the noise filter from ``(noise_seed, noise_offset)`` (see ``sins_synth``).  With gradients enabled and a control
     that requires grad the differentiable composition is used (the filters at every hop and bin count; their fast adjoint kernels at hop 512, n_mag <= 257)."""
@@ -545,6 +545,12 @@ def combsub_synth(f0_frames, state: PhaseState, group_delay, harmonic_magnitude,
     nz, is_u01, seed, offset = _noise_arg(noise, noise_seed, noise_offset, noise_is_u01, B, T, hop, n_nz, fir_impl, dev)
     ws, need = _workspace(B, F, hop, max(n_ap, n_h, n_nz), dev)
     signal, harm, nzo = _outputs(B, T, dev, want_components)
+    if signal_out is not None:
+        # (inference only) the waveform goes where the caller wants it -- e.g. this rank's slice of a gather's result tensor
+        # (sharding.gather_utterances(out=)): no copy between the synthesis and the collective
+        if tuple(signal_out.shape) != (B, T) or signal_out.dtype != torch.float32 or signal_out.device != dev or not signal_out.is_contiguous():
+            raise ValueError("signal_out must be a contiguous float32 [%d, %d] tensor on %s" % (B, T, dev))
+        signal = signal_out
     _ffi.check(_ffi.lib().ddsp_hip_combsub_synth(
         ptr(f0), ptr(state.initial_phase), ptr(state.phase0), ptr(cg), ldg, ptr(ch), ldh, ptr(cn), ldn,
         ptr(nz), int(is_u01), B, F, hop, float(sampling_rate), int(state.infer), n_ap, n_h, n_nz,

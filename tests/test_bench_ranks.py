@@ -138,6 +138,9 @@ def test_two_ranks_step_reduce_and_emit():
     for k in ("ms_per_step", "ms_per_step_with_gather", "gather_ms", "value", "value_with_gather"):
         assert c0[k] == c1[k] and c0[k] > 0, (k, c0[k], c1[k])
     assert c0["n_gpus"] == 2 and c0["batch_per_gpu"] == 2 and c0.get("gather_checked_rows") == 4 and "gather_checked_rows" not in c1
+    # ... and the gather without a copy of the local shard ran on both ranks (rank 0's synthesis wrote into its slice of the result)
+    assert "cfg4_in_place_error" not in r0["comm"] and "cfg4_in_place_error" not in r1["comm"], (r0["comm"], r1["comm"])
+    assert c0["ms_per_step_with_gather_in_place"] == c1["ms_per_step_with_gather_in_place"] and c0["ms_per_step_with_gather_in_place"] > 0
     T = (int(0.03 * 44100) // 512 + 1) * 512
     assert abs(c0["value"] - 2 * 2 * T * c0["steps"] / (c0["ms_per_step"] * 1e-3 * c0["steps"])) <= 1e-6 * c0["value"]
 

@@ -55,6 +55,51 @@ def test_gather_world2_gloo(n_total, dst):
     assert all(ok for _, ok in res), res
 
 
+def _worker_in_place(rank, world, port, n_total, dst, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1 or True:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ddsp_svc_amd.sharding import gather_utterances, shard_bounds
+    T = 6
+    full = torch.arange(n_total * T, dtype=torch.float32).reshape(n_total, T)
+    receiver = dst is None or rank == dst
+    lo, hi = shard_bounds(n_total, rank, world)
+    ok = True
+    for step in range(2):                                   # the result tensor is kept from step to step
+        if receiver:
+            if step == 0:
+                out = torch.full((n_total, T), -1.0)
+            local = out[lo:hi]                              # the "synthesis" writes this rank's waveforms straight into its slice
+            local.copy_(full[lo:hi] + step)
+        else:
+            out, local = None, full[lo:hi] + step
+        got = gather_utterances(local, n_total, dst=dst, out=out)
+        if receiver:
+            ok = ok and got is out and torch.equal(got, full + step)
+        else:
+            ok = ok and got is None
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,dst", [(2, 8, 0), (2, 8, None), (1, 4, 0), (1, 4, None)])
+def test_gather_into_the_callers_result_tensor_gloo(world, n_total, dst):
+    """gather_utterances(out=): a receiving rank whose shard IS its slice of the result tensor (the synthesis wrote it there,
+    synth.combsub_synth(signal_out=)) sends from there -- no copy of its own shard, nothing at all with one rank -- and the result is
+    the caller's tensor, step after step"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + world * 11 + n_total * 7 + (0 if dst is None else 3)) % 2000
+    procs = [ctx.Process(target=_worker_in_place, args=(r, world, port, n_total, dst, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
 def _emu_backend():
     """what tests/backends.py's ``emu`` fixture does, for a spawned worker process"""
     import ctypes
