@@ -75,7 +75,9 @@ def gather_utterances(local: torch.Tensor, n_total: int, dst: Optional[int] = 0,
     elif dst is None:
         work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
     else:
-        bufs = [out[r * mx:(r + 1) * mx] for r in range(world)] if receiver else None
+        # (in place: the root's own slot is the very tensor it sends -- the backend's copy of a root's own shard is then a copy of a
+        # tensor onto itself, which torch skips, not a device copy between two views of the same memory)
+        bufs = [send if (in_place and r == rank) else out[r * mx:(r + 1) * mx] for r in range(world)] if receiver else None
         # torch.distributed addresses the destination by GLOBAL rank; translate the group-local one
         gdst = dist.get_global_rank(group, dst) if group is not None else dst
         work = dist.gather(send, bufs, dst=gdst, group=group, async_op=async_op)
